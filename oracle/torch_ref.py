@@ -1,0 +1,296 @@
+"""ORACLE (test infrastructure, never shipped, never on the product path).
+
+CPU restatement, in torch fp32 ops + autograd, of the op sequences wildltr/ptranking executes
+for the ltr_adhoc loss / metric hot path.  The reference's arithmetic lives in PyTorch ATen CPU
+kernels, so the closest possible CPU "port" is the same ATen ops in the same
+order: sigmoid rounding, binary_cross_entropy's -100 log clamp and 1e-12 backward epsilon,
+pow-with-tensor-exponent, cumsum order etc. are inherited from torch rather than re-derived.
+
+Parity pin: tests/test_oracle_golden.py checks every function here against tests/golden/*.npz,
+which tests/golden/make_golden.py produced by running the reference itself (incl. the five
+known-answer vectors of the reference's testing/metric/testing_metric.py).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+Each function cites the reference file:line it follows.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+EPS_LAMBDALOSS = 1e-8  # ptranking/ltr_global.py:10
+
+
+# --------------------------------------------------------------------------- helpers
+def _gain(labels):
+    """2^l - 1 (MultiLabel gains), ptranking/metric/adhoc/adhoc_metric.py:208-209."""
+    return torch.pow(2.0, labels) - 1.0
+
+
+def dcg_full(rankings):
+    """DCG over the whole list -> [B,1]; ptranking/metric/adhoc/adhoc_metric.py:197-217 (cutoff=None)."""
+    L = rankings.size(1)
+    disc = torch.log2(torch.arange(L, dtype=torch.float32) + 2.0)
+    return torch.sum(_gain(rankings) / disc, dim=1, keepdim=True)
+
+
+def _pairwise(preds, labels, sigma):
+    """s_ij, p_ij, target p̄_ij; ptranking/ltr_adhoc/util/lambda_utils.py:5-23."""
+    s_ij = preds.unsqueeze(2) - preds.unsqueeze(1)
+    p_ij = torch.sigmoid(sigma * s_ij)
+    S_ij = torch.clamp(labels.unsqueeze(2) - labels.unsqueeze(1), min=-1.0, max=1.0)
+    return p_ij, 0.5 * (1.0 + S_ij)
+
+
+def _delta_ndcg(ideal, ranked):
+    """|ΔnDCG| of swapping two predicted positions; ptranking/metric/metric_utils.py:19-45."""
+    G = _gain(ranked) / dcg_full(ideal)
+    dG = G.unsqueeze(2) - G.unsqueeze(1)
+    D = 1.0 / torch.log2(torch.arange(ranked.size(1), dtype=torch.float32) + 2.0)
+    dD = D.view(1, -1, 1) - D.view(1, 1, -1)
+    return torch.abs(dG) * torch.abs(dD)
+
+
+# --------------------------------------------------------------------------- losses (autograd)
+def ranknet_loss(preds, labels, sigma=1.0):
+    """ptranking/ltr_adhoc/pairwise/ranknet.py:32-36 — unweighted BCE over the upper triangle, input order."""
+    p, t = _pairwise(preds, labels, sigma)
+    l = F.binary_cross_entropy(torch.triu(p, 1), torch.triu(t, 1), reduction="none")
+    return l.sum()
+
+
+def lambdarank_loss(preds, labels, sigma=1.0):
+    """ptranking/ltr_adhoc/listwise/lambdarank.py:39-56 — labels must be in ideal (descending) order."""
+    sp, idx = torch.sort(preds, dim=1, descending=True)
+    ranked = torch.gather(labels, 1, idx)
+    p, t = _pairwise(sp, ranked, sigma)
+    w = _delta_ndcg(labels, ranked)
+    l = F.binary_cross_entropy(torch.triu(p, 1), torch.triu(t, 1), weight=torch.triu(w, 1), reduction="none")
+    return l.sum()
+
+
+def lambdaloss_loss(preds, labels, k=5, sigma=1.0, mu=5.0, loss_type=1, presort=True):
+    """ptranking/ltr_adhoc/listwise/lambdaloss.py:83-132.  loss_type 1 = NDCG_Loss2 (:36-45), 2 = NDCG_Loss2++ (:47-58).
+    The inverted discount table (`pow(1/log2(r+2), -1)`) is reproduced as the reference computes it (SURVEY §7 iii)."""
+    if presort:
+        tp, ideal = preds, labels
+    else:
+        ideal, li = torch.sort(labels, dim=1, descending=True)
+        tp = torch.gather(preds, 1, li)
+    sp, idx = torch.sort(tp, dim=1, descending=True)
+    ranked = torch.gather(ideal, 1, idx)
+    L = tp.size(1)
+    disc = 1.0 / torch.log2(torch.arange(L, dtype=torch.float32) + 2.0)
+    G = _gain(ranked) / dcg_full(ideal)
+    r = torch.arange(L)
+    dist = (r[:, None] - r[None, :]).abs()
+    inv = torch.pow(disc, -1.0)
+    delta = torch.abs(inv[dist - 1] - inv[dist])       # index -1 wraps on the diagonal, then zeroed (:41-42)
+    delta.diagonal().zero_()
+    absG = torch.abs(G[:, :, None] - G[:, None, :])
+    if loss_type == 1:
+        w = delta[None] * absG
+    elif loss_type == 2:
+        rho = torch.abs(inv[:, None] - inv[None, :])
+        w = (rho + mu * delta)[None] * absG
+    else:
+        raise NotImplementedError("NDCG_Loss1 only broadcasts for B == 1 in the reference; not part of the path")
+    d = (sp.unsqueeze(2) - sp.unsqueeze(1)).clamp(min=-1e8, max=1e8)
+    d = torch.where(torch.isnan(d), torch.zeros_like(d), d)
+    wp = (torch.sigmoid(sigma * d).clamp(min=EPS_LAMBDALOSS) ** w).clamp(min=EPS_LAMBDALOSS)
+    lw = torch.log2(wp)
+    trunc = torch.zeros(L, L, dtype=torch.bool)
+    trunc[:k, :k] = True
+    mask = ((ranked.unsqueeze(2) - ranked.unsqueeze(1)) > 0) & trunc
+    return -torch.sum(lw[mask])
+
+
+def _robust_sigmoid(x_in, sigma):
+    """Forward of Robust_Sigmoid (ptranking/base/utils.py:57-81); autograd through these ops gives the same
+    derivative sigma*y*(1-y) the reference stores by hand, because the inactive where-branch gets zero gradient."""
+    x = x_in if sigma == 1.0 else sigma * x_in
+    pos = torch.where(x_in > 0, 1.0 / (1.0 + torch.exp(-x)), torch.full_like(x, 0.5))
+    ex = torch.exp(x)
+    return torch.where(x_in < 0, ex / (1.0 + ex), pos)
+
+
+class _RobustSigmoid(torch.autograd.Function):
+    """Same hand-written backward as the reference (saved grad tensor), ptranking/base/utils.py:78-93."""
+
+    @staticmethod
+    def forward(ctx, inp, sigma):
+        with torch.no_grad():
+            y = _robust_sigmoid(inp, sigma)
+            g = y * (1.0 - y) if sigma == 1.0 else sigma * y * (1.0 - y)
+        ctx.save_for_backward(g)
+        return y
+
+    @staticmethod
+    def backward(ctx, go):
+        return go * ctx.saved_tensors[0], None
+
+
+def approxndcg_loss(preds, labels, alpha=10.0, presort=True, couple_batch=True):
+    """ptranking/ltr_adhoc/listwise/approxNDCG.py:19-27,45-62.  couple_batch=True reproduces the reference's
+    [B]/[B,1] broadcast (loss = -(Σ_b DCG_b)(Σ_a 1/IDCG_a), SURVEY §7 vi); False is the per-query form."""
+    if presort:
+        tp, ideal = preds, labels
+    else:
+        ideal, li = torch.sort(labels, dim=1, descending=True)
+        tp = torch.gather(preds, 1, li)
+    diffs = tp.unsqueeze(2) - tp.unsqueeze(1)
+    ind = _RobustSigmoid.apply(diffs.transpose(1, 2), alpha)
+    hat_pi = ind.sum(dim=2) + 0.5
+    idcg = dcg_full(ideal)                                      # [B,1]
+    dcg = torch.sum(_gain(ideal) / torch.log2(hat_pi + 1.0), dim=1)  # [B]
+    if couple_batch:
+        return -torch.sum(dcg / idcg)                            # [B]/[B,1] -> [B,B]
+    return -torch.sum(dcg / idcg.view(-1))
+
+
+def listnet_loss(preds, labels):
+    """ptranking/ltr_adhoc/listwise/listnet.py:39."""
+    return torch.sum(-torch.sum(F.softmax(labels, dim=1) * F.log_softmax(preds, dim=1), dim=1))
+
+
+def arg_shuffle_ties(labels, generator=None):
+    """Random tie-broken descending order; ptranking/ltr_adhoc/util/sampling_utils.py:13-28."""
+    B, L = labels.shape
+    rperm = torch.stack([torch.randperm(L, generator=generator) for _ in range(B)], dim=0)
+    shuffled = torch.gather(labels, 1, rperm)
+    desc = torch.argsort(shuffled, descending=True)
+    return torch.gather(rperm, 1, desc)
+
+
+def listmle_loss(preds, perm):
+    """ptranking/ltr_adhoc/listwise/listmle.py:81-97 with the permutation supplied by the caller."""
+    u = torch.gather(preds, 1, perm)
+    m, _ = torch.max(u, dim=1, keepdim=True)
+    y = torch.exp(u - m)
+    tail = torch.flip(torch.cumsum(torch.flip(y, dims=[1]), dim=1), dims=[1])
+    return torch.sum(torch.log(tail) + m - u)
+
+
+def loss_and_grad(fn, preds, *args, **kw):
+    """Evaluate `fn` on a leaf copy of preds -> (loss float32 0-d tensor, dL/dpreds)."""
+    p = preds.detach().clone().requires_grad_(True)
+    loss = fn(p, *args, **kw)
+    loss.backward()
+    return loss.detach(), p.grad.detach()
+
+
+# --------------------------------------------------------------------------- metrics
+def sort_desc(preds):
+    """torch.sort(descending=True) as ptranking/base/ranker.py:50 calls it (values, int64 indices)."""
+    return torch.sort(preds, dim=1, descending=True)
+
+
+def _pad_ks(vals_at, ks, L, B):
+    used = [k for k in ks if k <= L]
+    out = torch.zeros(B, len(ks))
+    if used:
+        out[:, :len(used)] = vals_at(used)
+    return out
+
+
+def ndcg_at_ks(sys_sorted, ideal_sorted, ks):
+    """ptranking/metric/adhoc/adhoc_metric.py:219-260 (cumsum DCG, zero-fill cut-offs > L at the END of the row)."""
+    B, L = sys_sorted.shape
+
+    def at(used):
+        m = max(used)
+        disc = torch.log2(torch.arange(m, dtype=torch.float32) + 2.0)
+        s = torch.cumsum(_gain(sys_sorted[:, :m]) / disc, dim=1)
+        i = torch.cumsum(_gain(ideal_sorted[:, :m]) / disc, dim=1)
+        ix = torch.tensor(used) - 1
+        return s[:, ix] / i[:, ix]
+    return _pad_ks(at, ks, L, B)
+
+
+def ap_at_ks(sys_sorted, ideal_sorted, ks):
+    """ptranking/metric/adhoc/adhoc_metric.py:91-123; denominator = cumsum of GRADED ideal labels (bug-compatible)."""
+    B, L = sys_sorted.shape
+
+    def at(used):
+        m = max(used)
+        rel = torch.clamp(sys_sorted[:, :m], min=0, max=1)
+        prec = torch.cumsum(rel, dim=1) / (torch.arange(m, dtype=torch.float32) + 1.0)
+        num = torch.cumsum(prec * rel, dim=1)
+        den = torch.cumsum(ideal_sorted, dim=1)[:, :m]
+        ix = torch.tensor(used) - 1
+        return (num / den)[:, ix]
+    return _pad_ks(at, ks, L, B)
+
+
+def precision_at_ks(sys_sorted, ks):
+    """ptranking/metric/adhoc/adhoc_metric.py:36-62."""
+    B, L = sys_sorted.shape
+
+    def at(used):
+        m = max(used)
+        rel = torch.clamp(sys_sorted[:, :m], min=0, max=1)
+        prec = torch.cumsum(rel, dim=1) / (torch.arange(m, dtype=torch.float32) + 1.0)
+        return prec[:, torch.tensor(used) - 1]
+    return _pad_ks(at, ks, L, B)
+
+
+def _rankwise_err(rankings, max_label, m):
+    """ptranking/metric/adhoc/adhoc_metric.py:127-150 (point=False)."""
+    lab = rankings[:, :m]
+    sat = (torch.pow(2.0, lab) - 1.0) / math.pow(2.0, float(max_label))
+    unsat = torch.cumprod(1.0 - sat, dim=1)
+    casc = torch.ones_like(lab)
+    casc[:, 1:m] = unsat[:, 0:m - 1]
+    return torch.cumsum((1.0 / (torch.arange(m, dtype=torch.float32) + 1.0)) * sat * casc, dim=1)
+
+
+def nerr_at_ks(sys_sorted, ideal_sorted, ks, max_label=None):
+    """ptranking/metric/adhoc/adhoc_metric.py:164-193; max_label defaults to the BATCH maximum (:174-175)."""
+    B, L = sys_sorted.shape
+    if max_label is None:
+        max_label = float(torch.max(ideal_sorted))
+
+    def at(used):
+        m = max(used)
+        ix = torch.tensor(used) - 1
+        return (_rankwise_err(sys_sorted, max_label, m) / _rankwise_err(ideal_sorted, max_label, m))[:, ix]
+    return _pad_ks(at, ks, L, B)
+
+
+def evaluate_at_ks(preds, labels, ks, presort, max_label=None):
+    """Evaluator prologue + four metrics for one batch, ptranking/base/ranker.py:220-243 -> dict of [B,len(ks)]."""
+    _, idx = sort_desc(preds)
+    sys_sorted = torch.gather(labels, 1, idx)
+    ideal = labels if presort else torch.sort(labels, dim=1, descending=True)[0]
+    return dict(ndcg=ndcg_at_ks(sys_sorted, ideal, ks), nerr=nerr_at_ks(sys_sorted, ideal, ks, max_label),
+                ap=ap_at_ks(sys_sorted, ideal, ks), p=precision_at_ks(sys_sorted, ks), sort_idx=idx)
+
+
+# --------------------------------------------------------------------------- whole train step (cpu_baseline leg)
+def build_pointsf(num_features, h_dim=100, num_layers=3, dropout=0.1, seed=137):
+    """Pointwise MLP scorer as ptranking/base/point_ranker.py:30-42 + base/utils.py:288-356 build it with
+    AF='R', BN=False, apply_tl_af=False: (Dropout -> Linear(xavier_normal) -> ReLU) x num_layers -> Linear."""
+    g = torch.Generator().manual_seed(seed)
+    dims = [num_features] + [h_dim] * num_layers + [1]
+    net = torch.nn.Sequential()
+    for i in range(1, len(dims) - 1):
+        net.add_module(f"dr_{i}", torch.nn.Dropout(dropout))
+        lin = torch.nn.Linear(dims[i - 1], dims[i])
+        torch.nn.init.xavier_normal_(lin.weight, generator=g)
+        net.add_module(f"ff_{i + 1}", lin)
+        net.add_module(f"act_{i + 1}", torch.nn.ReLU())
+    last = torch.nn.Linear(dims[-2], dims[-1])
+    torch.nn.init.xavier_normal_(last.weight, generator=g)
+    net.add_module(f"ff_{len(dims)}", last)
+    return net
+
+
+def cpu_train_step(net, opt, X, Y, loss_fn, **loss_kw):
+    """One reference-shaped train step on CPU: forward (ptranking/base/point_ranker.py:45-55) -> loss ->
+    zero_grad/backward/step (e.g. lambdarank.py:58-60) -> .item() (ptranking/base/ranker.py:584)."""
+    preds = net(X).view(-1, X.size(1))
+    loss = loss_fn(preds, Y, **loss_kw)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    return loss.item()

@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by RUNNING THE REFERENCE ITSELF.
+
+Run here (the build container), never on the GPU box:
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+It imports wildltr/ptranking read-only from /root/reference, feeds seeded synthetic
+batches through the reference's own loss classes / metric functions on CPU and stores
+inputs + outputs as small .npz files.  The reference cannot travel to the GPU box, the
+fixtures do: every parity test (oracle vs golden on CPU, HIP vs golden on the GPU)
+reads these files and nothing else.
+
+How (loss, dL/dpreds) is extracted without the reference's optimizer side effects
+(SURVEY.md §8c): the ranker class is constructed WITHOUT init() (so no scorer / no real
+optimizer), `ranker.optimizer` is replaced by a stub whose zero_grad()/step() are
+no-ops, and `custom_loss_function` is called on a leaf `preds` tensor; after the call
+`preds.grad` is the reference gradient.
+
+Reference entry points exercised:
+  ptranking/ltr_adhoc/pairwise/ranknet.py:25-42
+  ptranking/ltr_adhoc/listwise/lambdarank.py:27-62
+  ptranking/ltr_adhoc/listwise/lambdaloss.py:73-138
+  ptranking/ltr_adhoc/listwise/approxNDCG.py:83-109
+  ptranking/ltr_adhoc/listwise/listnet.py:22-45
+  ptranking/ltr_adhoc/listwise/listmle.py:73-104
+  ptranking/metric/adhoc/adhoc_metric.py (P / AP / nERR / nDCG @k(s))
+  ptranking/base/ranker.py:31-263 (Evaluator sort->gather prologue)
+  testing/metric/testing_metric.py:17-61 (the reference's only known-answer vectors)
+"""
+import os
+import sys
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+if not os.path.isdir(REF):
+    raise SystemExit("the reference tree is only mounted in the build container")
+sys.path.insert(0, REF)
+
+import numpy as np
+import torch
+
+from ptranking.data.data_utils import LABEL_TYPE
+from ptranking.ltr_adhoc.pairwise.ranknet import RankNet
+from ptranking.ltr_adhoc.listwise.lambdarank import LambdaRank
+from ptranking.ltr_adhoc.listwise.lambdaloss import LambdaLoss
+from ptranking.ltr_adhoc.listwise.approxNDCG import ApproxNDCG
+from ptranking.ltr_adhoc.listwise.listnet import ListNet
+from ptranking.ltr_adhoc.listwise.listmle import ListMLE
+import ptranking.ltr_adhoc.listwise.listmle as ref_listmle_mod
+from ptranking.metric.adhoc.adhoc_metric import (
+    torch_ndcg_at_k, torch_ndcg_at_ks, torch_ap_at_k, torch_ap_at_ks,
+    torch_nerr_at_k, torch_nerr_at_ks, torch_precision_at_k, torch_precision_at_ks)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SEED = 137  # ptranking/ltr_global.py:7
+MSLR_P = [0.5147, 0.3250, 0.1339, 0.0183, 0.0081]   # testing/data/testing_data_utils.py:326
+YAHOO_P = [0.2609, 0.3580, 0.2855, 0.0767, 0.0189]  # testing/data/testing_data_utils.py:342
+
+SF = {"sf_id": "pointsf", "opt": "Adam", "lr": 1e-3,
+      "pointsf": dict(num_layers=3, AF="R", TL_AF="S", apply_tl_af=False, BN=False, bn_type=None, bn_affine=False)}
+
+
+class _StubOptimizer:
+    def zero_grad(self):
+        pass
+
+    def step(self):
+        pass
+
+
+def synth(rng, B, L, p=MSLR_P, presort=True):
+    preds = rng.standard_normal((B, L)).astype(np.float32)
+    labels = rng.choice(len(p), size=(B, L), p=np.asarray(p) / np.sum(p)).astype(np.float32)
+    for b in range(B):               # min_rele=1 (ptranking/data/data_utils.py:398-400)
+        if labels[b].max() < 1:
+            labels[b, rng.integers(L)] = 1.0
+    if presort:
+        labels = -np.sort(-labels, axis=1)
+    return preds, labels
+
+
+def run_loss(ranker, preds, labels, presort=True, **extra):
+    ranker.optimizer = _StubOptimizer()
+    p = torch.from_numpy(preds).clone().requires_grad_(True)
+    y = torch.from_numpy(labels).clone()
+    loss = ranker.custom_loss_function(p, y, presort=presort, label_type=LABEL_TYPE.MultiLabel, **extra)
+    return np.float32(loss.detach().item()), p.grad.detach().numpy().astype(np.float32)
+
+
+def pred_sort_idx(preds):
+    return torch.sort(torch.from_numpy(preds), dim=1, descending=True)[1].numpy().astype(np.int64)
+
+
+def add(store, name, **arrays):
+    for k, v in arrays.items():
+        store[f"{name}/{k}"] = np.asarray(v)
+
+
+SHAPES = [(3, 8), (4, 32), (3, 64), (2, 128), (2, 200), (2, 256)]
+
+
+def gen_losses():
+    store = {}
+    rng = np.random.default_rng(SEED)
+    torch.manual_seed(SEED)
+    names = []
+    for ci, (B, L) in enumerate(SHAPES):
+        preds, labels = synth(rng, B, L)
+        for sigma in ((1.0, 2.5) if ci < 2 else (1.0,)):
+            tag = f"c{ci}_s{sigma:g}"
+            # RankNet
+            loss, grad = run_loss(RankNet(sf_para_dict=SF, model_para_dict={"sigma": sigma}, device="cpu"), preds, labels)
+            add(store, f"ranknet/{tag}", preds=preds, labels=labels, sigma=np.float32(sigma), loss=loss, grad=grad)
+            names.append(f"ranknet/{tag}")
+            # LambdaRank
+            loss, grad = run_loss(LambdaRank(sf_para_dict=SF, model_para_dict={"sigma": sigma}, device="cpu"), preds, labels)
+            add(store, f"lambdarank/{tag}", preds=preds, labels=labels, sigma=np.float32(sigma), loss=loss, grad=grad,
+                sort_idx=pred_sort_idx(preds))
+            names.append(f"lambdarank/{tag}")
+        # LambdaLoss: type code 1 = NDCG_Loss2, 2 = NDCG_Loss2++ (NDCG_Loss1 only broadcasts for B == 1, SURVEY §7 iii)
+        for lt, code in (("NDCG_Loss2", 1), ("NDCG_Loss2++", 2)):
+            for k in sorted({5, min(L, 40), L}):
+                mpd = dict(k=k, sigma=1.0, loss_type=lt, mu=5.0)
+                loss, grad = run_loss(LambdaLoss(sf_para_dict=SF, model_para_dict=mpd, device="cpu"), preds, labels)
+                tag = f"c{ci}_t{code}_k{k}"
+                add(store, f"lambdaloss/{tag}", preds=preds, labels=labels, sigma=np.float32(1.0), k=np.int32(k),
+                    mu=np.float32(5.0), loss_type=np.int32(code), loss=loss, grad=grad)
+                names.append(f"lambdaloss/{tag}")
+        # ApproxNDCG (batch-coupled reference semantics, SURVEY §7 vi); alpha 10 is the default, 1.0 exercises the
+        # sigma==1 branch of Robust_Sigmoid (ptranking/base/utils.py:68,76)
+        for alpha in (10.0, 1.0):
+            loss, grad = run_loss(ApproxNDCG(sf_para_dict=SF, model_para_dict={"alpha": alpha}, device="cpu"), preds, labels)
+            tag = f"c{ci}_a{alpha:g}"
+            add(store, f"approxndcg/{tag}", preds=preds, labels=labels, alpha=np.float32(alpha), loss=loss, grad=grad)
+            names.append(f"approxndcg/{tag}")
+        # ListNet
+        loss, grad = run_loss(ListNet(sf_para_dict=SF, device="cpu"), preds, labels)
+        add(store, f"listnet/c{ci}", preds=preds, labels=labels, loss=loss, grad=grad)
+        names.append(f"listnet/c{ci}")
+        # ListMLE: capture the tie-shuffled permutation the reference drew
+        captured = {}
+        orig = ref_listmle_mod.arg_shuffle_ties
+
+        def spy(batch_rankings, descending=True, device=None):
+            out = orig(batch_rankings=batch_rankings, descending=descending, device=device)
+            captured["perm"] = out.numpy().astype(np.int64)
+            return out
+
+        ref_listmle_mod.arg_shuffle_ties = spy
+        try:
+            loss, grad = run_loss(ListMLE(sf_para_dict=SF, device="cpu"), preds, labels)
+        finally:
+            ref_listmle_mod.arg_shuffle_ties = orig
+        add(store, f"listmle/c{ci}", preds=preds, labels=labels, perm=captured["perm"], loss=loss, grad=grad)
+        names.append(f"listmle/c{ci}")
+
+    # Yahoo-shaped labels, one case per pairwise/listwise family
+    preds, labels = synth(rng, 3, 48, p=YAHOO_P)
+    loss, grad = run_loss(LambdaRank(sf_para_dict=SF, model_para_dict={"sigma": 1.0}, device="cpu"), preds, labels)
+    add(store, "lambdarank/yahoo", preds=preds, labels=labels, sigma=np.float32(1.0), loss=loss, grad=grad,
+        sort_idx=pred_sort_idx(preds))
+    loss, grad = run_loss(ApproxNDCG(sf_para_dict=SF, model_para_dict={"alpha": 10.0}, device="cpu"), preds, labels)
+    add(store, "approxndcg/yahoo", preds=preds, labels=labels, alpha=np.float32(10.0), loss=loss, grad=grad)
+    names += ["lambdarank/yahoo", "approxndcg/yahoo"]
+
+    # ---- edge cases pinned in SURVEY.md Appendix A ----
+    # saturation: sigmoid rounds to 1.0f, BCE log clamps at -100, gradient is exactly zero
+    sp = np.array([[-60, -40, -20, 0, 20, 40]], np.float32)
+    sl = np.array([[2, 2, 1, 1, 0, 0]], np.float32)
+    loss, grad = run_loss(LambdaRank(sf_para_dict=SF, model_para_dict={"sigma": 1.0}, device="cpu"), sp, sl)
+    add(store, "lambdarank/saturated", preds=sp, labels=sl, sigma=np.float32(1.0), loss=loss, grad=grad, sort_idx=pred_sort_idx(sp))
+    loss, grad = run_loss(RankNet(sf_para_dict=SF, model_para_dict={"sigma": 1.0}, device="cpu"), sp, sl)
+    add(store, "ranknet/saturated", preds=sp, labels=sl, sigma=np.float32(1.0), loss=loss, grad=grad)
+    # moderately large score gaps (fp32 rounding of 1-p matters but nothing clamps)
+    mp = np.array([[-6, 4.5, -2.25, 0.5, 3, 7.75, -9, 1.125]], np.float32)
+    ml = np.array([[4, 3, 2, 2, 1, 0, 0, 0]], np.float32)
+    loss, grad = run_loss(LambdaRank(sf_para_dict=SF, model_para_dict={"sigma": 1.0}, device="cpu"), mp, ml)
+    add(store, "lambdarank/wide", preds=mp, labels=ml, sigma=np.float32(1.0), loss=loss, grad=grad, sort_idx=pred_sort_idx(mp))
+    loss, grad = run_loss(RankNet(sf_para_dict=SF, model_para_dict={"sigma": 1.0}, device="cpu"), mp, ml)
+    add(store, "ranknet/wide", preds=mp, labels=ml, sigma=np.float32(1.0), loss=loss, grad=grad)
+    loss, grad = run_loss(ApproxNDCG(sf_para_dict=SF, model_para_dict={"alpha": 10.0}, device="cpu"), mp, ml)
+    add(store, "approxndcg/wide", preds=mp, labels=ml, alpha=np.float32(10.0), loss=loss, grad=grad)
+    mpd = dict(k=8, sigma=1.0, loss_type="NDCG_Loss2", mu=5.0)
+    loss, grad = run_loss(LambdaLoss(sf_para_dict=SF, model_para_dict=mpd, device="cpu"), mp, ml)
+    add(store, "lambdaloss/wide", preds=mp, labels=ml, sigma=np.float32(1.0), k=np.int32(8), mu=np.float32(5.0),
+        loss_type=np.int32(1), loss=loss, grad=grad)
+    # all-tied scores, L=6: CPU torch.sort keeps the input order (== our (score desc, index asc) rule)
+    tp = np.zeros((1, 6), np.float32)
+    tl = np.array([[2, 1, 1, 0, 0, 0]], np.float32)
+    loss, grad = run_loss(LambdaRank(sf_para_dict=SF, model_para_dict={"sigma": 1.0}, device="cpu"), tp, tl)
+    add(store, "lambdarank/tied", preds=tp, labels=tl, sigma=np.float32(1.0), loss=loss, grad=grad, sort_idx=pred_sort_idx(tp))
+    # B == 1 (ApproxNDCG batch coupling degenerates to the per-query form)
+    preds, labels = synth(rng, 1, 24)
+    loss, grad = run_loss(ApproxNDCG(sf_para_dict=SF, model_para_dict={"alpha": 10.0}, device="cpu"), preds, labels)
+    add(store, "approxndcg/b1", preds=preds, labels=labels, alpha=np.float32(10.0), loss=loss, grad=grad)
+    # LambdaLoss / ApproxNDCG with presort=False (labels arrive unsorted; the reference sorts them first)
+    preds, labels = synth(rng, 3, 40, presort=False)
+    mpd = dict(k=10, sigma=1.0, loss_type="NDCG_Loss2", mu=5.0)
+    loss, grad = run_loss(LambdaLoss(sf_para_dict=SF, model_para_dict=mpd, device="cpu"), preds, labels, presort=False)
+    add(store, "lambdaloss/unsorted", preds=preds, labels=labels, sigma=np.float32(1.0), k=np.int32(10), mu=np.float32(5.0),
+        loss_type=np.int32(1), loss=loss, grad=grad, presort=np.int32(0))
+    loss, grad = run_loss(ApproxNDCG(sf_para_dict=SF, model_para_dict={"alpha": 10.0}, device="cpu"), preds, labels, presort=False)
+    add(store, "approxndcg/unsorted", preds=preds, labels=labels, alpha=np.float32(10.0), loss=loss, grad=grad, presort=np.int32(0))
+    # ListNet / ListMLE never look at presort; RankNet uses the input order as is
+    loss, grad = run_loss(RankNet(sf_para_dict=SF, model_para_dict={"sigma": 1.0}, device="cpu"), preds, labels, presort=False)
+    add(store, "ranknet/unsorted", preds=preds, labels=labels, sigma=np.float32(1.0), loss=loss, grad=grad)
+
+    np.savez_compressed(os.path.join(HERE, "losses.npz"), **store)
+    print(f"losses.npz: {len(store)} arrays, {len(set(k.rsplit('/', 1)[0] for k in store))} cases")
+
+
+def gen_metrics():
+    store = {}
+    # --- the reference's own known-answer vectors, testing/metric/testing_metric.py:17-61 ---
+    kat = [
+        ("ap1", [1, 0, 1, 0, 1], [1, 1, 1, 1, 1], [1, 3, 5], "ap", [1.0000, 0.5556, 0.4533]),        # :20-23
+        ("ap2", [1, 0, 1, 0, 1], [1, 1, 1, 0, 0], [1, 3, 5], "ap", [1.0000, 0.5556, 0.7556]),        # :27-30
+        ("ap3", [1, 1, 0, 1, 0, 0, 1], [1, 1, 1, 1, 0, 0, 0], [1, 2, 3, 5, 7], "ap",
+         [1.0000, 1.0000, 0.6667, 0.6875, 0.8304]),                                                  # :33-36
+        ("ndcg1", [1, 1, 0, 1, 0, 0, 1], [1, 1, 1, 1, 0, 0, 0], [1, 2, 3, 4, 5, 6, 7], "ndcg",
+         [1.0000, 1.0000, 0.7654, 0.8048, 0.8048, 0.8048, 0.9349]),                                  # :43-46
+        ("nerr1", [3, 2, 4], [4, 3, 2], [1, 2, 3], "nerr", [0.4667, 0.5154, 0.6640]),                 # :54-58
+    ]
+    fn = {"ap": lambda s, i, ks: torch_ap_at_ks(s, i, ks=ks),
+          "ndcg": lambda s, i, ks: torch_ndcg_at_ks(s, i, ks=ks),
+          "nerr": lambda s, i, ks: torch_nerr_at_ks(s, i, ks=ks)}
+    for name, sys_l, std_l, ks, kind, commented in kat:
+        s = torch.tensor([sys_l], dtype=torch.float32)
+        i = torch.tensor([std_l], dtype=torch.float32)
+        out = fn[kind](s, i, ks).numpy().astype(np.float32)
+        assert np.allclose(out[0], commented, atol=5e-5), (name, out, commented)
+        add(store, f"kat/{name}", sys_sorted=s.numpy(), ideal_sorted=i.numpy(), ks=np.asarray(ks, np.int32),
+            kind=np.array(kind), expected=out, commented=np.asarray(commented, np.float32))
+
+    # --- Evaluator prologue + all four metrics on random batches (ptranking/base/ranker.py:202-263) ---
+    rng = np.random.default_rng(SEED + 1)
+    KS = [1, 3, 5, 10, 20, 50]  # ptranking/ltr_adhoc/eval/parameter.py:456
+    for ci, (B, L, presort, p) in enumerate([(4, 8, True, MSLR_P), (3, 30, True, MSLR_P), (3, 64, False, MSLR_P),
+                                             (2, 128, True, MSLR_P), (2, 256, True, YAHOO_P), (2, 50, False, YAHOO_P)]):
+        preds, labels = synth(rng, B, L, p=p, presort=presort)
+        tp, tl = torch.from_numpy(preds), torch.from_numpy(labels)
+        _, idx = torch.sort(tp, dim=1, descending=True)
+        sys_sorted = torch.gather(tl, 1, idx)
+        ideal = tl if presort else torch.sort(tl, dim=1, descending=True)[0]
+        out = dict(
+            ndcg=torch_ndcg_at_ks(sys_sorted, ideal, ks=KS, label_type=LABEL_TYPE.MultiLabel),
+            nerr=torch_nerr_at_ks(sys_sorted, ideal, ks=KS, label_type=LABEL_TYPE.MultiLabel, max_label=None),
+            ap=torch_ap_at_ks(sys_sorted, ideal, ks=KS),
+            p=torch_precision_at_ks(sys_sorted, ks=KS))
+        k1 = min(5, L)
+        single = dict(
+            ndcg_k=torch_ndcg_at_k(sys_sorted, ideal, k=k1, label_type=LABEL_TYPE.MultiLabel),
+            nerr_k=torch_nerr_at_k(sys_sorted, ideal, k=k1, label_type=LABEL_TYPE.MultiLabel, device="cpu"),
+            ap_k=torch_ap_at_k(sys_sorted, ideal, k=k1),
+            p_k=torch_precision_at_k(sys_sorted, k=k1))
+        add(store, f"rand/c{ci}", preds=preds, labels=labels, presort=np.int32(presort), ks=np.asarray(KS, np.int32),
+            sort_idx=idx.numpy().astype(np.int64), sorted_vals=torch.sort(tp, dim=1, descending=True)[0].numpy(),
+            max_label=np.float32(ideal.max().item()), k1=np.int32(k1),
+            **{k: v.numpy().astype(np.float32) for k, v in out.items()},
+            **{k: v.numpy().astype(np.float32) for k, v in single.items()})
+    np.savez_compressed(os.path.join(HERE, "metrics.npz"), **store)
+    print(f"metrics.npz: {len(store)} arrays")
+
+
+if __name__ == "__main__":
+    gen_losses()
+    gen_metrics()
+    print("torch", torch.__version__, "numpy", np.__version__)

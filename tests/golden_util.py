@@ -1,0 +1,57 @@
+"""Loader for the committed golden fixtures (tests/golden/*.npz, produced by tests/golden/make_golden.py
+from the reference itself).  Returns {case_name: {field: ndarray}} per loss family."""
+import os
+from collections import defaultdict
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# fp32 parity tolerance of BASELINE.json's north_star ("within 1e-5 fp32"): absolute 1e-5 on values of
+# magnitude <= 1, relative 1e-5 above that (fp32 summation order alone moves a sum of ~1e4 terms by ~1e-6 rel).
+RTOL = 1e-5
+ATOL = 1e-5
+
+
+def tol(ref):
+    ref = np.asarray(ref, dtype=np.float64)
+    return ATOL + RTOL * (np.max(np.abs(ref)) if ref.size else 0.0)
+
+
+def assert_close(got, ref, what=""):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, f"{what}: shape {got.shape} vs {ref.shape}"
+    if ref.size == 0:
+        return
+    err = np.max(np.abs(got - ref))
+    assert err <= tol(ref), f"{what}: max|diff|={err:.3e} > tol={tol(ref):.3e} (scale {np.max(np.abs(ref)):.3e})"
+
+
+def _load(fname):
+    z = np.load(os.path.join(GOLDEN_DIR, fname), allow_pickle=False)
+    fams = defaultdict(lambda: defaultdict(dict))
+    for key in z.files:
+        fam, case, field = key.split("/")
+        fams[fam][case][field] = z[key]
+    return {f: dict(c) for f, c in fams.items()}
+
+
+_CACHE = {}
+
+
+def losses():
+    if "l" not in _CACHE:
+        _CACHE["l"] = _load("losses.npz")
+    return _CACHE["l"]
+
+
+def metrics():
+    if "m" not in _CACHE:
+        _CACHE["m"] = _load("metrics.npz")
+    return _CACHE["m"]
+
+
+def case_ids(fam, which="losses"):
+    d = losses() if which == "losses" else metrics()
+    return sorted(d[fam].keys())
