@@ -93,3 +93,103 @@ def test_evaluator_metrics(name):
     assert np.array_equal(out["sort_idx"].numpy(), c["sort_idx"])
     for m in ("ndcg", "nerr", "ap", "p"):
         G.assert_close(out[m].numpy(), c[m], m)
+
+
+# =================================================================== the plain-C oracle (closed-form gradients)
+from oracle import c_oracle as CO
+
+
+@pytest.mark.parametrize("name", G.case_ids("ranknet"))
+def test_c_oracle_ranknet(name):
+    c = G.losses()["ranknet"][name]
+    lq, grad = CO.ranknet(c["preds"], c["labels"], float(c["sigma"]))
+    G.assert_close(lq.astype(np.float64).sum(), c["loss"], "loss")
+    G.assert_close(grad, c["grad"], "grad")
+
+
+@pytest.mark.parametrize("name", G.case_ids("lambdarank"))
+def test_c_oracle_lambdarank(name):
+    c = G.losses()["lambdarank"][name]
+    lq, grad = CO.lambdarank(c["preds"], c["labels"], float(c["sigma"]))
+    G.assert_close(lq.astype(np.float64).sum(), c["loss"], "loss")
+    G.assert_close(grad, c["grad"], "grad")
+    assert np.array_equal(CO.sort_desc(c["preds"])[1], c["sort_idx"])
+
+
+@pytest.mark.parametrize("name", G.case_ids("lambdaloss"))
+def test_c_oracle_lambdaloss(name):
+    c = G.losses()["lambdaloss"][name]
+    lq, grad = CO.lambdaloss(c["preds"], c["labels"], int(c["k"]), float(c["sigma"]), float(c["mu"]),
+                             int(c["loss_type"]), _presort(c))
+    G.assert_close(lq.astype(np.float64).sum(), c["loss"], "loss")
+    G.assert_close(grad, c["grad"], "grad")
+
+
+@pytest.mark.parametrize("name", G.case_ids("approxndcg"))
+def test_c_oracle_approxndcg(name):
+    c = G.losses()["approxndcg"][name]
+    loss, dcg, inv, grad = CO.approxndcg(c["preds"], c["labels"], float(c["alpha"]), _presort(c), True)
+    G.assert_close(loss, c["loss"], "loss")
+    G.assert_close(grad, c["grad"], "grad")
+    G.assert_close(-(dcg.astype(np.float64).sum() * inv.astype(np.float64).sum()), c["loss"], "loss from slots")
+
+
+@pytest.mark.parametrize("name", G.case_ids("listnet"))
+def test_c_oracle_listnet(name):
+    c = G.losses()["listnet"][name]
+    lq, grad = CO.listnet(c["preds"], c["labels"])
+    G.assert_close(lq.astype(np.float64).sum(), c["loss"], "loss")
+    G.assert_close(grad, c["grad"], "grad")
+
+
+@pytest.mark.parametrize("name", G.case_ids("listmle"))
+def test_c_oracle_listmle(name):
+    c = G.losses()["listmle"][name]
+    lq, grad = CO.listmle(c["preds"], c["perm"])
+    G.assert_close(lq.astype(np.float64).sum(), c["loss"], "loss")
+    G.assert_close(grad, c["grad"], "grad")
+
+
+@pytest.mark.parametrize("name", G.case_ids("rand", "metrics"))
+def test_c_oracle_metrics(name):
+    c = G.metrics()["rand"][name]
+    out = CO.metrics_at_ks(c["preds"], c["labels"], c["ks"], bool(int(c["presort"])))
+    for m in ("ndcg", "nerr", "ap", "p"):
+        G.assert_close(out[m], c[m], m)
+    vals, idx = CO.sort_desc(c["preds"])
+    assert np.array_equal(idx, c["sort_idx"])
+    assert np.array_equal(vals, c["sorted_vals"])
+
+
+def test_c_oracle_known_answers_via_identity_scores():
+    """Feed the reference's hand vectors through the full prologue: scores that already rank the list as given."""
+    checked = 0
+    for name in G.case_ids("kat", "metrics"):
+        c = G.metrics()["kat"][name]
+        sys_sorted = c["sys_sorted"]
+        L = sys_sorted.shape[1]
+        preds = -np.arange(L, dtype=np.float32)[None]          # keeps the given order
+        kind = str(c["kind"])
+        # only vectors whose 'ideal' row is the sorted 'system' row can go through the sort->gather prologue
+        if sorted(sys_sorted[0].tolist(), reverse=True) == c["ideal_sorted"][0].tolist():
+            out = CO.metrics_at_ks(preds, sys_sorted, c["ks"], presort=False)
+            G.assert_close(out[kind][0], c["expected"][0], name)
+            checked += 1
+    assert checked >= 3
+
+
+def test_c_oracle_padding_equals_unpadded():
+    rng = np.random.default_rng(5)
+    B, L = 5, 40
+    lens = np.array([40, 17, 1, 33, 8], np.int32)
+    preds = rng.standard_normal((B, L)).astype(np.float32)
+    labels = -np.sort(-rng.integers(0, 5, (B, L)).astype(np.float32), axis=1)
+    labels[:, 0] = np.maximum(labels[:, 0], 1)
+    for fn, args in ((CO.lambdarank, (1.0,)), (CO.ranknet, (1.0,)), (CO.listnet, ())):
+        lq, g = fn(preds, labels, *args, lens=lens)
+        for b in range(B):
+            n = lens[b]
+            lq1, g1 = fn(preds[b:b + 1, :n], labels[b:b + 1, :n], *args)
+            assert np.allclose(lq[b], lq1[0], rtol=1e-6, atol=1e-6)
+            assert np.allclose(g[b, :n], g1[0], rtol=1e-6, atol=1e-6)
+            assert np.all(g[b, n:] == 0)
