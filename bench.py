@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: queries/sec of one LambdaRank train step (scorer forward + fused delta-NDCG loss/grad kernel +
+scorer backward + optimiser step) on MSLR-WEB30K-shaped synthetic batches, list_len=128, 136 features (BASELINE.json
+configs[1]).  One process per GPU:
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline      the fused LambdaRank kernel: algorithmic bytes (12*L+4 per query) / its average launch
+                duration measured with HIP events on the launch stream during the timed region, vs HBM peak 8 TB/s
+  cpu_baseline  the oracle's torch-CPU restatement of the reference train step, timed on this box's host cores on a
+                bounded sample of the same workload (rank 0, N=1 only)
+Inputs are resident in HBM before the timed region; a step does no host synchronisation.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+MSLR_P = [0.5147, 0.3250, 0.1339, 0.0183, 0.0081]   # label histogram of MSLR-WEB30K
+SEED = 137                        # ptranking/ltr_global.py:7
+
+
+def synth_batch(gen, B, L, F, device):
+    """MSLR-shaped synthetic batch: X ~ N(0,1), graded labels sorted descending (presort=True), >= 1 relevant doc."""
+    X = torch.randn((B, L, F), generator=gen, device=device, dtype=torch.float32)
+    probs = torch.tensor(MSLR_P, device=device)
+    Y = torch.multinomial(probs.expand(B, -1), L, replacement=True, generator=gen).float()
+    Y[:, 0] = torch.clamp(Y[:, 0], min=1.0)
+    Y, _ = torch.sort(Y, dim=1, descending=True)
+    return X, Y.contiguous()
+
+
+def sf_para_dict(F, lr=1e-3):
+    return {"sf_id": "pointsf", "opt": "Adam", "lr": lr,
+            "pointsf": dict(num_features=F, num_layers=3, AF="R", TL_AF="S", apply_tl_af=False, BN=False, bn_type=None,
+                            bn_affine=False)}   # h_dim=100, dropout=0.1 are hard-wired (point_ranker.py:30-31)
+
+
+def cpu_baseline(L, F, budget_s):
+    """Torch-CPU restatement of the reference's LambdaRank train step (oracle/torch_ref.py), all host cores."""
+    from oracle import torch_ref as T
+    torch.manual_seed(SEED)
+    B = 256
+    gen = torch.Generator().manual_seed(SEED)
+    X, Y = synth_batch(gen, B, L, F, "cpu")
+    net = T.build_pointsf(F, seed=SEED)
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-3)
+    for _ in range(2):
+        T.cpu_train_step(net, opt, X, Y, T.lambdarank_loss, sigma=1.0)
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        T.cpu_train_step(net, opt, X, Y, T.lambdarank_loss, sigma=1.0)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or steps >= 200:
+            break
+    return {"value": B * steps / el, "unit": "queries/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} train steps of {B} queries x {L} docs x {F} feats (torch-CPU restatement of the reference "
+                      f"train_op: pointsf scorer + LambdaRank + Adam), {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4096, help="queries per GPU per step (weak scaling)")
+    ap.add_argument("--list-len", type=int, default=128)
+    ap.add_argument("--features", type=int, default=136)
+    ap.add_argument("--nbatches", type=int, default=4, help="distinct HBM-resident batches cycled through (> L3 capacity)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import ptranking_amd as pa
+    from ptranking_amd import _lib, dp
+
+    rank, world, local = dp.init_from_env()
+    if world != args.gpus and rank == 0:
+        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    device = f"cuda:{local}"
+    torch.cuda.set_device(local)
+    B, L, F = args.batch, args.list_len, args.features
+
+    torch.manual_seed(SEED)                       # identical initial weights on every rank
+    ranker = pa.LambdaRank(sf_para_dict=sf_para_dict(F), model_para_dict={"model_id": "LambdaRank", "sigma": 1.0},
+                           gpu=True, device=device)
+    ranker.init()
+    ranker.train_mode()                           # dropout 0.1 active, exactly like the reference's train()
+    gen = torch.Generator(device=device).manual_seed(SEED + 1000 * rank)   # every rank owns different queries
+    batches = [synth_batch(gen, B, L, F, device) for _ in range(max(1, args.nbatches))]
+
+    def step(i):
+        X, Y = batches[i % len(batches)]
+        loss, _ = ranker.train_op(X, Y, epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
+        return loss
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    _lib.TIMING = {}
+    epoch_loss = torch.zeros((), device=device)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        epoch_loss += step(i).detach()
+    sync()
+    elapsed = time.perf_counter() - t0
+    timing, _lib.TIMING = _lib.TIMING, None
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(epoch_loss.item())
+    if not np.isfinite(final_loss):
+        raise SystemExit(f"non-finite loss {final_loss}")
+
+    if rank == 0:
+        ev = timing.get("ptr_lambdarank_fwd_bwd", [])
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
+        algo_bytes = B * (12 * L + 4)
+        achieved = algo_bytes / (kern_ms * 1e-3) / 1e9 if ev else float("nan")
+        qps = world * B * args.steps / elapsed
+        out = {
+            "metric": "queries/sec fwd+bwd LambdaRank, MSLR-WEB30K-shaped list_len=128",
+            "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"LambdaRank dNDCG train step (pointsf 3x100 ReLU scorer, dropout 0.1, Adam), "
+                                   f"MSLR-WEB30K-shaped synthetic, {F} feats, list_len={L}",
+                       "queries_per_gpu_per_step": B, "global_batch": world * B, "list_len": L, "features": F,
+                       "parallelism": f"dp{world}", "resident_batches": len(batches)},
+            "roofline": {"kernel": "pairwise_bce_kernel<WEIGHTED> (fused LambdaRank loss+grad)", "bound": "hbm",
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": None, "avg_launch_ms": kern_ms, "algorithmic_bytes_per_launch": algo_bytes,
+                         "note": "O(L^2) pair work: VALU/transcendental-bound, not HBM-bound (DESIGN.md)"},
+            "loss_kernel_share_of_step": kern_ms / (1e3 * elapsed / args.steps) if ev else None,
+            "final_epoch_loss": final_loss,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(L, F, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,114 @@
+/*
+ * ptranking_amd — C ABI of the MI355X-native ltr_adhoc loss / metric hot path.
+ *
+ * This is the drop-in boundary.  The reference (wildltr/ptranking) is pure Python and has no
+ * FFI of its own; each entry point below replaces the ATen op sequence that one reference function executes, and
+ * is what a `ctypes` binding on the reference side would bind (INTEGRATION.md shows that stub).  The Python host
+ * layer in ptranking_amd/ mirrors the reference's plugin surface (`NeuralRanker.custom_loss_function`,
+ * `Evaluator.*`) on top of these calls.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into HBM unless it is marked "host"; the caller owns every buffer,
+ *     nothing is allocated, freed or retained by the library; no state survives a call;
+ *   - batches are padded row-major (B, L) fp32: `preds[q*L + i]`, `labels[q*L + i]`; `lens` (int32[B], nullable)
+ *     gives the number of real documents per query (NULL => L for every query); padded documents are excluded
+ *     from every sum and receive gradient 0;
+ *   - calls only ENQUEUE work on `stream` (a hipStream_t passed as void*, NULL = the legacy default stream) and
+ *     never synchronise the host; results are run-to-run bit-stable (no floating-point atomics across waves);
+ *   - return value: 0 on success, a hipError_t (> 0, < 1000) if the HIP runtime failed, or one of PTR_ERR_*;
+ *     ptr_last_error() returns a thread-local message for the last non-zero return on this thread;
+ *   - list lengths up to PTR_MAX_LIST_LEN are supported (per-query tiles live in LDS).
+ */
+#ifndef PTRANKING_AMD_H
+#define PTRANKING_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTR_ABI_VERSION 1
+#define PTR_MAX_LIST_LEN 4096
+#define PTR_MAX_CUTOFFS 32
+
+#define PTR_ERR_INVALID_ARG 1001   /* NULL pointer, negative size, bad enum value               */
+#define PTR_ERR_UNSUPPORTED 1002   /* L > PTR_MAX_LIST_LEN, nk > PTR_MAX_CUTOFFS, ...            */
+
+#define PTR_LAMBDALOSS_NDCG_LOSS2 1    /* 'NDCG_Loss2'   (ptranking/ltr_adhoc/listwise/lambdaloss.py:36-45) */
+#define PTR_LAMBDALOSS_NDCG_LOSS2PP 2  /* 'NDCG_Loss2++' (ptranking/ltr_adhoc/listwise/lambdaloss.py:47-58) */
+
+int ptr_abi_version(void);
+const char *ptr_last_error(void);
+
+/* RankNet — replaces ptranking/ltr_adhoc/pairwise/ranknet.py:32-36 (+ ltr_adhoc/util/lambda_utils.py:5-23) and
+ * its autograd backward.  Pairs i<j in INPUT order, unweighted BCE, ties have target 0.5.
+ *   loss_q[B] = per-query loss; grad[B,L]; loss_out[1] = sum over queries (nullable: NULL skips the reduction launch,
+ *   the caller can run ptr_sum_f32 over loss_q itself).  Same convention for every *_fwd_bwd below. */
+int ptr_ranknet_fwd_bwd(const float *preds, const float *labels, const int32_t *lens, int B, int L, float sigma,
+                        float *loss_out, float *loss_q, float *grad, void *stream);
+
+/* LambdaRank — replaces ptranking/ltr_adhoc/listwise/lambdarank.py:39-56 (torch.sort, gather,
+ * get_pairwise_comp_probs, get_delta_ndcg = ptranking/metric/metric_utils.py:19-45, weighted BCE over the upper
+ * triangle) and its backward, fused into one kernel.  `labels` must be in ideal (descending) order per query, as
+ * the reference asserts (lambdarank.py:36).  sigma must be >= 0.  Ties in `preds` are ranked by original index. */
+int ptr_lambdarank_fwd_bwd(const float *preds, const float *labels, const int32_t *lens, int B, int L, float sigma,
+                           float *loss_out, float *loss_q, float *grad, void *stream);
+
+/* LambdaLoss — replaces ptranking/ltr_adhoc/listwise/lambdaloss.py:83-132 and its backward.
+ * loss_type: PTR_LAMBDALOSS_*; k = truncation (pairs with both ranks < k); mu only used by NDCG_Loss2++;
+ * presort != 0 => labels already in ideal order (lambdaloss.py:83-84), else they are sorted first (:86-87). */
+int ptr_lambdaloss_fwd_bwd(const float *preds, const float *labels, const int32_t *lens, int B, int L, int k,
+                           float sigma, float mu, int loss_type, int presort, float *loss_out, float *loss_q,
+                           float *grad, void *stream);
+
+/* ApproxNDCG — replaces ptranking/ltr_adhoc/listwise/approxNDCG.py:19-27,45-62 (+ Robust_Sigmoid,
+ * ptranking/base/utils.py:57-95) and its backward.  alpha must be > 0.
+ * couple_batch != 0 reproduces the reference: loss = -(sum_b DCG_b) * S, S = sum_a 1/IDCG_a, gradients scaled by
+ * S (SURVEY.md §7 vi); couple_batch == 0 gives the per-query normalised form -sum_b DCG_b/IDCG_b.
+ * Outputs: loss_out[1]; dcg_q[B] (approximate DCG per query); inv_idcg_q[B]; grad[B,L] (fully scaled);
+ * scale_out[2] = {factor applied to the gradients, local S}.  With couple_batch != 0 and grad_scale_override > 0 the
+ * gradients and loss are scaled with that value instead of the local S (data parallel: pass 1.0, all-reduce the
+ * local S with the parameter gradients and rescale them afterwards — they are linear in S). */
+int ptr_approxndcg_fwd_bwd(const float *preds, const float *labels, const int32_t *lens, int B, int L, float alpha,
+                           int presort, int couple_batch, float grad_scale_override, float *loss_out, float *dcg_q,
+                           float *inv_idcg_q, float *scale_out, float *grad, void *stream);
+
+/* ListNet — replaces ptranking/ltr_adhoc/listwise/listnet.py:39 and its backward. */
+int ptr_listnet_fwd_bwd(const float *preds, const float *labels, const int32_t *lens, int B, int L, float *loss_out,
+                        float *loss_q, float *grad, void *stream);
+
+/* ListMLE — replaces ptranking/ltr_adhoc/listwise/listmle.py:82,92-97 and its backward.  `perm` (int64[B,L]) is
+ * the tie-shuffled label-descending order the reference obtains from arg_shuffle_ties
+ * (ptranking/ltr_adhoc/util/sampling_utils.py:13-28); row q holds a permutation of 0..len_q-1 in its first len_q
+ * entries. */
+int ptr_listmle_fwd_bwd(const float *preds, const int64_t *perm, const int32_t *lens, int B, int L, float *loss_out,
+                        float *loss_q, float *grad, void *stream);
+
+/* Device tie-shuffled label-descending order (the role of arg_shuffle_ties, sampling_utils.py:13-28) from a
+ * counter-based RNG: same distribution, NOT the torch.randperm stream (not parity-checked, statistically tested). */
+int ptr_shuffle_ties_order(const float *labels, const int32_t *lens, int B, int L, uint64_t seed, int64_t *perm,
+                           void *stream);
+
+/* torch.sort(preds, dim=1, descending=True) as ptranking/base/ranker.py:50 and lambdarank.py:39 call it:
+ * vals[B,L] fp32, idx[B,L] int64; order = (value descending, original index ascending); padded tail: 0 / identity. */
+int ptr_sort_desc(const float *preds, const int32_t *lens, int B, int L, float *vals, int64_t *idx, void *stream);
+
+/* Evaluator prologue + metrics — replaces ptranking/base/ranker.py:46-60,220-243 (sort, gather, ideal sort) and
+ * ptranking/metric/adhoc/adhoc_metric.py:36-62 (P@ks), :91-123 (AP@ks), :127-193 (nERR@ks), :219-260 (nDCG@ks).
+ *   ks: HOST int32[nk] cut-offs (nk <= PTR_MAX_CUTOFFS); presort != 0 => labels already ideal-ordered;
+ *   max_label: nERR's 2^max_label normaliser; < 0 => the batch maximum is computed on device into max_label_ws[1];
+ *   ndcg/nerr/ap/prec: [B,nk] outputs, each nullable.  Cut-offs larger than the list are zero-filled at the END
+ *   of the row exactly like the reference's padded_*_at_ks. */
+int ptr_metrics_at_ks(const float *preds, const float *labels, const int32_t *lens, int B, int L, const int32_t *ks,
+                      int nk, int presort, float max_label, float *max_label_ws, float *ndcg, float *nerr, float *ap,
+                      float *prec, void *stream);
+
+/* Deterministic sum of n floats (fixed reduction tree): out[0] = scale * sum(x).  Used for the per-query loss slots
+ * and for Evaluator running sums. */
+int ptr_sum_f32(const float *x, int n, float scale, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTRANKING_AMD_H */

@@ -1,0 +1,105 @@
+"""ctypes binding of libptranking_amd.so (the C ABI declared in include/ptranking_amd.h).
+
+The product path has exactly one implementation: the HIP kernels behind this library.  There is no CPU or eager
+fallback — if the library is missing, or a tensor is not on the GPU, the call fails loudly.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  — must be imported first so that OUR .so binds to the HIP runtime torch already loaded
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libptranking_amd.so")
+
+ABI_VERSION = 1
+MAX_LIST_LEN = 4096
+MAX_CUTOFFS = 32
+
+_vp, _i, _f, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_uint64
+
+# name -> argtypes (restype is int unless listed in _RESTYPES).  Mirrors include/ptranking_amd.h one to one.
+SIGNATURES = {
+    "ptr_abi_version": [],
+    "ptr_last_error": [],
+    "ptr_ranknet_fwd_bwd": [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp],
+    "ptr_lambdarank_fwd_bwd": [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp],
+    "ptr_lambdaloss_fwd_bwd": [_vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp],
+    "ptr_approxndcg_fwd_bwd": [_vp, _vp, _vp, _i, _i, _f, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ptr_listnet_fwd_bwd": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
+    "ptr_listmle_fwd_bwd": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
+    "ptr_shuffle_ties_order": [_vp, _vp, _i, _i, _u64, _vp, _vp],
+    "ptr_sort_desc": [_vp, _vp, _i, _i, _vp, _vp, _vp],
+    "ptr_metrics_at_ks": [_vp, _vp, _vp, _i, _i, C.POINTER(C.c_int32), _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ptr_sum_f32": [_vp, _i, _f, _vp, _vp],
+    "ptr_mlp_forward": [_vp, _vp, _i, _i, _i, _i, _f, _u64, _vp, _vp, _vp],
+    "ptr_mlp_backward": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _vp, _vp, _vp],
+    "ptr_adam_step": [_vp, _vp, _vp, _vp, C.c_int64, _f, _f, _f, _f, _f, _i, _vp],
+}
+_RESTYPES = {"ptr_last_error": C.c_char_p}
+OPTIONAL = {"ptr_mlp_forward", "ptr_mlp_backward", "ptr_adam_step"}
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises NativeLibraryError when the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} is missing: build the HIP extension first (python -m ptranking_amd.build, or "
+            f"__graft_entry__.build()).  ptranking_amd has no CPU / eager fallback by design.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            if name in OPTIONAL:
+                continue
+            raise NativeLibraryError(f"{LIB_PATH} does not export {name}; rebuild it")
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    v = lib.ptr_abi_version()
+    if v != ABI_VERSION:
+        raise NativeLibraryError(f"ABI version mismatch: library {v}, binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def has(name):
+    return hasattr(load(), name)
+
+
+# Optional profiling hook (bench.py): TIMING = {} makes call() bracket every entry point with HIP events recorded on
+# torch's current stream (the stream the kernels are enqueued on); TIMING[name] collects (start, end) event pairs.
+TIMING = None
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point; raise RuntimeError(ptr_last_error()) on a non-zero return."""
+    lib = load()
+    if TIMING is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        rc = getattr(lib, name)(*args)
+        ev1.record()
+        TIMING.setdefault(name, []).append((ev0, ev1))
+    else:
+        rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.ptr_last_error()
+        raise RuntimeError(f"{name} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

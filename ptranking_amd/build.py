@@ -1,0 +1,69 @@
+"""Builds ptranking_amd/libptranking_amd.so (hand-written HIP kernels + the C ABI) for gfx950 with hipcc.
+
+`python -m ptranking_amd.build [--force]`.  hipcc cross-compiles without a GPU; the resulting .so is git-ignored
+but travels with the tree to the GPU box.  One translation unit per kernel family, linked into one shared library
+whose only runtime dependency is the HIP runtime (libamdhip64) — no torch types anywhere in the ABI.
+"""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+OBJ_DIR = os.path.join(PKG_DIR, "csrc", "build")
+LIB_PATH = os.path.join(PKG_DIR, "libptranking_amd.so")
+ARCH = "gfx950"
+SOURCES = ["abi.hip", "pairwise.hip", "lambdaloss.hip", "approxndcg.hip", "listwise.hip", "metrics.hip", "scorer.hip"]
+HEADERS = ["ptr_device.h", os.path.join("..", "..", "include", "ptranking_amd.h")]
+CXXFLAGS = ["-O3", "-std=c++20", "-fPIC", "-fno-gpu-rdc", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+            "-ffp-contract=off"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (expected /opt/rocm/bin/hipcc)")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 and link the shared library.  Returns the library path."""
+    hipcc = _hipcc()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    jobs = []
+    objs = []
+    for s in srcs:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ_DIR, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append([hipcc] + CXXFLAGS + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout)
+        return r.stdout
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or _stale(LIB_PATH, objs):
+        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB_PATH] + objs)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

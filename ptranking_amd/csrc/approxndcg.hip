@@ -1,0 +1,255 @@
+// Fused ApproxNDCG kernels.
+//
+// Reference: ptranking/ltr_adhoc/listwise/approxNDCG.py:19-27 (approximate ranks), :45-62 (loss), :83-109 (ranker),
+//            Robust_Sigmoid ptranking/base/utils.py:57-95.
+//
+//   pi_hat_i = 0.5 + sum_j rs(alpha * (s_j - s_i))          (j == i contributes 0.5)
+//   DCG_b    = sum_i (2^l_i - 1) / log2(pi_hat_i + 1)       in ideal (label-descending) order
+//   loss     = -(sum_b DCG_b) * (sum_a 1/IDCG_a)            <- the reference's [B]/[B,1] broadcast (SURVEY.md §7 vi)
+//
+// Kernel 1 (per query, O(L^2) sigmoids, two circulant half-matrix passes):
+//   pass 1: every unordered pair {a,b} is visited once; e = exp(-alpha*|s_a - s_b|) gives BOTH indicators
+//           (1/(1+e) for the higher score's partner, e/(1+e) for the other) — Robust_Sigmoid's two branches;
+//   pass 2: gradient; d(pi_hat_a)/d(s_b) = alpha*y_ab*(1-y_ab) with y_ab the stored-forward value, exactly the tensor the
+//           reference saves for backward (base/utils.py:78-79).
+//   Outputs per query: DCG_b, 1/IDCG_b and the gradient for scale 1 (or already times 1/IDCG_b when un-coupled).
+// Kernel 2 (one workgroup): S = sum 1/IDCG, loss, scale.   Kernel 3: grad *= S (coupled mode only).
+#include "ptr_device.h"
+
+namespace ptr {
+
+// LDS per group (floats): S_id[Lp] | Y_id[Lp] | acc[NW][Lp] | red[4]
+__host__ __device__ constexpr size_t approx_group_floats(int Lp, int NW) { return (size_t)Lp * (2 + NW) + 4; }
+
+// Both Robust_Sigmoid values of an unordered pair from one exponential.
+// delta = s_b - s_a.  ya = rs(alpha*delta) (contribution of b to pi_hat_a), yb = rs(-alpha*delta).
+__device__ __forceinline__ void robust_pair(float delta, float alpha, float &ya, float &yb) {
+    const float x = alpha * fabsf(delta);
+    const float e = __expf(-x);
+    const float dd = 1.0f + e;
+    float r = __builtin_amdgcn_rcpf(dd);
+    r = fmaf(r, fmaf(-dd, r, 1.0f), r);          // 1/(1+e)      (base/utils.py:71)
+    const float sm = e * r;                       // e/(1+e)      (base/utils.py:73-74)
+    const bool pos = delta > 0.0f, neg = delta < 0.0f;
+    ya = pos ? r : (neg ? sm : 0.5f);
+    yb = pos ? sm : (neg ? r : 0.5f);
+}
+
+template <int G, int DPT>
+__global__ void __launch_bounds__(kBlock)
+approxndcg_kernel(const float *__restrict__ preds, const float *__restrict__ labels, const int32_t *__restrict__ lens, int B,
+                  int L, int Lp, float alpha, int presort, int couple_batch, float *__restrict__ dcg_q,
+                  float *__restrict__ inv_idcg_q, float *__restrict__ grad) {
+    constexpr int QPB = kBlock / G, NW = G / kWave;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, grp = tid / G, t = tid % G, wv = t >> 6;
+    const int q = blockIdx.x * QPB + grp;
+    const bool valid = q < B;
+    const int n = valid ? query_len(lens, q, L) : 0;
+
+    float *base = smem + (size_t)grp * approx_group_floats(Lp, NW);
+    float *S_id = base, *Y_id = base + Lp, *acc = base + 2 * (size_t)Lp, *red = acc + (size_t)NW * Lp;
+
+    float si[DPT], li[DPT];
+    int ipos[DPT];
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int i = t + m * G;
+        const bool in = i < n;
+        si[m] = in ? preds[(size_t)q * L + i] : -INFINITY;
+        li[m] = in ? labels[(size_t)q * L + i] : 0.0f;
+        if (i < Lp) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) acc[(size_t)w * Lp + i] = 0.0f;
+        }
+    }
+    stage_ideal_order<G, DPT>(S_id, Y_id, n, Lp, t, presort != 0, si, li, ipos);
+
+    // thread t owns ideal positions a = t + m*G
+    float sa[DPT], gna[DPT], pia[DPT];
+    float part = 0.0f;
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int a = t + m * G;
+        sa[m] = a < n ? S_id[a] : 0.0f;
+        gna[m] = a < n ? gain_of(Y_id[a]) : 0.0f;
+        pia[m] = 0.0f;
+        if (a < n) part += gna[m] / log2f((float)a + 2.0f);
+    }
+    const float idcg = group_sum<G>(part, red, t);
+    float *aw = acc + (size_t)wv * Lp;
+    const int half = (n - 1) >> 1;
+
+    // ---- pass 1: approximate rank positions
+    for (int d = 1; d <= half; ++d) {
+#pragma unroll
+        for (int m = 0; m < DPT; ++m) {
+            const int a = t + m * G;
+            if (a < n) {
+                int b = a + d; if (b >= n) b -= n;
+                float ya, yb;
+                robust_pair(S_id[b] - sa[m], alpha, ya, yb);
+                pia[m] += ya;
+                atomicAdd(&aw[b], yb);
+            }
+        }
+    }
+    if (n > 0 && (n & 1) == 0) {
+        const int d = n >> 1;
+#pragma unroll
+        for (int m = 0; m < DPT; ++m) {
+            const int a = t + m * G;
+            if (a < d) {
+                float ya, yb;
+                robust_pair(S_id[a + d] - sa[m], alpha, ya, yb);
+                pia[m] += ya;
+                atomicAdd(&aw[a + d], yb);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- per-position DCG term and dLoss/d(pi_hat) (for scale 1)
+    const float ln2 = 0.6931471805599453f;
+    float ca[DPT];
+    float dpart = 0.0f;
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int a = t + m * G;
+        ca[m] = 0.0f;
+        if (a < n) {
+            float pi = pia[m];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) pi += acc[(size_t)w * Lp + a];
+            pi += 1.0f;                                       // 0.5 (diagonal term) + 0.5 (approxNDCG.py:25)
+            const float lg = log2f(pi + 1.0f);
+            dpart += gna[m] / lg;                             // approxNDCG.py:58
+            ca[m] = gna[m] / (ln2 * (1.0f + pi) * lg * lg);   // d(-g/log2(1+pi))/d(pi)
+        }
+    }
+    const float dcg = group_sum<G>(dpart, red, t);            // (G == 256: contains the barriers that fence `acc` reuse)
+    if constexpr (G == kWave) __syncthreads();
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int a = t + m * G;
+        if (a < Lp) {
+            Y_id[a] = ca[m];                                  // c by ideal position (labels no longer needed)
+#pragma unroll
+            for (int w = 0; w < NW; ++w) acc[(size_t)w * Lp + a] = 0.0f;
+        }
+    }
+    __syncthreads();
+
+    // ---- pass 2: gradient.  Entry (a,b): pi_hat_a depends on s_b with +d_ab and on s_a with -d_ab, d_ab = (alpha*y_ab)*(1-y_ab).
+    float ga[DPT];
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) ga[m] = 0.0f;
+    auto gpair = [&](int m, int a, int b) {
+        float ya, yb;
+        robust_pair(S_id[b] - sa[m], alpha, ya, yb);
+        const float dab = (alpha * ya) * (1.0f - ya);         // base/utils.py:78
+        const float dba = (alpha * yb) * (1.0f - yb);
+        const float cb = Y_id[b];
+        const float flow = cb * dba - ca[m] * dab;            // d loss / d s_a from this pair
+        ga[m] += flow;
+        atomicAdd(&aw[b], -flow);
+    };
+    for (int d = 1; d <= half; ++d) {
+#pragma unroll
+        for (int m = 0; m < DPT; ++m) {
+            const int a = t + m * G;
+            if (a < n) { int b = a + d; if (b >= n) b -= n; gpair(m, a, b); }
+        }
+    }
+    if (n > 0 && (n & 1) == 0) {
+        const int d = n >> 1;
+#pragma unroll
+        for (int m = 0; m < DPT; ++m) {
+            const int a = t + m * G;
+            if (a < d) gpair(m, a, a + d);
+        }
+    }
+    __syncthreads();
+
+    const float inv_idcg = 1.0f / idcg;
+    const float scale = couple_batch ? 1.0f : inv_idcg;
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int a = t + m * G;
+        if (a < n) {
+            float tot = ga[m];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tot += acc[(size_t)w * Lp + a];
+            S_id[a] = tot * scale;                            // own index only
+        }
+    }
+    __syncthreads();
+    if (valid) {
+#pragma unroll
+        for (int m = 0; m < DPT; ++m) {
+            const int i = t + m * G;
+            if (i < L) grad[(size_t)q * L + i] = i < n ? S_id[ipos[m]] : 0.0f;
+        }
+        if (t == 0) { dcg_q[q] = dcg; inv_idcg_q[q] = inv_idcg; }
+    }
+}
+
+// One workgroup: S = sum 1/IDCG, loss, the factor kernel 3 applies.  out_scale[0] = applied factor, out_scale[1] = local S.
+__global__ void __launch_bounds__(kBlock)
+approx_finish_kernel(const float *__restrict__ dcg_q, const float *__restrict__ inv_q, int B, int couple_batch,
+                     float scale_override, float *__restrict__ loss_out, float *__restrict__ scale_ws) {
+    __shared__ float red[4];
+    float sd = 0.0f, ss = 0.0f, sn = 0.0f;
+    for (int i = threadIdx.x; i < B; i += kBlock) { const float d = dcg_q[i], v = inv_q[i]; sd += d; ss += v; sn += d * v; }
+    const float D = group_sum<kBlock>(sd, red, threadIdx.x);
+    const float S = group_sum<kBlock>(ss, red, threadIdx.x);
+    const float N = group_sum<kBlock>(sn, red, threadIdx.x);
+    if (threadIdx.x == 0) {
+        const float f = couple_batch ? (scale_override > 0.0f ? scale_override : S) : 1.0f;
+        loss_out[0] = couple_batch ? -(D * f) : -N;
+        scale_ws[0] = f;
+        scale_ws[1] = S;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) scale_inplace_kernel(float *__restrict__ x, size_t n, const float *__restrict__ f) {
+    const float s = f[0];
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) x[i] *= s;
+}
+
+}  // namespace ptr
+
+extern "C" int ptr_approxndcg_fwd_bwd(const float *preds, const float *labels, const int32_t *lens, int B, int L, float alpha,
+                                      int presort, int couple_batch, float grad_scale_override, float *loss_out, float *dcg_q,
+                                      float *inv_idcg_q, float *scale_out, float *grad, void *stream) {
+    using namespace ptr;
+    const char *who = "ptr_approxndcg_fwd_bwd";
+    if (int rc = check_batch(preds, labels, B, L, who)) return rc;
+    if (!loss_out || !dcg_q || !inv_idcg_q || !grad || !scale_out) { set_error("%s: NULL output pointer", who); return PTR_ERR_INVALID_ARG; }
+    if (!(alpha > 0.0f)) { set_error("%s: alpha must be > 0 (got %g)", who, (double)alpha); return PTR_ERR_INVALID_ARG; }
+    hipStream_t st = as_stream(stream);
+    if (B > 0) {
+        const int Lp = round_up(L, 4);
+        int rc = dispatch_tiling(L, [&]<int G, int DPT>() -> int {
+            constexpr int QPB = kBlock / G, NW = G / kWave;
+            auto kern = approxndcg_kernel<G, DPT>;
+            const size_t lds = QPB * approx_group_floats(Lp, NW) * sizeof(float);
+            if (int e = allow_lds(kern, lds)) return e;
+            hipLaunchKernelGGL(kern, dim3((B + QPB - 1) / QPB), dim3(kBlock), lds, st, preds, labels, lens, B, L, Lp, alpha, presort,
+                               couple_batch, dcg_q, inv_idcg_q, grad);
+            return check_hip(hipGetLastError(), who);
+        });
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(approx_finish_kernel, dim3(1), dim3(kBlock), 0, st, dcg_q, inv_idcg_q, B, couple_batch, grad_scale_override,
+                       loss_out, scale_out);
+    if (int rc = check_hip(hipGetLastError(), who)) return rc;
+    if (couple_batch && B > 0 && grad_scale_override != 1.0f) {
+        const size_t nel = (size_t)B * L;
+        const int blocks = (int)((nel + kBlock * 4 - 1) / (kBlock * 4));
+        hipLaunchKernelGGL(scale_inplace_kernel, dim3(blocks < 2048 ? (blocks < 1 ? 1 : blocks) : 2048), dim3(kBlock), 0, st, grad, nel,
+                           scale_out);
+        if (int rc = check_hip(hipGetLastError(), who)) return rc;
+    }
+    return 0;
+}

@@ -1,0 +1,206 @@
+// Fused LambdaLoss kernel (NDCG_Loss2 / NDCG_Loss2++): ideal-order staging -> rank by score -> normalised gains ->
+// the k x k block of (winner, loser) pairs -> gradient scattered back through both permutations.
+//
+// Reference: ptranking/ltr_adhoc/listwise/lambdaloss.py:36-58 (power weights), :83-132 (loss), epsilon = 1e-8
+// (ptranking/ltr_global.py:10).  Bug-compatible details reproduced on purpose (SURVEY.md §7 iii):
+//   * the discount table is inverted twice: inv[r] = (1/log2(r+2))^-1, delta_d = |inv[d-1] - inv[d]|,
+//     rho_ij = |inv[i] - inv[j]| (not the paper's |1/D - 1/D|);
+//   * the mask is `label_i > label_j` AND both predicted ranks < k (a full-matrix mask: every unordered pair with
+//     different grades contributes exactly one term, seen from its winner);
+//   * clamp(min=1e-8) before and after the power, log2 (not ln), score differences clamped to +-1e8, NaN -> 0.
+#include "ptr_device.h"
+
+namespace ptr {
+
+// LDS per group (floats): pk float4[Lp] | S_id[Lp] | Y_id[Lp] | extra[max(NW-2,0)][Lp] | red[4].  Once the per-rank tile pk
+// is built, S_id / Y_id are dead and become partner-gradient accumulator rows 0 / 1 (rows 2.. live in `extra`).
+__host__ __device__ constexpr size_t lambdaloss_group_floats(int Lp, int NW) {
+    return (size_t)Lp * (4 + 2 + (NW > 2 ? NW - 2 : 0)) + 4;
+}
+
+template <int G, int DPT>
+__global__ void __launch_bounds__(kBlock)
+lambdaloss_kernel(const float *__restrict__ preds, const float *__restrict__ labels, const int32_t *__restrict__ lens, int B,
+                  int L, int Lp, int k, float sigma, float mu, int loss_type, int presort, float *__restrict__ loss_q,
+                  float *__restrict__ grad) {
+    constexpr int QPB = kBlock / G, NW = G / kWave;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, grp = tid / G, t = tid % G, wv = t >> 6;
+    const int q = blockIdx.x * QPB + grp;
+    const bool valid = q < B;
+    const int n = valid ? query_len(lens, q, L) : 0;
+
+    float *base = smem + (size_t)grp * lambdaloss_group_floats(Lp, NW);
+    float4 *pk = reinterpret_cast<float4 *>(base);   // by predicted rank: {score, normalised gain, inv[rank], label}
+    float *S_id = base + 4 * (size_t)Lp;              // scores by ideal position; later: accumulator row 0 / grad by rank
+    float *Y_id = S_id + Lp;                          // labels by ideal position; later: accumulator row 1 / grad by ideal pos
+    float *extra = Y_id + Lp;                         // accumulator rows 2..NW-1
+    float *red = extra + (size_t)(NW > 2 ? NW - 2 : 0) * Lp;
+    auto acc_row = [&](int w) -> float * { return w == 0 ? S_id : (w == 1 ? Y_id : extra + (size_t)(w - 2) * Lp); };
+
+    float si[DPT], li[DPT];
+    int ipos[DPT];
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int i = t + m * G;
+        const bool in = i < n;
+        si[m] = in ? preds[(size_t)q * L + i] : -INFINITY;
+        li[m] = in ? labels[(size_t)q * L + i] : 0.0f;
+    }
+    stage_ideal_order<G, DPT>(S_id, Y_id, n, Lp, t, presort != 0, si, li, ipos);
+
+    // from here on thread t owns IDEAL POSITIONS p = t + m*G
+    float sp[DPT], yp[DPT];
+    int rk[DPT];
+    float part = 0.0f;
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int p = t + m * G;
+        sp[m] = p < Lp ? S_id[p] : -INFINITY;
+        yp[m] = p < Lp ? Y_id[p] : 0.0f;
+        if (p < n) part += gain_of(yp[m]) / log2f((float)p + 2.0f);     // adhoc_metric.py:205-217 on the ideal ranking
+    }
+    count_ranks<G, DPT>(S_id, n, t, sp, rk);                              // lambdaloss.py:89
+    const float idcg = group_sum<G>(part, red, t);
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int p = t + m * G;
+        if (p < n) {
+            float *dst = reinterpret_cast<float *>(pk + rk[m]);
+            dst[0] = sp[m];
+            dst[1] = gain_of(yp[m]) / idcg;                               // lambdaloss.py:106
+            dst[3] = yp[m];
+            const float disc = 1.0f / log2f((float)p + 2.0f);             // lambdaloss.py:94
+            reinterpret_cast<float *>(pk + p)[2] = 1.0f / disc;           // torch.pow(discounts, -1.) (:41,49)
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int p = t + m * G;
+        if (p < Lp) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) acc_row(w)[p] = 0.0f;
+        }
+    }
+    __syncthreads();
+
+    const int kk = k < n ? (k < 0 ? 0 : k) : n;
+    const float eps = 1e-8f, inv_ln2 = 1.4426950408889634f;
+    float4 me[DPT];
+    float ga[DPT];
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int a = t + m * G;
+        me[m] = a < kk ? pk[a] : make_float4(0.f, 0.f, 0.f, 0.f);
+        ga[m] = 0.0f;
+    }
+    float lacc = 0.0f;
+    float *gw = acc_row(wv);
+
+    auto pair = [&](int m, int a, int d, float delta_fwd, float delta_wrap) {
+        int b = a + d;
+        const bool fwd = b < kk;
+        if (!fwd) b -= kk;
+        const float4 o = pk[b];
+        const bool a_wins = me[m].w > o.w, b_wins = o.w > me[m].w;        // lambdaloss.py:127-128
+        if (!(a_wins || b_wins)) return;
+        const float delta = fwd ? delta_fwd : delta_wrap;                  // |rank distance| = d or kk - d
+        const float absG = fabsf(me[m].y - o.y);
+        float w = delta * absG;                                            // NDCG_Loss2, lambdaloss.py:44
+        if (loss_type == PTR_LAMBDALOSS_NDCG_LOSS2PP) w = (fabsf(me[m].z - o.z) + mu * delta) * absG;   // :57
+        float df = a_wins ? me[m].x - o.x : o.x - me[m].x;                 // s_winner - s_loser
+        df = fminf(fmaxf(df, -1e8f), 1e8f);
+        if (df != df) df = 0.0f;                                           // lambdaloss.py:115-116
+        const float p0 = 1.0f / (1.0f + expf(-(sigma * df)));
+        const float p = fmaxf(p0, eps);
+        const float wp0 = exp2f(w * log2f(p));                             // p ** w
+        const float wp = fmaxf(wp0, eps);
+        lacc -= log2f(wp);                                                 // lambdaloss.py:118-119,132
+        float g = 0.0f;
+        if (p0 >= eps && wp0 >= eps) g = -(w * sigma * (1.0f - p0)) * inv_ln2;   // d/ds_winner; loser gets -g
+        const float ga_ = a_wins ? g : -g;
+        ga[m] += ga_;
+        atomicAdd(&gw[b], -ga_);
+    };
+
+    const int half = (kk - 1) >> 1;
+    for (int d = 1; d <= half; ++d) {
+        const float dfw = fabsf(reinterpret_cast<const float *>(pk + (d - 1))[2] - reinterpret_cast<const float *>(pk + d)[2]);
+        const int dw = kk - d;
+        const float dwr = fabsf(reinterpret_cast<const float *>(pk + (dw - 1))[2] - reinterpret_cast<const float *>(pk + dw)[2]);
+#pragma unroll
+        for (int m = 0; m < DPT; ++m) {
+            const int a = t + m * G;
+            if (a < kk) pair(m, a, d, dfw, dwr);
+        }
+    }
+    if (kk > 0 && (kk & 1) == 0) {
+        const int d = kk >> 1;
+        const float dfw = fabsf(reinterpret_cast<const float *>(pk + (d - 1))[2] - reinterpret_cast<const float *>(pk + d)[2]);
+#pragma unroll
+        for (int m = 0; m < DPT; ++m) {
+            const int a = t + m * G;
+            if (a < d) pair(m, a, d, dfw, dfw);
+        }
+    }
+    __syncthreads();
+
+    // gradient by predicted rank -> by ideal position -> by original index
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int a = t + m * G;
+        if (a < n) {
+            float tot = ga[m];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tot += acc_row(w)[a];
+            S_id[a] = tot;                               // own index only: safe to overwrite row 0 in place
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int p = t + m * G;
+        if (p < n) Y_id[p] = S_id[rk[m]];
+    }
+    __syncthreads();
+    const float loss = group_sum<G>(lacc, red, t);
+    if (valid) {
+#pragma unroll
+        for (int m = 0; m < DPT; ++m) {
+            const int i = t + m * G;
+            if (i < L) grad[(size_t)q * L + i] = i < n ? Y_id[ipos[m]] : 0.0f;
+        }
+        if (t == 0) loss_q[q] = loss;
+    }
+}
+
+}  // namespace ptr
+
+extern "C" int ptr_lambdaloss_fwd_bwd(const float *preds, const float *labels, const int32_t *lens, int B, int L, int k,
+                                      float sigma, float mu, int loss_type, int presort, float *loss_out, float *loss_q,
+                                      float *grad, void *stream) {
+    using namespace ptr;
+    const char *who = "ptr_lambdaloss_fwd_bwd";
+    if (int rc = check_batch(preds, labels, B, L, who)) return rc;
+    if (!loss_q || !grad) { set_error("%s: NULL output pointer", who); return PTR_ERR_INVALID_ARG; }
+    if (loss_type != PTR_LAMBDALOSS_NDCG_LOSS2 && loss_type != PTR_LAMBDALOSS_NDCG_LOSS2PP) {
+        set_error("%s: loss_type %d not supported (1 = NDCG_Loss2, 2 = NDCG_Loss2++)", who, loss_type);
+        return PTR_ERR_INVALID_ARG;
+    }
+    hipStream_t st = as_stream(stream);
+    if (B > 0) {
+        const int Lp = round_up(L, 4);
+        int rc = dispatch_tiling(L, [&]<int G, int DPT>() -> int {
+            constexpr int QPB = kBlock / G, NW = G / kWave;
+            auto kern = lambdaloss_kernel<G, DPT>;
+            const size_t lds = QPB * lambdaloss_group_floats(Lp, NW) * sizeof(float);
+            if (int e = allow_lds(kern, lds)) return e;
+            hipLaunchKernelGGL(kern, dim3((B + QPB - 1) / QPB), dim3(kBlock), lds, st, preds, labels, lens, B, L, Lp, k, sigma, mu,
+                               loss_type, presort, loss_q, grad);
+            return check_hip(hipGetLastError(), who);
+        });
+        if (rc) return rc;
+    }
+    return loss_out ? ptr_sum_f32(loss_q, B, 1.0f, loss_out, stream) : 0;
+}

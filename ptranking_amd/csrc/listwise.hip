@@ -1,0 +1,221 @@
+// Listwise softmax-over-list kernels: ListNet, ListMLE, and the device tie-shuffle that feeds ListMLE.
+// These are the HBM-bound members of the path: O(L) work per query, one wavefront per query, the query tile staged once
+// in LDS (one coalesced HBM read of scores/labels[/perm], one coalesced write of the gradient).
+//
+// Reference: ptranking/ltr_adhoc/listwise/listnet.py:39; ptranking/ltr_adhoc/listwise/listmle.py:82,92-97;
+//            ptranking/ltr_adhoc/util/sampling_utils.py:13-28 (arg_shuffle_ties).
+#include "ptr_device.h"
+
+namespace ptr {
+
+// queries per workgroup given the LDS bytes one query needs (one wave per query, at most 4 waves)
+static inline int waves_per_block(size_t bytes_per_query) {
+    const size_t budget = 150 * 1024;
+    int w = (int)(budget / (bytes_per_query ? bytes_per_query : 1));
+    return w >= 4 ? 4 : (w >= 2 ? 2 : 1);
+}
+
+// ------------------------------------------------------------------------------------------------ ListNet
+// loss_q = -sum_i softmax(labels)_i * log_softmax(preds)_i ; grad_i = softmax(preds)_i * sum_j softmax(labels)_j - softmax(labels)_i
+__global__ void __launch_bounds__(kBlock)
+listnet_kernel(const float *__restrict__ preds, const float *__restrict__ labels, const int32_t *__restrict__ lens, int B, int L,
+               int Lp, float *__restrict__ loss_q, float *__restrict__ grad) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    const int q = blockIdx.x * wpb + wv;
+    if (q >= B) return;                                   // no workgroup barriers below: waves are independent
+    const int n = query_len(lens, q, L);
+    float *s = smem + (size_t)wv * 2 * Lp, *y = s + Lp;
+    const float *ps = preds + (size_t)q * L, *py = labels + (size_t)q * L;
+
+    float ms = -INFINITY, my = -INFINITY;
+    for (int i = lane; i < n; i += 64) {
+        const float a = ps[i], b = py[i];
+        s[i] = a; y[i] = b;
+        ms = fmaxf(ms, a); my = fmaxf(my, b);
+    }
+    ms = wave_max(ms); my = wave_max(my);
+    float zs = 0.0f, zy = 0.0f;
+    for (int i = lane; i < n; i += 64) {                  // each lane re-reads only what it wrote: no fence needed
+        const float ea = expf(s[i] - ms), eb = expf(y[i] - my);
+        y[i] = eb;
+        zs += ea; zy += eb;
+    }
+    zs = wave_sum(zs); zy = wave_sum(zy);
+    const float lzs = logf(zs);
+    float loss = 0.0f, sumpy = 0.0f;
+    for (int i = lane; i < n; i += 64) {
+        const float pyv = y[i] / zy;
+        const float lsm = (s[i] - ms) - lzs;              // log_softmax
+        loss -= pyv * lsm;
+        sumpy += pyv;
+        y[i] = pyv; s[i] = lsm;
+    }
+    loss = wave_sum(loss); sumpy = wave_sum(sumpy);
+    float *g = grad + (size_t)q * L;
+    for (int i = lane; i < L; i += 64) g[i] = i < n ? expf(s[i]) * sumpy - y[i] : 0.0f;   // log_softmax backward
+    if (lane == 0) loss_q[q] = loss;
+}
+
+// ------------------------------------------------------------------------------------------------ ListMLE
+// u = s[perm]; m = max u; T_k = sum_{j>=k} exp(u_j - m); loss = sum_k (log T_k + m - u_k);
+// d loss / d u_k = exp(u_k - m) * sum_{i<=k} 1/T_i - 1, scattered back through perm.
+__global__ void __launch_bounds__(kBlock)
+listmle_kernel(const float *__restrict__ preds, const int64_t *__restrict__ perm, const int32_t *__restrict__ lens, int B, int L,
+               int Lp, float *__restrict__ loss_q, float *__restrict__ grad) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    const int q = blockIdx.x * wpb + wv;
+    if (q >= B) return;
+    const int n = query_len(lens, q, L);
+    float *s = smem + (size_t)wv * 4 * Lp;                // scores by original index; later: gradient by original index
+    float *T = s + Lp;                                    // tail sums by position
+    float *E = T + Lp;                                    // exp(u - m) by position
+    int *pi = reinterpret_cast<int *>(E + Lp);            // permutation, narrowed to int32
+    const float *ps = preds + (size_t)q * L;
+    const int64_t *pp = perm + (size_t)q * L;
+
+    float m = -INFINITY;
+    for (int i = lane; i < n; i += 64) {
+        const float a = ps[i];
+        s[i] = a;
+        m = fmaxf(m, a);
+        long long k = pp[i];
+        pi[i] = (k < 0 || k >= n) ? i : (int)k;           // malformed input cannot index out of the tile
+    }
+    m = wave_max(m);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // s[] / pi[] written by other lanes are read below
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    const int nchunk = (n + 63) >> 6;
+    float carry = 0.0f, loss = 0.0f;
+    for (int c = nchunk - 1; c >= 0; --c) {               // flip-cumsum-flip (listmle.py:95), chunk by chunk from the tail
+        const int k = c * 64 + lane;
+        const bool in = k < n;
+        const float u = in ? s[pi[k]] : 0.0f;
+        const float e = in ? expf(u - m) : 0.0f;
+        const float Tk = wave_incl_suffix_sum(e, lane) + carry;
+        carry = __shfl(Tk, 0, 64);
+        if (in) { T[k] = Tk; E[k] = e; loss += (logf(Tk) + m) - u; }
+    }
+    loss = wave_sum(loss);
+    // every lane now re-reads only its own T[k]/E[k]; the gradient is scattered into s[] which nobody reads any more
+    __builtin_amdgcn_wave_barrier();
+    float pc = 0.0f;
+    for (int c = 0; c < nchunk; ++c) {
+        const int k = c * 64 + lane;
+        const bool in = k < n;
+        const float inv = in ? 1.0f / T[k] : 0.0f;
+        const float P = wave_incl_sum(inv, lane) + pc;
+        pc = __shfl(P, 63, 64);
+        if (in) s[pi[k]] = E[k] * P - 1.0f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    float *g = grad + (size_t)q * L;
+    for (int i = lane; i < L; i += 64) g[i] = i < n ? s[i] : 0.0f;
+    if (lane == 0) loss_q[q] = loss;
+}
+
+// ------------------------------------------------------------------------------------------------ tie shuffle
+__device__ __forceinline__ uint32_t mix64(uint64_t x) {      // splitmix64 finaliser
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return (uint32_t)(x >> 16);
+}
+
+// perm = argsort by (label descending, random key ascending, index ascending): a uniformly random order inside
+// every group of equal labels — the distribution arg_shuffle_ties draws from (sampling_utils.py:13-28).
+__global__ void __launch_bounds__(kBlock)
+shuffle_ties_kernel(const float *__restrict__ labels, const int32_t *__restrict__ lens, int B, int L, int Lp, uint64_t seed,
+                    int64_t *__restrict__ perm) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    const int q = blockIdx.x * wpb + wv;
+    if (q >= B) return;
+    const int n = query_len(lens, q, L);
+    float *y = smem + (size_t)wv * 3 * Lp;
+    uint32_t *r = reinterpret_cast<uint32_t *>(y + Lp);
+    int *out = reinterpret_cast<int *>(y + 2 * Lp);
+    for (int i = lane; i < n; i += 64) {
+        y[i] = labels[(size_t)q * L + i];
+        r[i] = mix64(seed ^ ((uint64_t)q * 0x100000001B3ull + (uint64_t)i) * 0xD6E8FEB86659FD93ull);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int i = lane; i < n; i += 64) {
+        const float yi = y[i];
+        const uint32_t ri = r[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const float yj = y[j];
+            const uint32_t rj = r[j];
+            rank += (yj > yi || (yj == yi && (rj < ri || (rj == ri && j < i)))) ? 1 : 0;
+        }
+        out[rank] = i;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int i = lane; i < L; i += 64) perm[(size_t)q * L + i] = i < n ? (int64_t)out[i] : (int64_t)i;
+}
+
+}  // namespace ptr
+
+extern "C" int ptr_listnet_fwd_bwd(const float *preds, const float *labels, const int32_t *lens, int B, int L, float *loss_out,
+                                   float *loss_q, float *grad, void *stream) {
+    using namespace ptr;
+    const char *who = "ptr_listnet_fwd_bwd";
+    if (int rc = check_batch(preds, labels, B, L, who)) return rc;
+    if (!loss_q || !grad) { set_error("%s: NULL output pointer", who); return PTR_ERR_INVALID_ARG; }
+    if (B > 0) {
+        const int Lp = round_up(L, 4);
+        const size_t per_q = 2 * (size_t)Lp * sizeof(float);
+        const int wpb = waves_per_block(per_q);
+        if (int e = allow_lds(listnet_kernel, wpb * per_q)) return e;
+        hipLaunchKernelGGL(listnet_kernel, dim3((B + wpb - 1) / wpb), dim3(wpb * kWave), wpb * per_q, as_stream(stream), preds, labels,
+                           lens, B, L, Lp, loss_q, grad);
+        if (int rc = check_hip(hipGetLastError(), who)) return rc;
+    }
+    return loss_out ? ptr_sum_f32(loss_q, B, 1.0f, loss_out, stream) : 0;
+}
+
+extern "C" int ptr_listmle_fwd_bwd(const float *preds, const int64_t *perm, const int32_t *lens, int B, int L, float *loss_out,
+                                   float *loss_q, float *grad, void *stream) {
+    using namespace ptr;
+    const char *who = "ptr_listmle_fwd_bwd";
+    if (int rc = check_batch(preds, perm, B, L, who)) return rc;
+    if (!loss_q || !grad) { set_error("%s: NULL output pointer", who); return PTR_ERR_INVALID_ARG; }
+    if (B > 0) {
+        const int Lp = round_up(L, 4);
+        const size_t per_q = 4 * (size_t)Lp * sizeof(float);
+        const int wpb = waves_per_block(per_q);
+        if (int e = allow_lds(listmle_kernel, wpb * per_q)) return e;
+        hipLaunchKernelGGL(listmle_kernel, dim3((B + wpb - 1) / wpb), dim3(wpb * kWave), wpb * per_q, as_stream(stream), preds, perm,
+                           lens, B, L, Lp, loss_q, grad);
+        if (int rc = check_hip(hipGetLastError(), who)) return rc;
+    }
+    return loss_out ? ptr_sum_f32(loss_q, B, 1.0f, loss_out, stream) : 0;
+}
+
+extern "C" int ptr_shuffle_ties_order(const float *labels, const int32_t *lens, int B, int L, uint64_t seed, int64_t *perm,
+                                      void *stream) {
+    using namespace ptr;
+    const char *who = "ptr_shuffle_ties_order";
+    if (int rc = check_batch(labels, perm, B, L, who)) return rc;
+    if (B > 0) {
+        const int Lp = round_up(L, 4);
+        const size_t per_q = 3 * (size_t)Lp * sizeof(float);
+        const int wpb = waves_per_block(per_q);
+        if (int e = allow_lds(shuffle_ties_kernel, wpb * per_q)) return e;
+        hipLaunchKernelGGL(shuffle_ties_kernel, dim3((B + wpb - 1) / wpb), dim3(wpb * kWave), wpb * per_q, as_stream(stream), labels, lens,
+                           B, L, Lp, seed, perm);
+        if (int rc = check_hip(hipGetLastError(), who)) return rc;
+    }
+    return 0;
+}

@@ -1,0 +1,230 @@
+// Evaluation kernels: descending sort with indices, and the fused Evaluator prologue + nDCG / nERR / AP / P at cut-offs.
+//
+// Reference: ptranking/base/ranker.py:46-60 and :220-243 (predict -> .cpu() -> torch.sort -> gather -> ideal sort -> metric),
+//            ptranking/metric/adhoc/adhoc_metric.py:36-62 (P@ks), :91-123 (AP@ks), :127-193 (nERR@ks), :219-260 (nDCG@ks).
+// The reference moves every batch of predictions to the host and sorts there; here the whole chain runs on the device
+// and only [B, len(ks)] numbers per metric ever need to leave it.
+//
+// Per query: stage in ideal order -> rank documents by score (counting sort, (score desc, index asc)) -> labels by
+// predicted rank in LDS -> wave 0 walks the ranking in 64-position chunks with prefix scans (sum / product), writing
+// a result whenever position+1 equals a requested cut-off.  Cut-offs beyond the list are zero-filled at the END of
+// the row, like the reference's padded_*_at_ks.
+#include "ptr_device.h"
+
+namespace ptr {
+
+struct Cutoffs { int nk; int k[PTR_MAX_CUTOFFS]; };
+
+// ------------------------------------------------------------------------------------------------ sort_desc
+template <int G, int DPT>
+__global__ void __launch_bounds__(kBlock)
+sort_desc_kernel(const float *__restrict__ preds, const int32_t *__restrict__ lens, int B, int L, int Lp, float *__restrict__ vals,
+                 int64_t *__restrict__ idx) {
+    constexpr int QPB = kBlock / G;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, grp = tid / G, t = tid % G;
+    const int q = blockIdx.x * QPB + grp;
+    const bool valid = q < B;
+    const int n = valid ? query_len(lens, q, L) : 0;
+    float *keys = smem + (size_t)grp * 3 * Lp, *sv = keys + Lp;
+    int *si_ = reinterpret_cast<int *>(sv + Lp);
+    float own[DPT];
+    int rk[DPT];
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int i = t + m * G;
+        own[m] = i < n ? preds[(size_t)q * L + i] : -INFINITY;
+        if (i < Lp) keys[i] = own[m];
+    }
+    __syncthreads();
+    count_ranks<G, DPT>(keys, n, t, own, rk);
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int i = t + m * G;
+        if (i < n) { sv[rk[m]] = own[m]; si_[rk[m]] = i; }
+    }
+    __syncthreads();
+    if (valid) {
+#pragma unroll
+        for (int m = 0; m < DPT; ++m) {
+            const int r = t + m * G;
+            if (r < L) {
+                vals[(size_t)q * L + r] = r < n ? sv[r] : 0.0f;
+                idx[(size_t)q * L + r] = r < n ? (int64_t)si_[r] : (int64_t)r;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ batch max (nERR normaliser)
+__global__ void __launch_bounds__(kBlock)
+batch_max_kernel(const float *__restrict__ labels, const int32_t *__restrict__ lens, int B, int L, float *__restrict__ out) {
+    __shared__ float red[4];
+    float mx = -INFINITY;
+    const size_t total = (size_t)B * L;
+    for (size_t e = threadIdx.x; e < total; e += kBlock) {
+        const int q = (int)(e / L), i = (int)(e % L);
+        if (i < query_len(lens, q, L)) mx = fmaxf(mx, labels[e]);
+    }
+    mx = group_max<kBlock>(mx, red, threadIdx.x);
+    if (threadIdx.x == 0) out[0] = mx;
+}
+
+// ------------------------------------------------------------------------------------------------ metrics
+// LDS per group (floats): S_id[Lp] | Y_id[Lp] | Y_sys[Lp]
+template <int G, int DPT>
+__global__ void __launch_bounds__(kBlock)
+metrics_kernel(const float *__restrict__ preds, const float *__restrict__ labels, const int32_t *__restrict__ lens, int B, int L,
+               int Lp, Cutoffs ck, int presort, float max_label_host, const float *__restrict__ max_label_dev,
+               float *__restrict__ o_ndcg, float *__restrict__ o_nerr, float *__restrict__ o_ap, float *__restrict__ o_p) {
+    constexpr int QPB = kBlock / G;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, grp = tid / G, t = tid % G;
+    const int q = blockIdx.x * QPB + grp;
+    const bool valid = q < B;
+    const int n = valid ? query_len(lens, q, L) : 0;
+    float *S_id = smem + (size_t)grp * 3 * Lp, *Y_id = S_id + Lp, *Y_sys = Y_id + Lp;
+
+    float si[DPT], li[DPT];
+    int ipos[DPT];
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int i = t + m * G;
+        const bool in = i < n;
+        si[m] = in ? preds[(size_t)q * L + i] : -INFINITY;
+        li[m] = in ? labels[(size_t)q * L + i] : 0.0f;
+    }
+    // NOTE: the reference sorts the predictions in ORIGINAL order (ranker.py:50) — ties are broken by original index —
+    // and sorts the labels separately for the ideal ranking (ranker.py:53-56).  So rank by score first, on the raw tile.
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int i = t + m * G;
+        if (i < Lp) S_id[i] = si[m];
+    }
+    __syncthreads();
+    int rk[DPT];
+    count_ranks<G, DPT>(S_id, n, t, si, rk);
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int i = t + m * G;
+        if (i < n) Y_sys[rk[m]] = li[m];                    // torch.gather(labels, idx), ranker.py:52
+    }
+    __syncthreads();
+    stage_ideal_order<G, DPT>(S_id, Y_id, n, Lp, t, presort != 0, si, li, ipos);   // ends with a barrier
+
+    // ---- wave 0 of the group walks the two rankings
+    if (valid && t < kWave) {
+        const int lane = t;
+        const float max_label = max_label_dev ? max_label_dev[0] : max_label_host;
+        const float pow_max = exp2f(max_label);              // adhoc_metric.py:133
+        float *r_ndcg = o_ndcg ? o_ndcg + (size_t)q * ck.nk : nullptr;
+        float *r_nerr = o_nerr ? o_nerr + (size_t)q * ck.nk : nullptr;
+        float *r_ap = o_ap ? o_ap + (size_t)q * ck.nk : nullptr;
+        float *r_p = o_p ? o_p + (size_t)q * ck.nk : nullptr;
+        int used = 0;
+        for (int c = 0; c < ck.nk; ++c) used += (ck.k[c] >= 1 && ck.k[c] <= n) ? 1 : 0;
+        if (lane < ck.nk && lane >= used) {                  // zero padding goes last (adhoc_metric.py:255-258)
+            if (r_ndcg) r_ndcg[lane] = 0.0f;
+            if (r_nerr) r_nerr[lane] = 0.0f;
+            if (r_ap) r_ap[lane] = 0.0f;
+            if (r_p) r_p[lane] = 0.0f;
+        }
+        int kmax = 0;
+        for (int c = 0; c < ck.nk; ++c) if (ck.k[c] <= n && ck.k[c] > kmax) kmax = ck.k[c];
+        float c_sdcg = 0.f, c_idcg = 0.f, c_rel = 0.f, c_prec = 0.f, c_ideal = 0.f, c_serr = 0.f, c_ierr = 0.f, c_sun = 1.f, c_iun = 1.f;
+        const int nchunk = (kmax + 63) >> 6;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int r = ch * 64 + lane;
+            const bool in = r < kmax;
+            const float ys = in ? Y_sys[r] : 0.0f, yi = in ? Y_id[r] : 0.0f;
+            const float disc = log2f((float)r + 2.0f);
+            const float gs = in ? gain_of(ys) : 0.0f, gi = in ? gain_of(yi) : 0.0f;
+            const float sdcg = wave_incl_sum(in ? gs / disc : 0.0f, lane) + c_sdcg;     // adhoc_metric.py:233-234
+            const float idcg = wave_incl_sum(in ? gi / disc : 0.0f, lane) + c_idcg;
+            const float rel = in ? fminf(fmaxf(ys, 0.0f), 1.0f) : 0.0f;                // binary relevance (:106)
+            const float cumrel = wave_incl_sum(rel, lane) + c_rel;
+            const float pr = cumrel / ((float)r + 1.0f);                                // rank-wise precision (:111)
+            const float cumprec = wave_incl_sum(pr * rel, lane) + c_prec;               // (:112)
+            const float cumideal = wave_incl_sum(yi, lane) + c_ideal;                   // GRADED ideal labels (:114)
+            const float ssat = gs / pow_max, isat = gi / pow_max;                       // (:133)
+            // cascade: product of (1 - sat) over EARLIER ranks (:135-143) = exclusive prefix product
+            const float s_incl = wave_incl_prod(in ? 1.0f - ssat : 1.0f, lane), i_incl = wave_incl_prod(in ? 1.0f - isat : 1.0f, lane);
+            float s_excl = __shfl_up(s_incl, 1, 64), i_excl = __shfl_up(i_incl, 1, 64);
+            if (lane == 0) { s_excl = 1.0f; i_excl = 1.0f; }
+            const float rr = 1.0f / ((float)r + 1.0f);
+            const float serr = wave_incl_sum(in ? rr * ssat * (s_excl * c_sun) : 0.0f, lane) + c_serr;
+            const float ierr = wave_incl_sum(in ? rr * isat * (i_excl * c_iun) : 0.0f, lane) + c_ierr;
+            if (in) {
+                int slot = 0;
+                for (int c = 0; c < ck.nk; ++c) {
+                    const bool use = ck.k[c] >= 1 && ck.k[c] <= n;
+                    if (use && ck.k[c] == r + 1) {
+                        if (r_ndcg) r_ndcg[slot] = sdcg / idcg;
+                        if (r_nerr) r_nerr[slot] = serr / ierr;
+                        if (r_ap) r_ap[slot] = cumprec / cumideal;
+                        if (r_p) r_p[slot] = pr;
+                    }
+                    slot += use ? 1 : 0;
+                }
+            }
+            c_sdcg = __shfl(sdcg, 63, 64); c_idcg = __shfl(idcg, 63, 64); c_rel = __shfl(cumrel, 63, 64);
+            c_prec = __shfl(cumprec, 63, 64); c_ideal = __shfl(cumideal, 63, 64);
+            c_serr = __shfl(serr, 63, 64); c_ierr = __shfl(ierr, 63, 64);
+            c_sun *= __shfl(s_incl, 63, 64); c_iun *= __shfl(i_incl, 63, 64);
+        }
+    }
+}
+
+}  // namespace ptr
+
+extern "C" int ptr_sort_desc(const float *preds, const int32_t *lens, int B, int L, float *vals, int64_t *idx, void *stream) {
+    using namespace ptr;
+    const char *who = "ptr_sort_desc";
+    if (int rc = check_batch(preds, vals, B, L, who)) return rc;
+    if (B > 0 && !idx) { set_error("%s: NULL output pointer", who); return PTR_ERR_INVALID_ARG; }
+    if (B == 0) return 0;
+    const int Lp = round_up(L, 4);
+    return dispatch_tiling(L, [&]<int G, int DPT>() -> int {
+        constexpr int QPB = kBlock / G;
+        auto kern = sort_desc_kernel<G, DPT>;
+        const size_t lds = (size_t)QPB * 3 * Lp * sizeof(float);
+        if (int e = allow_lds(kern, lds)) return e;
+        hipLaunchKernelGGL(kern, dim3((B + QPB - 1) / QPB), dim3(kBlock), lds, as_stream(stream), preds, lens, B, L, Lp, vals, idx);
+        return check_hip(hipGetLastError(), who);
+    });
+}
+
+extern "C" int ptr_metrics_at_ks(const float *preds, const float *labels, const int32_t *lens, int B, int L, const int32_t *ks,
+                                 int nk, int presort, float max_label, float *max_label_ws, float *ndcg, float *nerr, float *ap,
+                                 float *prec, void *stream) {
+    using namespace ptr;
+    const char *who = "ptr_metrics_at_ks";
+    if (int rc = check_batch(preds, labels, B, L, who)) return rc;
+    if (nk < 0 || (nk > 0 && !ks)) { set_error("%s: bad cut-off list", who); return PTR_ERR_INVALID_ARG; }
+    if (nk > PTR_MAX_CUTOFFS) { set_error("%s: %d cut-offs exceed PTR_MAX_CUTOFFS=%d", who, nk, PTR_MAX_CUTOFFS); return PTR_ERR_UNSUPPORTED; }
+    if (nerr && max_label < 0.0f && !max_label_ws) {
+        set_error("%s: nERR with max_label < 0 needs the max_label_ws device scalar", who);
+        return PTR_ERR_INVALID_ARG;
+    }
+    if (B == 0 || nk == 0) return 0;
+    Cutoffs ck;
+    ck.nk = nk;
+    for (int c = 0; c < PTR_MAX_CUTOFFS; ++c) ck.k[c] = c < nk ? ks[c] : 0;
+    hipStream_t st = as_stream(stream);
+    const float *ml_dev = nullptr;
+    if (nerr && max_label < 0.0f) {
+        hipLaunchKernelGGL(batch_max_kernel, dim3(1), dim3(kBlock), 0, st, labels, lens, B, L, max_label_ws);
+        if (int rc = check_hip(hipGetLastError(), who)) return rc;
+        ml_dev = max_label_ws;
+    }
+    const int Lp = round_up(L, 4);
+    return dispatch_tiling(L, [&]<int G, int DPT>() -> int {
+        constexpr int QPB = kBlock / G;
+        auto kern = metrics_kernel<G, DPT>;
+        const size_t lds = (size_t)QPB * 3 * Lp * sizeof(float);
+        if (int e = allow_lds(kern, lds)) return e;
+        hipLaunchKernelGGL(kern, dim3((B + QPB - 1) / QPB), dim3(kBlock), lds, st, preds, labels, lens, B, L, Lp, ck, presort, max_label,
+                           ml_dev, ndcg, nerr, ap, prec);
+        return check_hip(hipGetLastError(), who);
+    });
+}

@@ -1,0 +1,215 @@
+// Fused pairwise-BCE kernels: LambdarRank (delta-NDCG weighted, predicted order) and RankNet (unweighted, input order).
+//
+// One kernel per batch does, per query and entirely out of LDS/registers:
+//   load scores+labels (coalesced) -> rank by score (counting sort, (score desc, index asc)) -> IDCG ->
+//   normalised gains G, discounts D -> all L(L-1)/2 pairs -> per-document gradient -> scatter back through the sort
+//   permutation -> coalesced store of grad[B,L] + one loss slot per query.
+// HBM traffic is the algorithmic minimum: 4L (scores) + 4L (labels) + 4L (grad) + 4 (loss) bytes per query.
+//
+// Pair schedule ("circulant"): with n documents at rank positions 0..n-1, step d = 1..floor((n-1)/2) visits the pair
+// (a, (a+d) mod n) for every a — each unordered pair exactly once (for even n the step d = n/2 is visited by
+// a < n/2 only).  Lane a keeps its own gradient in a register; the partner's share goes to LDS with a no-return
+// ds_add_f32 into a per-WAVE accumulator row (distinct lanes hit distinct addresses within one instruction, and one
+// wave's LDS ops execute in program order), so the result is run-to-run bit-stable.
+//
+// Arithmetic follows what the reference executes in ATen (SURVEY.md §7 i-ii):
+//   p = sigmoid(sigma*(s_i - s_j)) rounded to fp32; BCE with the -100 log clamp; backward w*(p-t)/max(p(1-p),1e-12)
+//   times sigmoid' = p(1-p) (=> gradient exactly 0 once p rounds to 1.0f).
+// Reference: ptranking/ltr_adhoc/listwise/lambdarank.py:39-56, ptranking/ltr_adhoc/pairwise/ranknet.py:32-36,
+//            ptranking/ltr_adhoc/util/lambda_utils.py:5-23, ptranking/metric/metric_utils.py:19-45.
+#include "ptr_device.h"
+
+namespace ptr {
+
+// LDS carve per group (floats): pk float4[Lp] | keys float[Lp] | gacc float[NW][Lp] | red float[4]
+__host__ __device__ constexpr size_t pairwise_group_floats(int Lp, int NW) { return (size_t)Lp * (4 + 1 + NW) + 4; }
+
+template <int G, int DPT, bool WEIGHTED>
+__global__ void __launch_bounds__(kBlock)
+pairwise_bce_kernel(const float *__restrict__ preds, const float *__restrict__ labels, const int32_t *__restrict__ lens,
+                    int B, int L, int Lp, float sigma, float *__restrict__ loss_q, float *__restrict__ grad) {
+    constexpr int QPB = kBlock / G, NW = G / kWave;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, grp = tid / G, t = tid % G, wv = t >> 6;
+    const int q = blockIdx.x * QPB + grp;
+    const bool valid = q < B;
+    const int n = valid ? query_len(lens, q, L) : 0;
+
+    float *base = smem + (size_t)grp * pairwise_group_floats(Lp, NW);
+    float4 *pk = reinterpret_cast<float4 *>(base);          // {score, gain-or-label, discount, -} by rank position
+    float *keys = base + 4 * (size_t)Lp;                     // raw scores for the counting sort; later: sorted grads
+    float *gacc = keys + Lp;                                 // [NW][Lp] partner-gradient accumulators (one row per wave)
+    float *red = gacc + (size_t)NW * Lp;
+
+    // ---- phase A: coalesced load of the query tile
+    float si[DPT], li[DPT];
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int i = t + m * G;
+        const bool in = i < n;
+        si[m] = in ? preds[(size_t)q * L + i] : -INFINITY;
+        li[m] = in ? labels[(size_t)q * L + i] : 0.0f;
+        if (i < Lp) {
+            keys[i] = si[m];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) gacc[(size_t)w * Lp + i] = 0.0f;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: rank positions, IDCG, per-position tile
+    int rk[DPT];
+    if constexpr (WEIGHTED) {
+        count_ranks<G, DPT>(keys, n, t, si, rk);
+        float part = 0.0f;
+#pragma unroll
+        for (int m = 0; m < DPT; ++m) {
+            const int i = t + m * G;
+            // labels arrive in ideal order (lambdarank.py:36), so DCG of the input order IS the IDCG (metric_utils.py:27)
+            if (i < n) part += gain_of(li[m]) / log2f((float)i + 2.0f);
+        }
+        const float idcg = group_sum<G>(part, red, t);
+#pragma unroll
+        for (int m = 0; m < DPT; ++m) {
+            const int i = t + m * G;
+            if (i < n) {
+                float *dst = reinterpret_cast<float *>(pk + rk[m]);
+                dst[0] = si[m];
+                dst[1] = gain_of(li[m]) / idcg;                                       // metric_utils.py:35
+                reinterpret_cast<float *>(pk + i)[2] = 1.0f / log2f((float)i + 2.0f);  // metric_utils.py:39
+            }
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < DPT; ++m) {
+            const int i = t + m * G;
+            rk[m] = i;
+            if (i < n) pk[i] = make_float4(si[m], li[m], 0.0f, 0.0f);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase C: all pairs
+    float4 me[DPT];
+    float ga[DPT];
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int a = t + m * G;
+        me[m] = a < n ? pk[a] : make_float4(0.f, 0.f, 0.f, 0.f);
+        ga[m] = 0.0f;
+    }
+    float lacc = 0.0f;
+    float *gw = gacc + (size_t)wv * Lp;
+
+    auto pair = [&](int m, int a, int d) {
+        int b = a + d;
+        if (b >= n) b -= n;
+        const bool fwd = b > a;                       // lo = a, hi = b (no wrap) — else lo = b, hi = a
+        const float4 o = pk[b];
+        const float ds = fwd ? me[m].x - o.x : o.x - me[m].x;   // s_lo - s_hi
+        const float dy = fwd ? me[m].y - o.y : o.y - me[m].y;   // gain (or label) of lo minus hi
+        float lam;
+        if constexpr (WEIGHTED) {
+            const float w = fabsf(dy) * fabsf(me[m].z - o.z);   // |G_i - G_j| * |D_i - D_j|, metric_utils.py:43
+            const float x = sigma * ds;                         // >= 0 in predicted order
+            const float e = __expf(-x);
+            const float dd = 1.0f + e;
+            float p = __builtin_amdgcn_rcpf(dd);
+            p = fmaf(p, fmaf(-dd, p, 1.0f), p);                 // one Newton step: correctly-rounded-class 1/(1+e)
+            const float qv = 1.0f - p;
+            const bool t1 = dy > 0.0f;                          // target 1 (lo has the higher grade) or 0; ties: w == 0
+            const float lg = fmaxf(fast_ln(t1 ? p : qv), -100.0f);  // argument is 0 or a normal float <= 1
+            lacc = fmaf(-w, lg, lacc);
+            const float pm = t1 ? -qv : (qv == 0.0f ? 0.0f : p);   // (p - t), zero once p(1-p) underflows
+            lam = (sigma * w) * pm;
+        } else {
+            const float S = fminf(fmaxf(dy, -1.0f), 1.0f);      // lambda_utils.py:20
+            const float tt = 0.5f * (1.0f + S);
+            const float x = sigma * ds;
+            const float p = 1.0f / (1.0f + expf(-x));           // IEEE division: p may legitimately hit 0 / 1
+            const float qv = 1.0f - p;
+            const float l1 = fmaxf(logf(p), -100.0f), l0 = fmaxf(logf(qv), -100.0f);
+            lacc += (tt - 1.0f) * l0 - tt * l1;
+            const float den = qv * p;
+            lam = sigma * (((p - tt) / fmaxf(den, 1e-12f)) * den);
+        }
+        const float sl = fwd ? lam : -lam;
+        ga[m] += sl;
+        atomicAdd(&gw[b], -sl);                                 // ds_add_f32, per-wave row => deterministic
+    };
+
+    const int half = (n - 1) >> 1;
+    for (int d = 1; d <= half; ++d) {
+#pragma unroll
+        for (int m = 0; m < DPT; ++m) {
+            const int a = t + m * G;
+            if (a < n) pair(m, a, d);
+        }
+    }
+    if (n > 0 && (n & 1) == 0) {
+        const int d = n >> 1;
+#pragma unroll
+        for (int m = 0; m < DPT; ++m) {
+            const int a = t + m * G;
+            if (a < d) pair(m, a, d);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase D: combine, un-sort, store
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int a = t + m * G;
+        if (a < n) {
+            float tot = ga[m];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tot += gacc[(size_t)w * Lp + a];
+            keys[a] = tot;
+        }
+    }
+    __syncthreads();
+    const float loss = group_sum<G>(lacc, red, t);
+    if (valid) {
+#pragma unroll
+        for (int m = 0; m < DPT; ++m) {
+            const int i = t + m * G;
+            if (i < L) grad[(size_t)q * L + i] = i < n ? keys[rk[m]] : 0.0f;
+        }
+        if (t == 0) loss_q[q] = loss;
+    }
+}
+
+template <bool WEIGHTED>
+static int launch_pairwise(const float *preds, const float *labels, const int32_t *lens, int B, int L, float sigma,
+                           float *loss_out, float *loss_q, float *grad, void *stream, const char *who) {
+    if (int rc = check_batch(preds, labels, B, L, who)) return rc;
+    if (!loss_q || !grad) { set_error("%s: NULL output pointer", who); return PTR_ERR_INVALID_ARG; }
+    if (WEIGHTED && !(sigma >= 0.0f)) { set_error("%s: sigma must be >= 0 (got %g)", who, (double)sigma); return PTR_ERR_INVALID_ARG; }
+    hipStream_t st = as_stream(stream);
+    if (B > 0) {
+        const int Lp = round_up(L, 4);
+        int rc = dispatch_tiling(L, [&]<int G, int DPT>() -> int {
+            constexpr int QPB = kBlock / G, NW = G / kWave;
+            auto kern = pairwise_bce_kernel<G, DPT, WEIGHTED>;
+            const size_t lds = QPB * pairwise_group_floats(Lp, NW) * sizeof(float);
+            if (int e = allow_lds(kern, lds)) return e;
+            hipLaunchKernelGGL(kern, dim3((B + QPB - 1) / QPB), dim3(kBlock), lds, st, preds, labels, lens, B, L, Lp, sigma,
+                               loss_q, grad);
+            return check_hip(hipGetLastError(), who);
+        });
+        if (rc) return rc;
+    }
+    return loss_out ? ptr_sum_f32(loss_q, B, 1.0f, loss_out, stream) : 0;
+}
+
+}  // namespace ptr
+
+extern "C" int ptr_ranknet_fwd_bwd(const float *preds, const float *labels, const int32_t *lens, int B, int L, float sigma,
+                                   float *loss_out, float *loss_q, float *grad, void *stream) {
+    return ptr::launch_pairwise<false>(preds, labels, lens, B, L, sigma, loss_out, loss_q, grad, stream, "ptr_ranknet_fwd_bwd");
+}
+
+extern "C" int ptr_lambdarank_fwd_bwd(const float *preds, const float *labels, const int32_t *lens, int B, int L, float sigma,
+                                      float *loss_out, float *loss_q, float *grad, void *stream) {
+    return ptr::launch_pairwise<true>(preds, labels, lens, B, L, sigma, loss_out, loss_q, grad, stream, "ptr_lambdarank_fwd_bwd");
+}

@@ -1,0 +1,209 @@
+// Device + host helpers shared by every kernel of the ltr_adhoc hot path (gfx950 / CDNA4 only).
+//
+// Execution model used throughout: one "group" of G threads (G = 64: one wavefront, or G = 256: four) owns one
+// query; a 256-thread workgroup therefore holds 256/G queries.  Per-query tiles (scores, gains, discounts, partial
+// gradients) live in LDS; each thread owns the documents i = t, t+G, t+2G, ... (DPT of them, compile-time bound).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ptranking_amd.h"
+
+namespace ptr {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;
+
+// ---------------------------------------------------------------- host side: errors + launch plumbing
+void set_error(const char *fmt, ...);
+int check_hip(hipError_t e, const char *what);
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// Shapes: L in (0, PTR_MAX_LIST_LEN]; B >= 0.  Returns 0 or an error code (message set).
+int check_batch(const void *preds, const void *second, int B, int L, const char *who);
+
+// (G, DPT) tiling by list length: G*DPT >= round_up(L, 4) always holds.
+struct Tiling { int G; int DPT; };
+inline Tiling pick_tiling(int L) {
+    if (L <= 64) return {64, 1};
+    if (L <= 128) return {64, 2};
+    if (L <= 256) return {256, 1};
+    if (L <= 512) return {256, 2};
+    if (L <= 1024) return {256, 4};
+    if (L <= 2048) return {256, 8};
+    return {256, 16};
+}
+
+// Calls f.template operator()<G, DPT>() for the tiling of L.
+template <class F> inline int dispatch_tiling(int L, F &&f) {
+    Tiling t = pick_tiling(L);
+    if (t.G == 64 && t.DPT == 1) return f.template operator()<64, 1>();
+    if (t.G == 64 && t.DPT == 2) return f.template operator()<64, 2>();
+    if (t.DPT == 1) return f.template operator()<256, 1>();
+    if (t.DPT == 2) return f.template operator()<256, 2>();
+    if (t.DPT == 4) return f.template operator()<256, 4>();
+    if (t.DPT == 8) return f.template operator()<256, 8>();
+    return f.template operator()<256, 16>();
+}
+
+// Raises the dynamic-LDS cap of `kernel` when a launch needs more than the 64 KiB default.
+template <class K> inline int allow_lds(K kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return 0;
+    return check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes), "hipFuncSetAttribute");
+}
+
+// ---------------------------------------------------------------- device side
+#if defined(__HIPCC__)
+
+__device__ __forceinline__ int query_len(const int32_t *lens, int q, int L) {
+    if (!lens) return L;
+    int n = lens[q];
+    return n < 0 ? 0 : (n > L ? L : n);
+}
+
+// Butterfly reductions over one wavefront: every lane ends with the bit-identical result.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+// Sum over the G threads of one group, fixed order (deterministic).  For G == 256 the group IS the workgroup, so the
+// barriers inside are workgroup barriers: every thread of the block must call it.  `red` = 4 floats of LDS.
+template <int G> __device__ __forceinline__ float group_sum(float v, float *red, int t) {
+    v = wave_sum(v);
+    if constexpr (G == kWave) {
+        return v;
+    } else {
+        __syncthreads();
+        if ((t & 63) == 0) red[t >> 6] = v;
+        __syncthreads();
+        float r = red[0];
+#pragma unroll
+        for (int w = 1; w < G / kWave; ++w) r += red[w];
+        return r;
+    }
+}
+template <int G> __device__ __forceinline__ float group_max(float v, float *red, int t) {
+    v = wave_max(v);
+    if constexpr (G == kWave) {
+        return v;
+    } else {
+        __syncthreads();
+        if ((t & 63) == 0) red[t >> 6] = v;
+        __syncthreads();
+        float r = red[0];
+#pragma unroll
+        for (int w = 1; w < G / kWave; ++w) r = fmaxf(r, red[w]);
+        return r;
+    }
+}
+
+// Inclusive prefix scans over one wavefront (lane order).
+__device__ __forceinline__ float wave_incl_sum(float v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        float o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_incl_prod(float v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        float o = __shfl_up(v, d, 64);
+        if (lane >= d) v *= o;
+    }
+    return v;
+}
+// Inclusive SUFFIX sum over one wavefront (lane i gets sum of lanes i..63).
+__device__ __forceinline__ float wave_incl_suffix_sum(float v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        float o = __shfl_down(v, d, 64);
+        if (lane + d < 64) v += o;
+    }
+    return v;
+}
+
+// ln(x) = log2(x)*ln2 on the transcendental pipe (v_log_f32); for x == 0 or normal x only (no denormal scaling).
+__device__ __forceinline__ float fast_ln(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+
+// 2^l - 1 (ptranking/metric/adhoc/adhoc_metric.py:208-209); exact for the integer grades 0..4 stored as floats.
+__device__ __forceinline__ float gain_of(float label) { return exp2f(label) - 1.0f; }
+
+// Descending rank of each owned key among keys[0..n): rank = #{j : k_j > k_i  or (k_j == k_i and j < i)}, i.e. the
+// position torch.sort(descending=True) gives on tie-free input, with ties broken by original index.
+// keys[] is in LDS, padded with -inf up to a multiple of 4 (float4 broadcast reads).  own[m] / index t + m*G.
+template <int G, int DPT>
+__device__ __forceinline__ void count_ranks(const float *keys, int n, int t, const float (&own)[DPT], int (&rk)[DPT]) {
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) rk[m] = 0;
+    const float4 *k4 = reinterpret_cast<const float4 *>(keys);
+    const int n4 = (n + 3) >> 2;
+    for (int j4 = 0; j4 < n4; ++j4) {
+        const float4 v = k4[j4];
+        const int j = j4 << 2;
+#pragma unroll
+        for (int m = 0; m < DPT; ++m) {
+            const int i = t + m * G;
+            const float s = own[m];
+            rk[m] += (v.x > s || (v.x == s && j + 0 < i)) ? 1 : 0;
+            rk[m] += (v.y > s || (v.y == s && j + 1 < i)) ? 1 : 0;
+            rk[m] += (v.z > s || (v.z == s && j + 2 < i)) ? 1 : 0;
+            rk[m] += (v.w > s || (v.w == s && j + 3 < i)) ? 1 : 0;
+        }
+    }
+}
+
+// Ideal-order staging shared by LambdaLoss / ApproxNDCG / the metric kernel.
+// Every thread arrives with its own documents i = t + m*G (score si, label li; padded docs: -inf / 0) and leaves with
+//   ipos[m]  = position of document i in the ideal (label-descending, index-ascending on ties) order,
+//   S_id/Y_id = scores / labels by ideal position in LDS (Lp entries; padded tail: -inf / 0).
+// presort != 0: the labels already are in ideal order (ipos = i) — the reference's `if presort:` branches
+// (ptranking/ltr_adhoc/listwise/lambdaloss.py:83-87, approxNDCG.py:94-98, ptranking/base/ranker.py:53-56).
+// Ends with a workgroup barrier; must be called by every thread of the block.
+template <int G, int DPT>
+__device__ __forceinline__ void stage_ideal_order(float *S_id, float *Y_id, int n, int Lp, int t, bool presort,
+                                                  const float (&si)[DPT], const float (&li)[DPT], int (&ipos)[DPT]) {
+    if (presort) {
+#pragma unroll
+        for (int m = 0; m < DPT; ++m) {
+            const int i = t + m * G;
+            ipos[m] = i;
+            if (i < Lp) { S_id[i] = si[m]; Y_id[i] = li[m]; }
+        }
+        __syncthreads();
+        return;
+    }
+    // keys = labels (padded with -inf) staged in S_id first, ranks counted, then both arrays rewritten in ideal order
+    float ky[DPT];
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int i = t + m * G;
+        ky[m] = i < n ? li[m] : -INFINITY;
+        if (i < Lp) S_id[i] = ky[m];
+    }
+    __syncthreads();
+    count_ranks<G, DPT>(S_id, n, t, ky, ipos);
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int i = t + m * G;
+        if (i < n) { S_id[ipos[m]] = si[m]; Y_id[ipos[m]] = li[m]; }
+        else if (i < Lp) { S_id[i] = -INFINITY; Y_id[i] = 0.0f; ipos[m] = i; }
+        else ipos[m] = i;
+    }
+    __syncthreads();
+}
+
+#endif  // __HIPCC__
+}  // namespace ptr

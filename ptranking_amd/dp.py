@@ -1,0 +1,100 @@
+"""Data-parallel training of the hot path: one process per GPU, queries sharded across ranks, replicated scorer.
+
+The reference is single-device (no torch.distributed call site anywhere); queries are independent
+units in every in-scope loss, and every loss is a SUM over queries (lambdarank.py:56, listnet.py:39, ...), so the
+only exchange step is ONE `all_reduce(SUM)` of the flattened parameter gradient per iteration —
+136 KB for the 136-feature scorer: latency-bound on xGMI, so everything is kept in a single bucket.
+
+`FlatGradBucket` makes every `p.grad` a view into one contiguous buffer, so the collective runs in place with no
+flatten/unflatten copies; `extra` trailing floats carry scalars that must be reduced with the gradients (ApproxNDCG's
+batch coupling: local sum(1/IDCG) and local sum(DCG)).
+Backend: 'nccl' (= RCCL on ROCm) on GPUs, 'gloo' in the CPU tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_distributed():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def world_size():
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def rank():
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun) and bind this process
+    to its GPU (LOCAL_RANK).  Returns (rank, world_size, local_rank).  No-op for single-process runs."""
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    rk = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    if ws > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend=backend, rank=rk, world_size=ws, **kw)
+    return rk, ws, local
+
+
+def shard_queries(num_queries, rank_=None, world_=None):
+    """Contiguous slice [lo, hi) of the query dimension owned by this rank (remainder spread over the first ranks)."""
+    r = rank() if rank_ is None else rank_
+    w = world_size() if world_ is None else world_
+    base, rem = divmod(num_queries, w)
+    lo = r * base + min(r, rem)
+    return lo, lo + base + (1 if r < rem else 0)
+
+
+class FlatGradBucket:
+    """All gradients of `params` as views of one flat fp32 buffer (+ `extra` trailing scalars)."""
+
+    def __init__(self, params, extra=0):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        self.numel = sum(p.numel() for p in self.params)
+        self.extra = extra
+        self.flat = torch.zeros(self.numel + extra, device=dev, dtype=dt)
+        self.attach()
+
+    def attach(self):
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            view = self.flat[off:off + n].view_as(p)
+            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
+                p.grad = view
+            off += n
+
+    @property
+    def extras(self):
+        return self.flat[self.numel:]
+
+    def zero(self):
+        self.flat.zero_()
+        self.attach()     # re-alias in case something set a grad to None
+
+    def all_reduce(self):
+        if is_distributed():
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+
+
+def broadcast_parameters(params, src=0):
+    """Make every replica start from rank `src`'s weights."""
+    if is_distributed():
+        for p in params:
+            dist.broadcast(p.data, src=src)

@@ -1,0 +1,296 @@
+"""Host-side mirror of the reference's plugin interface for the ltr_adhoc hot path (names, arguments, return types and
+error behaviour follow wildltr/ptranking; the arithmetic runs in the HIP kernels behind ptranking_amd.functional).
+
+  LABEL_TYPE              ptranking/data/data_utils.py:88-92
+  DeviceEvaluator         ptranking/base/ranker.py:28-263   (class Evaluator; metrics computed on the GPU instead of
+                          predict -> .cpu() -> torch.sort -> gather -> metric on the host)
+  DeviceTrainLoop         ptranking/base/ranker.py:565-603  (train / train_op; no per-batch .item() host sync)
+  PointScorerRanker       ptranking/base/ranker.py:479-561 + ptranking/base/point_ranker.py:9-74 +
+                          ptranking/base/adhoc_ranker.py:7-87 for sf_id == 'pointsf' (the scorer the benchmark configs use)
+
+When the reference package itself is importable, `ptranking_amd.install()` builds the same ranker classes on top of
+the reference's own `AdhocNeuralRanker` instead of PointScorerRanker, so everything outside the hot path (listsf
+scorer, BN variants, checkpoint naming...) is literally the reference's code.
+"""
+import os
+from enum import Enum, unique, auto
+
+import torch
+import torch.nn as nn
+import torch.optim as optim
+from torch.optim.lr_scheduler import StepLR
+
+from . import functional as F_
+
+
+@unique
+class LABEL_TYPE(Enum):
+    """The types of labels of supported datasets (ptranking/data/data_utils.py:88-92)."""
+    MultiLabel = auto()
+    Permutation = auto()
+
+
+def is_multilabel(label_type):
+    """True for our LABEL_TYPE.MultiLabel and for the reference's enum member of the same name."""
+    return getattr(label_type, "name", label_type) == "MultiLabel"
+
+
+# ------------------------------------------------------------------------------------------------ evaluation
+class DeviceEvaluator:
+    """In-built evaluation APIs with the signature of ptranking/base/ranker.py:28-263.  Results are CPU float32 tensors
+    of shape [1] (single cut-off) or [len(ks)], as in the reference; `device` is accepted and ignored (the reference
+    passes 'cpu' because it evaluates on the host)."""
+
+    def _to_dev(self, t):
+        return t.to(self.device, non_blocking=True) if t.device != torch.device(self.device) else t
+
+    def _run_eval(self, test_data, ks, presort, which, max_label=None, min_len=None, need_per_q=False):
+        self.eval_mode()
+        num_queries = 0
+        sums = None
+        per_q = {m: [] for m in which} if need_per_q else None
+        for batch_ids, batch_q_doc_vectors, batch_std_labels in test_data:
+            if min_len is not None and batch_std_labels.size(1) < min_len:
+                continue  # skip if the number of documents is smaller than k (ranker.py:41-42)
+            num_queries += len(batch_ids)
+            batch_preds = self.predict(self._to_dev(batch_q_doc_vectors))
+            out = F_.metrics_at_ks(batch_preds.detach(), self._to_dev(batch_std_labels).float(), ks, presort=presort,
+                                   max_label=max_label, which=which)
+            if sums is None:
+                sums = {m: torch.zeros(len(ks), device=batch_preds.device) for m in which}
+            for m in which:
+                sums[m] += out[m].sum(dim=0)
+                if need_per_q:
+                    per_q[m].append(out[m].cpu())
+        if sums is None:   # nothing evaluated: the reference divides 0 by 0 here
+            avg = {m: torch.zeros(len(ks)) / 0.0 for m in which}
+        else:
+            avg = {m: (sums[m] / num_queries).cpu() for m in which}
+        return avg, per_q
+
+    def ndcg_at_k(self, test_data=None, k=10, label_type=LABEL_TYPE.MultiLabel, presort=False, device='cpu'):
+        """ranker.py:31-65"""
+        if not is_multilabel(label_type):
+            raise NotImplementedError
+        return self._run_eval(test_data, [k], presort, ("ndcg",), min_len=k)[0]["ndcg"]
+
+    def ndcg_at_ks(self, test_data=None, ks=[1, 5, 10], label_type=LABEL_TYPE.MultiLabel, presort=False, device='cpu'):
+        """ranker.py:67-95"""
+        if not is_multilabel(label_type):
+            raise NotImplementedError
+        return self._run_eval(test_data, ks, presort, ("ndcg",))[0]["ndcg"]
+
+    def nerr_at_k(self, test_data=None, k=10, label_type=LABEL_TYPE.MultiLabel, max_label=None, presort=False, device='cpu'):
+        """ranker.py:97-128"""
+        if not is_multilabel(label_type):
+            raise NotImplementedError
+        return self._run_eval(test_data, [k], presort, ("nerr",), max_label=max_label, min_len=k)[0]["nerr"]
+
+    def ap_at_k(self, test_data=None, k=10, presort=False, device='cpu'):
+        """ranker.py:130-160"""
+        return self._run_eval(test_data, [k], presort, ("ap",), min_len=k)[0]["ap"]
+
+    def p_at_k(self, test_data=None, k=10, device='cpu'):
+        """ranker.py:162-187"""
+        return self._run_eval(test_data, [k], True, ("p",), min_len=k)[0]["p"]
+
+    def validation(self, vali_data=None, vali_metric=None, k=5, presort=False, max_label=None,
+                   label_type=LABEL_TYPE.MultiLabel, device='cpu'):
+        """ranker.py:189-200"""
+        if 'nDCG' == vali_metric:
+            return self.ndcg_at_k(test_data=vali_data, k=k, label_type=label_type, presort=presort, device=device)
+        elif 'nERR' == vali_metric:
+            return self.nerr_at_k(test_data=vali_data, k=k, label_type=label_type, max_label=max_label, presort=presort,
+                                  device=device)
+        elif 'AP' == vali_metric:
+            return self.ap_at_k(test_data=vali_data, k=k, presort=presort, device=device)
+        elif 'P' == vali_metric:
+            return self.p_at_k(test_data=vali_data, k=k, device=device)
+        else:
+            raise NotImplementedError
+
+    def adhoc_performance_at_ks(self, test_data=None, ks=[1, 5, 10], label_type=LABEL_TYPE.MultiLabel, max_label=None,
+                                presort=False, device='cpu', need_per_q=False):
+        """ranker.py:202-263 -> (avg nDCG, avg nERR, avg AP, avg P)[, per-query lists in the same order]"""
+        if not is_multilabel(label_type):
+            raise NotImplementedError
+        avg, per_q = self._run_eval(test_data, ks, presort, ("ndcg", "nerr", "ap", "p"), max_label=max_label,
+                                    need_per_q=need_per_q)
+        if need_per_q:
+            return (avg["ndcg"], avg["nerr"], avg["ap"], avg["p"], per_q["ndcg"], per_q["nerr"], per_q["ap"], per_q["p"])
+        return avg["ndcg"], avg["nerr"], avg["ap"], avg["p"]
+
+
+# ------------------------------------------------------------------------------------------------ training loop
+class DeviceTrainLoop:
+    """train / train_op with the reference's contract (ranker.py:565-603) minus the per-batch `.item()` host sync:
+    the running loss stays on the device; the caller still receives `(epoch_loss [1] tensor on self.device, stop)`."""
+
+    def train(self, train_data, epoch_k=None, **kwargs):
+        self.train_mode()
+        assert 'label_type' in kwargs and 'presort' in kwargs
+        label_type, presort = kwargs['label_type'], kwargs['presort']
+        num_queries = 0
+        epoch_loss = torch.zeros(1, device=self.device)
+        stop_training = False
+        for batch_ids, batch_q_doc_vectors, batch_std_labels in train_data:
+            num_queries += len(batch_ids)
+            batch_q_doc_vectors = batch_q_doc_vectors.to(self.device, non_blocking=True)
+            batch_std_labels = batch_std_labels.to(self.device, non_blocking=True)
+            batch_loss, stop_training = self.train_op(batch_q_doc_vectors, batch_std_labels, batch_ids=batch_ids,
+                                                      epoch_k=epoch_k, presort=presort, label_type=label_type)
+            if stop_training:
+                break
+            epoch_loss += batch_loss.detach().reshape(-1)[:1]
+        epoch_loss = epoch_loss / num_queries
+        return epoch_loss, stop_training
+
+    def train_op(self, batch_q_doc_vectors, batch_std_labels, **kwargs):
+        stop_training = False
+        batch_preds = self.forward(batch_q_doc_vectors)
+        if 'epoch_k' in kwargs and kwargs['epoch_k'] % self.stop_check_freq == 0:
+            stop_training = self.stop_training(batch_preds)
+        return self.custom_loss_function(batch_preds, batch_std_labels, **kwargs), stop_training
+
+
+# ------------------------------------------------------------------------------------------------ standalone base ranker
+_AF = {'R': nn.ReLU, 'LR': nn.LeakyReLU, 'RR': nn.RReLU, 'E': nn.ELU, 'SE': nn.SELU, 'CE': nn.CELU, 'GE': nn.GELU,
+       'S': nn.Sigmoid, 'T': nn.Tanh}
+
+
+def get_AF(af_str):
+    """String identifier -> activation module (ptranking/base/utils.py:101-143)."""
+    if af_str in _AF:
+        return _AF[af_str]()
+    raise NotImplementedError(af_str)
+
+
+class _BatchNormOverDocs(nn.Module):
+    """'BN': statistics over batch x docs (ptranking/base/utils.py:201-223)."""
+
+    def __init__(self, num_features, momentum=0.1, affine=True):
+        super().__init__()
+        self.bn = nn.BatchNorm1d(num_features, momentum=momentum, affine=affine, track_running_stats=False)
+
+    def forward(self, X):
+        return self.bn(X.permute(0, 2, 1)).permute(0, 2, 1) if X.dim() == 3 else self.bn(X)
+
+
+def build_pointsf(num_features=None, h_dim=100, out_dim=1, num_layers=3, AF='R', TL_AF='S', apply_tl_af=False, BN=True,
+                  bn_type=None, bn_affine=False, dropout=0.1):
+    """The stacked feed-forward scorer (ptranking/base/point_ranker.py:30-42 + base/utils.py:288-356):
+    (Dropout -> Linear[xavier_normal] -> [BN] -> AF) x num_layers -> Linear [-> [BN] -> TL_AF].  Module names match the
+    reference so state_dicts are interchangeable (dr_i / ff_{i+1} / bn_{i+1} / act_{i+1})."""
+    ff_dims = [num_features] + [h_dim] * num_layers + [out_dim]
+
+    def bn(dim):
+        if bn_type == 'BN':
+            return _BatchNormOverDocs(dim, momentum=0.1, affine=bn_affine)
+        raise NotImplementedError(f"bn_type={bn_type!r}: only 'BN' is mirrored stand-alone; use ptranking_amd.install() "
+                                  f"with the reference package for 'BN2'")
+
+    net = nn.Sequential()
+    n = len(ff_dims)
+    for i in range(1, n - 1):
+        net.add_module(f'dr_{i}', nn.Dropout(dropout))
+        lin = nn.Linear(ff_dims[i - 1], ff_dims[i])
+        nn.init.xavier_normal_(lin.weight)
+        net.add_module(f'ff_{i + 1}', lin)
+        if BN:
+            net.add_module(f'bn_{i + 1}', bn(ff_dims[i]))
+        net.add_module(f'act_{i + 1}', get_AF(AF))
+    last = nn.Linear(ff_dims[-2], ff_dims[-1])
+    nn.init.xavier_normal_(last.weight)
+    net.add_module(f'ff_{n}', last)
+    if apply_tl_af:
+        if BN:
+            net.add_module(f'bn_{n}', bn(ff_dims[-1]))
+        net.add_module(f'act_{n}', get_AF(TL_AF))
+    return net
+
+
+class PointScorerRanker:
+    """Stand-alone equivalent of NeuralRanker + PointNeuralRanker + AdhocNeuralRanker for sf_id == 'pointsf'."""
+
+    def __init__(self, id='AdhocNeuralRanker', sf_para_dict=None, weight_decay=1e-3, gpu=False, device=None):
+        self.id = id
+        self.gpu, self.device = gpu, device
+        self.sf_para_dict = sf_para_dict
+        self.sf_id = sf_para_dict['sf_id']
+        if self.sf_id != 'pointsf':
+            raise NotImplementedError("stand-alone ptranking_amd mirrors the 'pointsf' scorer; for 'listsf' use "
+                                      "ptranking_amd.install() on top of the reference package")
+        self.opt, self.lr = sf_para_dict['opt'], sf_para_dict['lr']
+        self.weight_decay = weight_decay
+        self.stop_check_freq = 10
+
+    # ---- ranker.py:499-545 / point_ranker.py:17-71
+    def init(self):
+        self.point_sf = self.config_point_neural_scoring_function()
+        self.config_optimizer()
+
+    def config_point_neural_scoring_function(self):
+        point_sf = self.ini_pointsf(**self.sf_para_dict[self.sf_para_dict['sf_id']])
+        if self.gpu:
+            point_sf = point_sf.to(self.device)
+        return point_sf
+
+    def ini_pointsf(self, **kw):
+        return build_pointsf(**kw)
+
+    def get_parameters(self):
+        return self.point_sf.parameters()
+
+    def config_optimizer(self):
+        if 'Adam' == self.opt:
+            self.optimizer = optim.Adam(self.get_parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        elif 'RMS' == self.opt:
+            self.optimizer = optim.RMSprop(self.get_parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        elif 'Adagrad' == self.opt:
+            self.optimizer = optim.Adagrad(self.get_parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        else:
+            raise NotImplementedError
+        self.scheduler = StepLR(self.optimizer, step_size=20, gamma=0.5)
+
+    def forward(self, batch_q_doc_vectors):
+        batch_size, num_docs, num_features = batch_q_doc_vectors.size()
+        _batch_preds = self.point_sf(batch_q_doc_vectors)
+        return _batch_preds.view(-1, num_docs)
+
+    def predict(self, batch_q_doc_vectors):
+        return self.forward(batch_q_doc_vectors)
+
+    def eval_mode(self):
+        self.point_sf.eval()
+
+    def train_mode(self):
+        self.point_sf.train(mode=True)
+
+    def save(self, dir, name):
+        if not os.path.exists(dir):
+            os.makedirs(dir)
+        torch.save(self.point_sf.state_dict(), dir + name)
+
+    def load(self, file_model, **kwargs):
+        device = kwargs['device']
+        self.point_sf.load_state_dict(torch.load(file_model, map_location=device))
+
+    def get_tl_af(self):
+        return self.sf_para_dict[self.sf_para_dict['sf_id']]['TL_AF']
+
+    def uniform_eval_setting(self, **kwargs):
+        pass
+
+    def stop_training(self, batch_preds):
+        """ranker.py:547-561"""
+        if torch.nonzero(batch_preds, as_tuple=False).size(0) <= 0:
+            print('All zero error.\n')
+            return True
+        if torch.isnan(batch_preds).any():
+            print('Including NaN error.')
+            return True
+        return False
+
+    def custom_loss_function(self, batch_preds, batch_std_labels, **kwargs):
+        raise NotImplementedError
+

@@ -1,0 +1,192 @@
+"""The six ltr_adhoc rankers of the hot path as drop-in replacements for the reference classes of the same name.
+
+Each class keeps the reference's constructor signature and `custom_loss_function` contract (consume `batch_preds`
+attached to the scorer graph + `batch_std_labels`, do zero_grad -> backward -> optimizer.step itself, return the scalar
+loss tensor; ptranking/base/ranker.py:605-613) but computes the loss and dLoss/dpreds with ONE fused HIP kernel.
+
+`make_ranker_classes(base)` builds the classes on top of any base that provides the reference's AdhocNeuralRanker
+interface: ptranking_amd.host.PointScorerRanker stand-alone, or the reference's own
+ptranking.base.adhoc_ranker.AdhocNeuralRanker when `ptranking_amd.install()` drops them into
+ptranking.ltr_adhoc.eval.ltr.
+"""
+import torch
+
+from . import dp
+from . import functional as F_
+from .host import DeviceEvaluator, DeviceTrainLoop, PointScorerRanker, is_multilabel
+
+RANKER_NAMES = ("RankNet", "LambdaRank", "LambdaLoss", "ApproxNDCG", "ListNet", "ListMLE")
+
+# default hyper-parameters = the reference's `default_para_dict()`s
+DEFAULT_PARAS = {
+    "RankNet": dict(model_id="RankNet", sigma=1.0),                                    # pairwise/ranknet.py:57
+    "LambdaRank": dict(model_id="LambdaRank", sigma=1.0),                              # listwise/lambdarank.py:78
+    "LambdaLoss": dict(model_id="LambdaLoss", k=5, sigma=1.0, mu=5.0, loss_type="NDCG_Loss2"),   # listwise/lambdaloss.py:155-158
+    "ApproxNDCG": dict(model_id="ApproxNDCG", alpha=10),                               # listwise/approxNDCG.py:131
+    "ListNet": dict(model_id="ListNet"),
+    "ListMLE": dict(model_id="ListMLE"),
+}
+
+
+class FusedStepMixin:
+    """zero_grad -> backward -> [one all_reduce(SUM) of the flat gradient under data parallelism] -> optimizer.step,
+    the tail every reference loss ends with (e.g. lambdarank.py:58-60)."""
+
+    data_parallel = True          # only takes effect when torch.distributed is initialised with world_size > 1
+    _grad_bucket = None
+
+    def _bucket(self, extra=0):
+        if self._grad_bucket is None or self._grad_bucket.extra != extra:
+            self._grad_bucket = dp.FlatGradBucket(list(self.get_parameters()), extra=extra)
+        return self._grad_bucket
+
+    def _fused_step(self, loss):
+        if self.data_parallel and dp.is_distributed():
+            bucket = self._bucket()
+            bucket.zero()
+            loss.backward()
+            bucket.all_reduce()
+        else:
+            self.optimizer.zero_grad()
+            loss.backward()
+        self.optimizer.step()
+        return loss
+
+
+class RankNetLoss(FusedStepMixin):
+    def custom_loss_function(self, batch_preds, batch_std_labels, **kwargs):
+        """ptranking/ltr_adhoc/pairwise/ranknet.py:25-42"""
+        return self._fused_step(F_.ranknet_loss(batch_preds, batch_std_labels, sigma=self.sigma))
+
+
+class LambdaRankLoss(FusedStepMixin):
+    def custom_loss_function(self, batch_preds, batch_std_labels, **kwargs):
+        """ptranking/ltr_adhoc/listwise/lambdarank.py:27-62"""
+        assert 'label_type' in kwargs and is_multilabel(kwargs['label_type'])
+        assert 'presort' in kwargs and kwargs['presort'] is True  # aiming for direct usage of ideal ranking
+        return self._fused_step(F_.lambdarank_loss(batch_preds, batch_std_labels, sigma=self.sigma))
+
+
+class LambdaLossLoss(FusedStepMixin):
+    def custom_loss_function(self, batch_preds, batch_std_labels, **kwargs):
+        """ptranking/ltr_adhoc/listwise/lambdaloss.py:73-138"""
+        assert is_multilabel(kwargs['label_type'])
+        presort = bool('presort' in kwargs and kwargs['presort'])
+        loss = F_.lambdaloss_loss(batch_preds, batch_std_labels, k=self.k, sigma=self.sigma, mu=getattr(self, 'mu', 5.0),
+                                  loss_type=self.loss_type, presort=presort)
+        return self._fused_step(loss)
+
+
+class ApproxNDCGLoss(FusedStepMixin):
+    couple_batch = True   # the reference's [B]/[B,1] broadcast (SURVEY.md §7 vi); False = per-query normalisation
+
+    def uniform_eval_setting(self, **kwargs):
+        """ptranking/ltr_adhoc/listwise/approxNDCG.py:78-81"""
+        eval_dict = kwargs['eval_dict']
+        if eval_dict["do_validation"] and not eval_dict['vali_metric'] == 'nDCG':
+            eval_dict['vali_metric'] = "nDCG"
+
+    def custom_loss_function(self, batch_preds, batch_std_labels, **kwargs):
+        """ptranking/ltr_adhoc/listwise/approxNDCG.py:83-109"""
+        assert is_multilabel(kwargs['label_type'])
+        presort = bool('presort' in kwargs and kwargs['presort'])
+        if not (self.data_parallel and dp.is_distributed() and self.couple_batch):
+            loss = F_.approxndcg_loss(batch_preds, batch_std_labels, alpha=self.alpha, presort=presort,
+                                      couple_batch=self.couple_batch)
+            return self._fused_step(loss)
+        # Data parallel + batch coupling: the global loss is -(sum_all DCG)(sum_all 1/IDCG).  Every rank back-propagates
+        # with scale 1, ships its local S = sum 1/IDCG and D = sum DCG in the gradient bucket, and rescales by the global S
+        # after the single all-reduce (gradients are linear in S) — SURVEY.md §8e.
+        loss1, parts = F_.approxndcg_loss(batch_preds, batch_std_labels, alpha=self.alpha, presort=presort,
+                                          couple_batch=True, grad_scale_override=1.0, return_parts=True)
+        bucket = self._bucket(extra=2)
+        bucket.zero()
+        loss1.backward()
+        bucket.extras[0] = parts["scale"][1]
+        bucket.extras[1] = -loss1.detach()            # = local sum of DCG (scale 1)
+        bucket.all_reduce()
+        S, D = bucket.extras[0].clone(), bucket.extras[1].clone()
+        bucket.flat[:bucket.numel].mul_(S)
+        self.optimizer.step()
+        return -(D * S)
+
+
+class ListNetLoss(FusedStepMixin):
+    def custom_loss_function(self, batch_preds, batch_std_labels, **kwargs):
+        """ptranking/ltr_adhoc/listwise/listnet.py:22-45"""
+        return self._fused_step(F_.listnet_loss(batch_preds, batch_std_labels))
+
+
+class ListMLELoss(FusedStepMixin):
+    tie_shuffle = "torch"     # "torch": the reference's randperm stream (parity); "device": counter-based HIP kernel
+    _tie_seed = 137           # ptranking/ltr_global.py:7
+    _tie_calls = 0
+
+    def _shuffle_ties(self, batch_std_labels):
+        if self.tie_shuffle == "device":
+            self._tie_calls += 1
+            return F_.shuffle_ties_order(batch_std_labels, seed=self._tie_seed * 0x9E3779B1 + self._tie_calls)
+        # ptranking/ltr_adhoc/util/sampling_utils.py:13-28, batched: one randperm per query from the global torch RNG
+        B, L = batch_std_labels.shape
+        dev = batch_std_labels.device
+        if B > 1:
+            rperms = torch.stack([torch.randperm(L, device=dev) for _ in range(B)], dim=0)
+        else:
+            rperms = torch.randperm(L, device=dev).view(1, -1)
+        shuffled = torch.gather(batch_std_labels, dim=1, index=rperms)
+        desc = torch.argsort(shuffled, descending=True)
+        return torch.gather(rperms, dim=1, index=desc)
+
+    def custom_loss_function(self, batch_preds, batch_std_labels, **kwargs):
+        """ptranking/ltr_adhoc/listwise/listmle.py:73-104"""
+        perm = self._shuffle_ties(batch_std_labels)   # shuffle per epoch rather than using the same order for a query
+        return self._fused_step(F_.listmle_loss(batch_preds, perm))
+
+
+def make_ranker_classes(base=PointScorerRanker):
+    """Return {name: class} built on `base` (anything with the reference's AdhocNeuralRanker interface)."""
+
+    class RankNet(RankNetLoss, DeviceTrainLoop, DeviceEvaluator, base):
+        def __init__(self, sf_para_dict=None, model_para_dict=None, gpu=False, device=None):
+            base.__init__(self, id='RankNet', sf_para_dict=sf_para_dict, gpu=gpu, device=device)
+            self.sigma = model_para_dict['sigma']
+
+    class LambdaRank(LambdaRankLoss, DeviceTrainLoop, DeviceEvaluator, base):
+        def __init__(self, sf_para_dict=None, model_para_dict=None, gpu=False, device=None):
+            base.__init__(self, id='LambdaRank', sf_para_dict=sf_para_dict, gpu=gpu, device=device)
+            self.sigma = model_para_dict['sigma']
+
+    class LambdaLoss(LambdaLossLoss, DeviceTrainLoop, DeviceEvaluator, base):
+        def __init__(self, sf_para_dict=None, model_para_dict=None, gpu=False, device=None):
+            base.__init__(self, id='LambdaLoss', sf_para_dict=sf_para_dict, gpu=gpu, device=device)
+            self.lambdaloss_dict = model_para_dict
+            self.k, self.sigma, self.loss_type = model_para_dict['k'], model_para_dict['sigma'], model_para_dict['loss_type']
+            if 'NDCG_Loss2++' == self.loss_type:
+                self.mu = model_para_dict['mu']
+            if self.loss_type not in F_.LAMBDALOSS_TYPES:
+                raise NotImplementedError(f"loss_type {self.loss_type!r}")
+
+    class ApproxNDCG(ApproxNDCGLoss, DeviceTrainLoop, DeviceEvaluator, base):
+        def __init__(self, sf_para_dict=None, model_para_dict=None, gpu=False, device=None):
+            base.__init__(self, id='ApproxNDCG', sf_para_dict=sf_para_dict, gpu=gpu, device=device)
+            self.alpha = model_para_dict['alpha']
+
+    class ListNet(ListNetLoss, DeviceTrainLoop, DeviceEvaluator, base):
+        def __init__(self, sf_para_dict=None, gpu=False, device=None):
+            base.__init__(self, id='ListNet', sf_para_dict=sf_para_dict, gpu=gpu, device=device)
+
+    class ListMLE(ListMLELoss, DeviceTrainLoop, DeviceEvaluator, base):
+        def __init__(self, sf_para_dict=None, model_para_dict=None, gpu=False, device=None):
+            base.__init__(self, id='ListMLE', sf_para_dict=sf_para_dict, gpu=gpu, device=device)
+
+    out = dict(RankNet=RankNet, LambdaRank=LambdaRank, LambdaLoss=LambdaLoss, ApproxNDCG=ApproxNDCG, ListNet=ListNet,
+               ListMLE=ListMLE)
+    for name, cls in out.items():
+        cls.__name__ = cls.__qualname__ = name
+        cls.__module__ = __name__
+    return out
+
+
+_standalone = make_ranker_classes(PointScorerRanker)
+RankNet, LambdaRank, LambdaLoss = _standalone["RankNet"], _standalone["LambdaRank"], _standalone["LambdaLoss"]
+ApproxNDCG, ListNet, ListMLE = _standalone["ApproxNDCG"], _standalone["ListNet"], _standalone["ListMLE"]

@@ -1,0 +1,332 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden fixtures produced by the reference, against
+the oracle on seeded inputs, and through size-independent properties at BASELINE.json's full list lengths.
+
+Tolerance (north_star: "losses/grads match the reference CPU path within 1e-5 fp32"): |got - ref| <= 1e-5 * max(1,
+max|ref|) — see tests/golden_util.py.  Sort indices: bit-exact on tie-free inputs.
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def F():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from ptranking_amd import functional
+    return functional
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t if dtype is None else t.to(dtype)
+
+
+def loss_and_grad(fn, preds_np, *args, **kw):
+    p = dev(preds_np).requires_grad_(True)
+    loss = fn(p, *args, **kw)
+    loss.backward()
+    return loss.detach().cpu().numpy(), p.grad.detach().cpu().numpy()
+
+
+def _presort(c):
+    return bool(int(c["presort"])) if "presort" in c else True
+
+
+# ------------------------------------------------------------------------------------------ golden fixtures (reference outputs)
+@pytest.mark.parametrize("name", G.case_ids("ranknet"))
+def test_golden_ranknet(F, name):
+    c = G.losses()["ranknet"][name]
+    loss, grad = loss_and_grad(F.ranknet_loss, c["preds"], dev(c["labels"]), sigma=float(c["sigma"]))
+    G.assert_close(loss, c["loss"], "loss")
+    G.assert_close(grad, c["grad"], "grad")
+
+
+@pytest.mark.parametrize("name", G.case_ids("lambdarank"))
+def test_golden_lambdarank(F, name):
+    c = G.losses()["lambdarank"][name]
+    loss, grad = loss_and_grad(F.lambdarank_loss, c["preds"], dev(c["labels"]), sigma=float(c["sigma"]))
+    G.assert_close(loss, c["loss"], "loss")
+    G.assert_close(grad, c["grad"], "grad")
+    vals, idx = F.sort_desc(dev(c["preds"]))
+    assert np.array_equal(idx.cpu().numpy(), c["sort_idx"]), "sort indices must be bit-exact"
+
+
+@pytest.mark.parametrize("name", G.case_ids("lambdaloss"))
+def test_golden_lambdaloss(F, name):
+    c = G.losses()["lambdaloss"][name]
+    lt = {1: "NDCG_Loss2", 2: "NDCG_Loss2++"}[int(c["loss_type"])]
+    loss, grad = loss_and_grad(F.lambdaloss_loss, c["preds"], dev(c["labels"]), k=int(c["k"]), sigma=float(c["sigma"]),
+                               mu=float(c["mu"]), loss_type=lt, presort=_presort(c))
+    G.assert_close(loss, c["loss"], "loss")
+    G.assert_close(grad, c["grad"], "grad")
+
+
+@pytest.mark.parametrize("name", G.case_ids("approxndcg"))
+def test_golden_approxndcg(F, name):
+    c = G.losses()["approxndcg"][name]
+    loss, grad = loss_and_grad(F.approxndcg_loss, c["preds"], dev(c["labels"]), alpha=float(c["alpha"]), presort=_presort(c))
+    G.assert_close(loss, c["loss"], "loss")
+    G.assert_close(grad, c["grad"], "grad")
+
+
+@pytest.mark.parametrize("name", G.case_ids("listnet"))
+def test_golden_listnet(F, name):
+    c = G.losses()["listnet"][name]
+    loss, grad = loss_and_grad(F.listnet_loss, c["preds"], dev(c["labels"]))
+    G.assert_close(loss, c["loss"], "loss")
+    G.assert_close(grad, c["grad"], "grad")
+
+
+@pytest.mark.parametrize("name", G.case_ids("listmle"))
+def test_golden_listmle(F, name):
+    c = G.losses()["listmle"][name]
+    loss, grad = loss_and_grad(F.listmle_loss, c["preds"], dev(c["perm"]))
+    G.assert_close(loss, c["loss"], "loss")
+    G.assert_close(grad, c["grad"], "grad")
+
+
+@pytest.mark.parametrize("name", G.case_ids("rand", "metrics"))
+def test_golden_metrics(F, name):
+    c = G.metrics()["rand"][name]
+    out = F.metrics_at_ks(dev(c["preds"]), dev(c["labels"]), [int(k) for k in c["ks"]], presort=bool(int(c["presort"])))
+    for m in ("ndcg", "nerr", "ap", "p"):
+        G.assert_close(out[m].cpu().numpy(), c[m], m)
+    vals, idx = F.sort_desc(dev(c["preds"]))
+    assert np.array_equal(idx.cpu().numpy(), c["sort_idx"])
+    assert np.array_equal(vals.cpu().numpy(), c["sorted_vals"])
+    # single cut-off forms (torch_*_at_k) equal the matching column
+    k1 = int(c["k1"])
+    one = F.metrics_at_ks(dev(c["preds"]), dev(c["labels"]), [k1], presort=bool(int(c["presort"])),
+                          max_label=float(c["max_label"]))
+    for m, key in (("ndcg", "ndcg_k"), ("nerr", "nerr_k"), ("ap", "ap_k"), ("p", "p_k")):
+        G.assert_close(one[m].cpu().numpy(), c[key], key)
+
+
+def test_golden_known_answer_vectors(F):
+    """The reference's own testing/metric/testing_metric.py vectors, pushed through the device prologue."""
+    checked = 0
+    for name in G.case_ids("kat", "metrics"):
+        c = G.metrics()["kat"][name]
+        sys_sorted = c["sys_sorted"]
+        if sorted(sys_sorted[0].tolist(), reverse=True) != c["ideal_sorted"][0].tolist():
+            continue
+        L = sys_sorted.shape[1]
+        preds = -np.arange(L, dtype=np.float32)[None]
+        out = F.metrics_at_ks(dev(preds), dev(sys_sorted), [int(k) for k in c["ks"]], presort=False)
+        G.assert_close(out[str(c["kind"])].cpu().numpy(), c["expected"], name)
+        assert np.allclose(out[str(c["kind"])].cpu().numpy()[0], c["commented"], atol=5e-5)
+        checked += 1
+    assert checked >= 3
+
+
+# ------------------------------------------------------------------------------------------ oracle on seeded inputs (all tilings)
+def synth(seed, B, L, lens=False, presort=True):
+    rng = np.random.default_rng(seed)
+    preds = rng.standard_normal((B, L)).astype(np.float32)
+    labels = rng.choice(5, size=(B, L), p=[0.5147, 0.3250, 0.1339, 0.0183, 0.0081]).astype(np.float32)
+    labels[:, 0] = np.maximum(labels[:, 0], 1.0)
+    ln = None
+    if lens:
+        ln = rng.integers(1, L + 1, size=B).astype(np.int32)
+        ln[0] = L
+        for b in range(B):
+            labels[b, ln[b]:] = 0
+            if labels[b, :ln[b]].max() < 1:
+                labels[b, 0] = 1
+    if presort:
+        for b in range(B):
+            n = L if ln is None else ln[b]
+            labels[b, :n] = -np.sort(-labels[b, :n])
+    return preds, labels, ln
+
+
+SHAPES = [(37, 1), (16, 2), (9, 64), (33, 65), (16, 128), (7, 129), (12, 256), (5, 300), (6, 512), (3, 1000), (3, 1024),
+          (2, 1500), (2, 2048), (1, 4096)]
+
+
+@pytest.mark.parametrize("B,L", SHAPES)
+@pytest.mark.parametrize("use_lens", [False, True])
+def test_oracle_pairwise(F, B, L, use_lens):
+    from oracle import c_oracle as CO
+    preds, labels, ln = synth(1000 + L, B, L, lens=use_lens)
+    lens_t = None if ln is None else dev(ln)
+    for name, fn, orc in (("lambdarank", F.lambdarank_loss, CO.lambdarank), ("ranknet", F.ranknet_loss, CO.ranknet)):
+        loss, grad = loss_and_grad(fn, preds, dev(labels), sigma=1.0, lens=lens_t)
+        lq, g = orc(preds, labels, 1.0, lens=ln)
+        G.assert_close(loss, lq.astype(np.float64).sum(), f"{name} loss")
+        G.assert_close(grad, g, f"{name} grad")
+
+
+@pytest.mark.parametrize("B,L", [(5, 7), (16, 128), (9, 256), (4, 512), (2, 1030)])
+@pytest.mark.parametrize("use_lens", [False, True])
+def test_oracle_lambdaloss_approx(F, B, L, use_lens):
+    from oracle import c_oracle as CO
+    for presort in (True, False):
+        preds, labels, ln = synth(2000 + L, B, L, lens=use_lens, presort=presort)
+        lens_t = None if ln is None else dev(ln)
+        for lt, code in (("NDCG_Loss2", 1), ("NDCG_Loss2++", 2)):
+            for k in (5, L):
+                loss, grad = loss_and_grad(F.lambdaloss_loss, preds, dev(labels), k=k, sigma=1.0, mu=5.0, loss_type=lt,
+                                           presort=presort, lens=lens_t)
+                lq, g = CO.lambdaloss(preds, labels, k, 1.0, 5.0, code, presort, lens=ln)
+                G.assert_close(loss, lq.astype(np.float64).sum(), f"lambdaloss {lt} k={k}")
+                G.assert_close(grad, g, f"lambdaloss {lt} k={k} grad")
+        for couple in (True, False):
+            loss, grad = loss_and_grad(F.approxndcg_loss, preds, dev(labels), alpha=10.0, presort=presort,
+                                       couple_batch=couple, lens=lens_t)
+            ol, dcg, inv, g = CO.approxndcg(preds, labels, 10.0, presort, couple, lens=ln)
+            G.assert_close(loss, ol, f"approxndcg couple={couple}")
+            G.assert_close(grad, g, f"approxndcg couple={couple} grad")
+
+
+@pytest.mark.parametrize("B,L", [(5, 3), (40, 64), (33, 256), (8, 700), (3, 4096)])
+@pytest.mark.parametrize("use_lens", [False, True])
+def test_oracle_listwise(F, B, L, use_lens):
+    from oracle import c_oracle as CO
+    preds, labels, ln = synth(3000 + L, B, L, lens=use_lens)
+    lens_t = None if ln is None else dev(ln)
+    loss, grad = loss_and_grad(F.listnet_loss, preds, dev(labels), lens=lens_t)
+    lq, g = CO.listnet(preds, labels, lens=ln)
+    G.assert_close(loss, lq.astype(np.float64).sum(), "listnet loss")
+    G.assert_close(grad, g, "listnet grad")
+    # ListMLE with the DEVICE tie shuffle: check the permutation is a valid tie-respecting order, then parity
+    perm = F.shuffle_ties_order(dev(labels), seed=11, lens=lens_t)
+    pn = perm.cpu().numpy()
+    for b in range(B):
+        n = L if ln is None else ln[b]
+        assert sorted(pn[b, :n].tolist()) == list(range(n))
+        assert np.all(np.diff(labels[b, pn[b, :n]]) <= 0)
+    loss, grad = loss_and_grad(F.listmle_loss, preds, perm, lens=lens_t)
+    lq, g = CO.listmle(preds, pn, lens=ln)
+    G.assert_close(loss, lq.astype(np.float64).sum(), "listmle loss")
+    G.assert_close(grad, g, "listmle grad")
+
+
+def test_tie_shuffle_is_uniform_enough(F):
+    """Device RNG path (not the torch.randperm stream): every position inside a tie group is about equally likely."""
+    L, B = 8, 4096
+    labels = np.tile(np.array([[2, 1, 1, 1, 1, 0, 0, 0]], np.float32), (B, 1))
+    perm = F.shuffle_ties_order(dev(labels), seed=5).cpu().numpy()
+    assert np.all(perm[:, 0] == 0)
+    counts = np.stack([(perm[:, 1:5] == d).sum(axis=0) for d in range(1, 5)])   # doc d at slot s
+    assert np.all(np.abs(counts / B - 0.25) < 0.03)
+    perm2 = F.shuffle_ties_order(dev(labels), seed=6).cpu().numpy()
+    assert not np.array_equal(perm, perm2)
+
+
+@pytest.mark.parametrize("B,L", [(6, 5), (32, 128), (9, 333), (4, 1024), (2, 4096)])
+@pytest.mark.parametrize("use_lens", [False, True])
+def test_oracle_metrics_and_sort(F, B, L, use_lens):
+    from oracle import c_oracle as CO
+    ks = [1, 3, 5, 10, 20, 50]
+    for presort in (True, False):
+        preds, labels, ln = synth(4000 + L, B, L, lens=use_lens, presort=presort)
+        lens_t = None if ln is None else dev(ln)
+        out = F.metrics_at_ks(dev(preds), dev(labels), ks, presort=presort, lens=lens_t)
+        ref = CO.metrics_at_ks(preds, labels, ks, presort, lens=ln)
+        for m in ("ndcg", "nerr", "ap", "p"):
+            G.assert_close(out[m].cpu().numpy(), ref[m], m)
+    vals, idx = F.sort_desc(dev(preds), lens=lens_t)
+    rv, ri = CO.sort_desc(preds, lens=ln)
+    assert np.array_equal(idx.cpu().numpy(), ri)
+    assert np.array_equal(vals.cpu().numpy(), rv)
+    if not use_lens:   # bit-exact against torch.sort itself on tie-free input
+        tv, ti = torch.sort(torch.from_numpy(preds), dim=1, descending=True)
+        assert np.array_equal(idx.cpu().numpy(), ti.numpy())
+
+
+# ------------------------------------------------------------------------------------------ properties at BASELINE.json's full sizes
+@pytest.mark.parametrize("L", [128, 256, 512])
+def test_properties_full_size(F, L):
+    B = 1024
+    preds, labels, _ = synth(77, B, L)
+    p, y = dev(preds), dev(labels)
+    # (1) run-to-run bit stability (no cross-wave float atomics)
+    l1, g1 = loss_and_grad(F.lambdarank_loss, preds, y)
+    l2, g2 = loss_and_grad(F.lambdarank_loss, preds, y)
+    assert l1 == l2 and np.array_equal(g1, g2)
+    # (2) every in-scope loss is invariant to a per-query score shift => gradients sum to zero per query
+    for fn, kw in ((F.lambdarank_loss, {}), (F.ranknet_loss, {}), (F.approxndcg_loss, {}), (F.listnet_loss, {}),
+                   (F.lambdaloss_loss, dict(k=L))):
+        _, g = loss_and_grad(fn, preds, y, **kw)
+        scale = max(1.0, np.abs(g).max())
+        assert np.abs(g.sum(axis=1)).max() <= 2e-4 * scale, fn.__name__
+    # (3) queries are independent: a batch equals the concatenation of its halves (sum of losses, same grads)
+    la, ga = loss_and_grad(F.lambdarank_loss, preds[: B // 2], dev(labels[: B // 2]))
+    lb, gb = loss_and_grad(F.lambdarank_loss, preds[B // 2:], dev(labels[B // 2:]))
+    assert np.array_equal(np.concatenate([ga, gb]), g1)
+    assert abs((la + lb) - l1) <= 1e-5 * abs(l1)
+    # (4) the sort kernel returns a permutation, values non-increasing, idempotent on its own output
+    vals, idx = F.sort_desc(p)
+    v = vals.cpu().numpy()
+    assert np.all(np.diff(v, axis=1) <= 0)
+    assert np.array_equal(np.sort(idx.cpu().numpy(), axis=1), np.tile(np.arange(L), (B, 1)))
+    v2, i2 = F.sort_desc(vals)
+    assert torch.equal(v2, vals) and np.array_equal(i2.cpu().numpy(), np.tile(np.arange(L), (B, 1)))
+    # (5) a perfect ranker has nDCG = 1 at every cut-off; padding a batch does not change real rows
+    out = F.metrics_at_ks(dev(-np.tile(np.arange(L, dtype=np.float32), (B, 1))), y, [1, 5, 10, 50], presort=True)
+    assert torch.allclose(out["ndcg"], torch.ones_like(out["ndcg"]), atol=1e-6)
+
+
+def test_padded_batch_equals_per_length_batches(F):
+    """The reference only ever batches equal-length lists (data_utils.py:683-742): a padded batch must equal them."""
+    preds, labels, ln = synth(99, 24, 96, lens=True)
+    lens_t = dev(ln)
+    _, g = loss_and_grad(F.lambdarank_loss, preds, dev(labels), lens=lens_t)
+    lq_total = 0.0
+    for b in range(24):
+        n = int(ln[b])
+        lb, gb = loss_and_grad(F.lambdarank_loss, preds[b:b + 1, :n].copy(), dev(labels[b:b + 1, :n].copy()))
+        assert np.allclose(g[b, :n], gb[0], rtol=1e-6, atol=1e-7)
+        assert np.all(g[b, n:] == 0)
+        lq_total += float(lb)
+    l_all, _ = loss_and_grad(F.lambdarank_loss, preds, dev(labels), lens=lens_t)
+    assert abs(l_all - lq_total) <= 1e-5 * max(1.0, abs(lq_total))
+
+
+def test_edge_cases_do_not_hang(F):
+    # a query without any relevant document: LambdaRank / ApproxNDCG -> NaN like the reference, LambdaLoss -> 0
+    preds = np.random.default_rng(0).standard_normal((2, 16)).astype(np.float32)
+    labels = np.zeros((2, 16), np.float32)
+    labels[1, 0] = 1
+    l, g = loss_and_grad(F.lambdarank_loss, preds, dev(labels))
+    assert np.isnan(l) and np.all(np.isfinite(g[1]))
+    l, g = loss_and_grad(F.lambdaloss_loss, preds[:1], dev(labels[:1]), k=5)
+    assert l == 0 and np.all(g == 0)
+    # empty batch and zero-length queries
+    l, g = loss_and_grad(F.lambdarank_loss, np.zeros((0, 8), np.float32), dev(np.zeros((0, 8), np.float32)))
+    assert l == 0 and g.shape == (0, 8)
+    lens = dev(np.array([0, 16], np.int32))
+    l, g = loss_and_grad(F.listnet_loss, preds, dev(labels), lens=lens)
+    assert np.isfinite(l) and np.all(g[0] == 0)
+    # NaN scores must not hang or crash
+    bad = preds.copy()
+    bad[0, 3] = np.nan
+    loss_and_grad(F.lambdarank_loss, bad, dev(labels + 1))
+    torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------------ raw C ABI (no wrapper logic)
+def test_c_abi_direct_calls_and_errors():
+    import ctypes as C
+    from ptranking_amd import _lib
+    lib = _lib.load()
+    x = torch.arange(1000, dtype=torch.float32, device="cuda")
+    out = torch.zeros(1, device="cuda")
+    rc = lib.ptr_sum_f32(C.c_void_p(x.data_ptr()), 1000, C.c_float(0.5), C.c_void_p(out.data_ptr()),
+                         C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    assert out.item() == 0.5 * 999 * 1000 / 2
+    # errors: list too long -> PTR_ERR_UNSUPPORTED with a message; NULL pointer -> PTR_ERR_INVALID_ARG
+    rc = lib.ptr_lambdarank_fwd_bwd(C.c_void_p(x.data_ptr()), C.c_void_p(x.data_ptr()), None, 1, 5000, C.c_float(1.0), None,
+                                    C.c_void_p(out.data_ptr()), C.c_void_p(x.data_ptr()), None)
+    assert rc == 1002 and b"PTR_MAX_LIST_LEN" in lib.ptr_last_error()
+    rc = lib.ptr_lambdarank_fwd_bwd(None, None, None, 1, 8, C.c_float(1.0), None, None, None, None)
+    assert rc == 1001
+    with pytest.raises(RuntimeError, match="sigma"):
+        from ptranking_amd import functional
+        functional.lambdarank_loss(torch.zeros(1, 4, device="cuda"), torch.zeros(1, 4, device="cuda"), sigma=-1.0)
