@@ -18,6 +18,9 @@
  *   - F.binary_cross_entropy:      -(t*max(log(y),-100) + (1-t)*max(log(1-y),-100)) * weight
  *     backward:                    w*(y-t)/max((1-y)*y, 1e-12), then sigmoid' = (1-y)*y
  *   - sort order:                  (score descending, original index ascending)
+ *   - torch.sum:                   cascade / vectorised summation, far more accurate than a sequential fp32 loop, so
+ *                                  the per-query LOSS totals below are accumulated in double and rounded once; the
+ *                                  per-pair terms themselves stay fp32
  */
 #include <math.h>
 #include <stdint.h>
@@ -97,7 +100,7 @@ int orc_ranknet(const float *preds, const float *labels, const int32_t *lens, in
         float *g = grad + (size_t)q * L;
         int n = qlen(lens, q, L);
         memset(g, 0, sizeof(float) * (size_t)L);
-        float loss = 0.0f;
+        double loss = 0.0;
         for (int i = 0; i < n; ++i)
             for (int j = i + 1; j < n; ++j) {
                 float S = y[i] - y[j]; S = S > 1.0f ? 1.0f : (S < -1.0f ? -1.0f : S);
@@ -105,7 +108,7 @@ int orc_ranknet(const float *preds, const float *labels, const int32_t *lens, in
                 bce_pair(sigma * (s[i] - s[j]), t, 1.0f, &l, &dx);
                 loss += l; g[i] += sigma * dx; g[j] -= sigma * dx;
             }
-        loss_q[q] = loss;
+        loss_q[q] = (float)loss;
     }
     return ORC_OK;
 }
@@ -134,7 +137,7 @@ int orc_lambdarank(const float *preds, const float *labels, const int32_t *lens,
             D[r] = 1.0f / log2f((float)r + 2.0f);               /* metric_utils.py:39 */
             gs[r] = 0.0f;
         }
-        float loss = 0.0f;
+        double loss = 0.0;
         for (int i = 0; i < n; ++i)
             for (int j = i + 1; j < n; ++j) {
                 float li = y[ix[i]], lj = y[ix[j]];
@@ -146,7 +149,7 @@ int orc_lambdarank(const float *preds, const float *labels, const int32_t *lens,
                 loss += l; gs[i] += sigma * dx; gs[j] -= sigma * dx;
             }
         for (int r = 0; r < n; ++r) g[ix[r]] = gs[r];
-        loss_q[q] = loss;
+        loss_q[q] = (float)loss;
     }
     free(tmp); free(ix); free(buf);
     return ORC_OK;
@@ -182,7 +185,7 @@ int orc_lambdaloss(const float *preds, const float *labels, const int32_t *lens,
             gs[r] = 0.0f;
         }
         int kk = k < n ? k : n;
-        float loss = 0.0f;
+        double loss = 0.0;
         for (int i = 0; i < kk; ++i)
             for (int j = 0; j < kk; ++j) {
                 if (i == j) continue;
@@ -204,7 +207,7 @@ int orc_lambdaloss(const float *preds, const float *labels, const int32_t *lens,
                 }
             }
         for (int r = 0; r < n; ++r) g[il[ip[r]]] = gs[r];
-        loss_q[q] = loss;
+        loss_q[q] = (float)loss;
     }
     free(tmp); free(il); free(ip); free(buf);
     return ORC_OK;
@@ -243,7 +246,7 @@ int orc_approxndcg(const float *preds, const float *labels, const int32_t *lens,
         }
         S += inv_idcg_q[q];
     }
-    float sum_dcg = 0.0f, sum_ndcg = 0.0f;
+    double sum_dcg = 0.0, sum_ndcg = 0.0;
     for (int q = 0; q < B; ++q) {
         const float *s = preds + (size_t)q * L, *y = labels + (size_t)q * L;
         float *g = grad + (size_t)q * L;
@@ -253,11 +256,11 @@ int orc_approxndcg(const float *preds, const float *labels, const int32_t *lens,
         else argsort_desc(y, n, tmp, il);
         for (int r = 0; r < n; ++r) { tp[r] = s[il[r]]; ideal[r] = y[il[r]]; }
         float scale = couple_batch ? S : inv_idcg_q[q];
-        float dcg = 0.0f;
+        double dcg = 0.0;
         for (int i = 0; i < n; ++i) {
-            float pi = 0.0f;
-            for (int j = 0; j < n; ++j) pi += robust_sigmoid(tp[j] - tp[i], alpha);   /* approxNDCG.py:21-25 */
-            pi += 0.5f;
+            double pid = 0.0;
+            for (int j = 0; j < n; ++j) pid += robust_sigmoid(tp[j] - tp[i], alpha);   /* approxNDCG.py:21-25 */
+            float pi = (float)pid + 0.5f;
             float lg = log2f(pi + 1.0f);
             float gi = gain(ideal[i]);
             dcg += gi / lg;
@@ -274,10 +277,10 @@ int orc_approxndcg(const float *preds, const float *labels, const int32_t *lens,
                 gs[j] += c[i] * d; gs[i] -= c[i] * d;
             }
         for (int r = 0; r < n; ++r) g[il[r]] = gs[r];
-        dcg_q[q] = dcg;
-        sum_dcg += dcg; sum_ndcg += dcg * inv_idcg_q[q];
+        dcg_q[q] = (float)dcg;
+        sum_dcg += dcg_q[q]; sum_ndcg += dcg_q[q] * inv_idcg_q[q];
     }
-    *loss_total = couple_batch ? -(sum_dcg * S) : -sum_ndcg;
+    *loss_total = couple_batch ? -((float)sum_dcg * S) : -(float)sum_ndcg;
     free(tmp); free(il); free(buf);
     return ORC_OK;
 }
@@ -293,16 +296,17 @@ int orc_listnet(const float *preds, const float *labels, const int32_t *lens, in
         if (n == 0) { loss_q[q] = 0.0f; continue; }
         float ms = s[0], my = y[0];
         for (int i = 1; i < n; ++i) { if (s[i] > ms) ms = s[i]; if (y[i] > my) my = y[i]; }
-        float zs = 0.0f, zy = 0.0f;
-        for (int i = 0; i < n; ++i) { zs += expf(s[i] - ms); zy += expf(y[i] - my); }
-        float lzs = logf(zs), loss = 0.0f;
+        double zsd = 0.0, zyd = 0.0, loss = 0.0;
+        for (int i = 0; i < n; ++i) { zsd += expf(s[i] - ms); zyd += expf(y[i] - my); }
+        float zs = (float)zsd, zy = (float)zyd;
+        float lzs = logf(zs);
         for (int i = 0; i < n; ++i) {
             float py = expf(y[i] - my) / zy;
             float lsm = (s[i] - ms) - lzs;
             loss -= py * lsm;
             g[i] = expf(lsm) - py;
         }
-        loss_q[q] = loss;
+        loss_q[q] = (float)loss;
     }
     return ORC_OK;
 }
@@ -328,13 +332,13 @@ int orc_listmle(const float *preds, const int64_t *perm, const int32_t *lens, in
         }
         float acc = 0.0f;
         for (int i = n - 1; i >= 0; --i) { e[i] = expf(u[i] - m); acc += e[i]; T[i] = acc; }   /* flip-cumsum-flip */
-        float loss = 0.0f, invsum = 0.0f;
+        double loss = 0.0; float invsum = 0.0f;
         for (int i = 0; i < n; ++i) {
             loss += (logf(T[i]) + m) - u[i];
             invsum += 1.0f / T[i];
             g[pi[i]] = e[i] * invsum - 1.0f;
         }
-        loss_q[q] = loss;
+        loss_q[q] = (float)loss;
     }
     free(buf);
     return ORC_OK;

@@ -225,7 +225,7 @@ extern "C" int ptr_approxndcg_fwd_bwd(const float *preds, const float *labels, c
     using namespace ptr;
     const char *who = "ptr_approxndcg_fwd_bwd";
     if (int rc = check_batch(preds, labels, B, L, who)) return rc;
-    if (!loss_out || !dcg_q || !inv_idcg_q || !grad || !scale_out) { set_error("%s: NULL output pointer", who); return PTR_ERR_INVALID_ARG; }
+    if (!loss_out || !scale_out || (B > 0 && (!dcg_q || !inv_idcg_q || !grad))) { set_error("%s: NULL output pointer", who); return PTR_ERR_INVALID_ARG; }
     if (!(alpha > 0.0f)) { set_error("%s: alpha must be > 0 (got %g)", who, (double)alpha); return PTR_ERR_INVALID_ARG; }
     hipStream_t st = as_stream(stream);
     if (B > 0) {

@@ -86,7 +86,7 @@ lambdaloss_kernel(const float *__restrict__ preds, const float *__restrict__ lab
     __syncthreads();
 
     const int kk = k < n ? (k < 0 ? 0 : k) : n;
-    const float eps = 1e-8f, inv_ln2 = 1.4426950408889634f;
+    const float eps = 1e-8f, inv_ln2 = 1.4426950408889634f, log2_eps = -26.575424759098897f;   // log2(1e-8)
     float4 me[DPT];
     float ga[DPT];
 #pragma unroll
@@ -112,13 +112,17 @@ lambdaloss_kernel(const float *__restrict__ preds, const float *__restrict__ lab
         float df = a_wins ? me[m].x - o.x : o.x - me[m].x;                 // s_winner - s_loser
         df = fminf(fmaxf(df, -1e8f), 1e8f);
         if (df != df) df = 0.0f;                                           // lambdaloss.py:115-116
-        const float p0 = 1.0f / (1.0f + expf(-(sigma * df)));
-        const float p = fmaxf(p0, eps);
-        const float wp0 = exp2f(w * log2f(p));                             // p ** w
-        const float wp = fmaxf(wp0, eps);
-        lacc -= log2f(wp);                                                 // lambdaloss.py:118-119,132
+        const float x = sigma * df;
+        const float p0 = 1.0f / (1.0f + expf(-x));
+        // log2(clamp(p, eps)): evaluated as -log1p(e^-x)/ln2 so that p close to 1 keeps full relative accuracy (the
+        // hardware log has an absolute error floor near 1 that would bias a sum over ~1e5 pairs).
+        const float lp = p0 >= eps ? -log1pf(expf(-x)) * inv_ln2 : log2_eps;
+        // log2(clamp(p^w, eps)) = max(w*log2(p), log2(eps)); the reference's fp32 rounding of p^w is unbiased noise
+        const float z = w * lp;
+        const bool wp_ok = z >= log2_eps;
+        lacc -= wp_ok ? z : log2_eps;                                      // lambdaloss.py:118-119,132
         float g = 0.0f;
-        if (p0 >= eps && wp0 >= eps) g = -(w * sigma * (1.0f - p0)) * inv_ln2;   // d/ds_winner; loser gets -g
+        if (p0 >= eps && wp_ok) g = -(w * sigma * (1.0f - p0)) * inv_ln2;  // d/ds_winner; loser gets -g
         const float ga_ = a_wins ? g : -g;
         ga[m] += ga_;
         atomicAdd(&gw[b], -ga_);
@@ -183,7 +187,7 @@ extern "C" int ptr_lambdaloss_fwd_bwd(const float *preds, const float *labels, c
     using namespace ptr;
     const char *who = "ptr_lambdaloss_fwd_bwd";
     if (int rc = check_batch(preds, labels, B, L, who)) return rc;
-    if (!loss_q || !grad) { set_error("%s: NULL output pointer", who); return PTR_ERR_INVALID_ARG; }
+    if (B > 0 && (!loss_q || !grad)) { set_error("%s: NULL output pointer", who); return PTR_ERR_INVALID_ARG; }
     if (loss_type != PTR_LAMBDALOSS_NDCG_LOSS2 && loss_type != PTR_LAMBDALOSS_NDCG_LOSS2PP) {
         set_error("%s: loss_type %d not supported (1 = NDCG_Loss2, 2 = NDCG_Loss2++)", who, loss_type);
         return PTR_ERR_INVALID_ARG;

@@ -172,7 +172,7 @@ extern "C" int ptr_listnet_fwd_bwd(const float *preds, const float *labels, cons
     using namespace ptr;
     const char *who = "ptr_listnet_fwd_bwd";
     if (int rc = check_batch(preds, labels, B, L, who)) return rc;
-    if (!loss_q || !grad) { set_error("%s: NULL output pointer", who); return PTR_ERR_INVALID_ARG; }
+    if (B > 0 && (!loss_q || !grad)) { set_error("%s: NULL output pointer", who); return PTR_ERR_INVALID_ARG; }
     if (B > 0) {
         const int Lp = round_up(L, 4);
         const size_t per_q = 2 * (size_t)Lp * sizeof(float);
@@ -190,7 +190,7 @@ extern "C" int ptr_listmle_fwd_bwd(const float *preds, const int64_t *perm, cons
     using namespace ptr;
     const char *who = "ptr_listmle_fwd_bwd";
     if (int rc = check_batch(preds, perm, B, L, who)) return rc;
-    if (!loss_q || !grad) { set_error("%s: NULL output pointer", who); return PTR_ERR_INVALID_ARG; }
+    if (B > 0 && (!loss_q || !grad)) { set_error("%s: NULL output pointer", who); return PTR_ERR_INVALID_ARG; }
     if (B > 0) {
         const int Lp = round_up(L, 4);
         const size_t per_q = 4 * (size_t)Lp * sizeof(float);

@@ -183,7 +183,7 @@ template <bool WEIGHTED>
 static int launch_pairwise(const float *preds, const float *labels, const int32_t *lens, int B, int L, float sigma,
                            float *loss_out, float *loss_q, float *grad, void *stream, const char *who) {
     if (int rc = check_batch(preds, labels, B, L, who)) return rc;
-    if (!loss_q || !grad) { set_error("%s: NULL output pointer", who); return PTR_ERR_INVALID_ARG; }
+    if (B > 0 && (!loss_q || !grad)) { set_error("%s: NULL output pointer", who); return PTR_ERR_INVALID_ARG; }
     if (WEIGHTED && !(sigma >= 0.0f)) { set_error("%s: sigma must be >= 0 (got %g)", who, (double)sigma); return PTR_ERR_INVALID_ARG; }
     hipStream_t st = as_stream(stream);
     if (B > 0) {

@@ -1,0 +1,133 @@
+"""CPU: host-side mirror of the reference's plugin surface (class shapes, constructor signatures, error behaviour) and
+the install() drop-in wiring into the reference's ltr module (when the reference is importable)."""
+import inspect
+import os
+import sys
+
+import pytest
+import torch
+
+import ptranking_amd as pa
+from ptranking_amd import host, rankers
+
+REF = "/root/reference"
+SF = {"sf_id": "pointsf", "opt": "Adam", "lr": 1e-3,
+      "pointsf": dict(num_features=12, num_layers=3, AF="R", TL_AF="S", apply_tl_af=False, BN=False, bn_type=None, bn_affine=False)}
+
+
+def test_constructor_signatures_match_the_reference():
+    """lambdarank.py:23, ranknet.py:20, lambdaloss.py:67, approxNDCG.py:74, listmle.py:70 vs listnet.py:19."""
+    for name in ("RankNet", "LambdaRank", "LambdaLoss", "ApproxNDCG", "ListMLE"):
+        assert list(inspect.signature(getattr(pa, name).__init__).parameters) == \
+            ["self", "sf_para_dict", "model_para_dict", "gpu", "device"], name
+    assert list(inspect.signature(pa.ListNet.__init__).parameters) == ["self", "sf_para_dict", "gpu", "device"]
+    for name in pa.RANKER_NAMES:
+        cls = getattr(pa, name)
+        for meth in ("init", "train", "train_op", "custom_loss_function", "forward", "predict", "save", "load", "validation",
+                     "ndcg_at_k", "ndcg_at_ks", "nerr_at_k", "ap_at_k", "p_at_k", "adhoc_performance_at_ks", "stop_training",
+                     "eval_mode", "train_mode", "uniform_eval_setting", "get_tl_af", "config_optimizer", "get_parameters"):
+            assert callable(getattr(cls, meth)), (name, meth)
+
+
+def test_evaluator_signatures_match_the_reference():
+    ev = host.DeviceEvaluator
+    assert list(inspect.signature(ev.ndcg_at_k).parameters) == ["self", "test_data", "k", "label_type", "presort", "device"]
+    assert list(inspect.signature(ev.ap_at_k).parameters) == ["self", "test_data", "k", "presort", "device"]
+    assert list(inspect.signature(ev.p_at_k).parameters) == ["self", "test_data", "k", "device"]
+    assert list(inspect.signature(ev.adhoc_performance_at_ks).parameters) == \
+        ["self", "test_data", "ks", "label_type", "max_label", "presort", "device", "need_per_q"]
+    assert list(inspect.signature(ev.validation).parameters) == \
+        ["self", "vali_data", "vali_metric", "k", "presort", "max_label", "label_type", "device"]
+
+
+def test_standalone_ranker_builds_the_reference_scorer():
+    r = pa.LambdaRank(sf_para_dict=SF, model_para_dict={"sigma": 1.0}, gpu=False, device="cpu")
+    r.init()
+    names = [n for n, _ in r.point_sf.named_children()]
+    assert names == ["dr_1", "ff_2", "act_2", "dr_2", "ff_3", "act_3", "dr_3", "ff_4", "act_4", "ff_5"]   # base/utils.py:299-322
+    assert sum(p.numel() for p in r.get_parameters()) == 12 * 100 + 100 + 2 * (100 * 100 + 100) + 100 + 1
+    assert isinstance(r.optimizer, torch.optim.Adam) and r.optimizer.defaults["weight_decay"] == 1e-3
+    assert r.scheduler.step_size == 20 and r.scheduler.gamma == 0.5                                        # ranker.py:525
+    assert r.forward(torch.randn(3, 7, 12)).shape == (3, 7)
+    assert r.stop_check_freq == 10 and r.sigma == 1.0
+    # NaN / all-zero detection (ranker.py:547-561)
+    assert r.stop_training(torch.zeros(2, 3)) is True
+    assert r.stop_training(torch.tensor([[1.0, float("nan")]])) is True
+    assert r.stop_training(torch.ones(2, 3)) is False
+
+
+def test_reference_error_behaviour_is_preserved():
+    r = pa.LambdaRank(sf_para_dict=SF, model_para_dict={"sigma": 1.0}, gpu=False, device="cpu")
+    p, y = torch.zeros(1, 4), torch.zeros(1, 4)
+    with pytest.raises(AssertionError):      # lambdarank.py:34
+        r.custom_loss_function(p, y, presort=True)
+    with pytest.raises(AssertionError):      # lambdarank.py:36
+        r.custom_loss_function(p, y, presort=False, label_type=pa.LABEL_TYPE.MultiLabel)
+    with pytest.raises(AssertionError):
+        r.custom_loss_function(p, y, presort=True, label_type=pa.LABEL_TYPE.Permutation)
+    with pytest.raises(NotImplementedError):
+        pa.LambdaLoss(sf_para_dict=SF, model_para_dict=dict(k=5, sigma=1.0, loss_type="ARP_Loss1"), gpu=False, device="cpu")
+    with pytest.raises(NotImplementedError):
+        bad = dict(SF, opt="SGD")
+        rr = pa.ListNet(sf_para_dict=bad, gpu=False, device="cpu")
+        rr.init()
+    with pytest.raises(NotImplementedError):
+        pa.RankNet(sf_para_dict=dict(SF, sf_id="listsf", listsf={}), model_para_dict={"sigma": 1.0})
+    with pytest.raises(NotImplementedError):
+        r.validation(vali_data=[], vali_metric="MRR")
+    ll = pa.LambdaLoss(sf_para_dict=SF, model_para_dict=pa.DEFAULT_PARAS["LambdaLoss"], gpu=False, device="cpu")
+    assert (ll.k, ll.sigma, ll.loss_type) == (5, 1.0, "NDCG_Loss2")
+    ap = pa.ApproxNDCG(sf_para_dict=SF, model_para_dict=pa.DEFAULT_PARAS["ApproxNDCG"], gpu=False, device="cpu")
+    ed = dict(do_validation=True, vali_metric="AP")
+    ap.uniform_eval_setting(eval_dict=ed)
+    assert ed["vali_metric"] == "nDCG"       # approxNDCG.py:78-81
+
+
+def test_label_type_accepts_the_reference_enum_by_name():
+    assert host.is_multilabel(pa.LABEL_TYPE.MultiLabel) and not host.is_multilabel(pa.LABEL_TYPE.Permutation)
+
+    class Fake:
+        name = "MultiLabel"
+    assert host.is_multilabel(Fake())
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
+def test_install_drops_into_the_reference_driver():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    try:
+        import ptranking.ltr_adhoc.eval.ltr as ref_ltr
+        from ptranking.base.adhoc_ranker import AdhocNeuralRanker
+        from ptranking.data.data_utils import LABEL_TYPE as REF_LABEL_TYPE
+        original = ref_ltr.LambdaRank
+        installed = pa.install()
+        try:
+            assert set(installed) == set(pa.RANKER_NAMES)
+            for n, cls in installed.items():
+                assert getattr(ref_ltr, n) is cls and issubclass(cls, AdhocNeuralRanker)
+                assert cls.custom_loss_function is not getattr(original if n == "LambdaRank" else AdhocNeuralRanker,
+                                                               "custom_loss_function")
+            # the reference's own factory instantiates OUR class with ITS calling convention (ltr.py:164-171)
+            ev = ref_ltr.LTREvaluator()
+            sf = {"sf_id": "pointsf", "opt": "Adam", "lr": 1e-3,
+                  "pointsf": dict(num_features=8, num_layers=3, AF="R", TL_AF="S", apply_tl_af=False, BN=False,
+                                  bn_type=None, bn_affine=False)}
+            for model_id, paras in (("LambdaRank", {"model_id": "LambdaRank", "sigma": 1.0}), ("ListNet", {"model_id": "ListNet"}),
+                                    ("ApproxNDCG", {"model_id": "ApproxNDCG", "alpha": 10})):
+                ranker = ev.load_ranker(sf_para_dict=sf, model_para_dict=paras)
+                assert type(ranker) is installed[model_id]
+                ranker.init()                       # the REFERENCE's scorer construction
+                assert ranker.forward(torch.randn(2, 5, 8)).shape == (2, 5)
+            assert host.is_multilabel(REF_LABEL_TYPE.MultiLabel)
+            # listsf scorers come from the reference base class unchanged
+            lsf = {"sf_id": "listsf", "opt": "Adam", "lr": 1e-3,
+                   "listsf": dict(num_features=8, ff_dims=[16, 16], AF="R", TL_AF="GE", apply_tl_af=False, BN=False, bn_type="BN2",
+                                  bn_affine=False, n_heads=2, encoder_layers=1, encoder_type="AllRank")}
+            lr = installed["LambdaRank"](sf_para_dict=lsf, model_para_dict={"sigma": 1.0}, gpu=False, device="cpu")
+            lr.init()
+            assert lr.forward(torch.randn(2, 6, 8)).shape == (2, 6)
+        finally:
+            pa.uninstall()
+        assert ref_ltr.LambdaRank is original
+    finally:
+        sys.path.remove(REF)

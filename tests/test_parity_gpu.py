@@ -234,9 +234,12 @@ def test_oracle_metrics_and_sort(F, B, L, use_lens):
     rv, ri = CO.sort_desc(preds, lens=ln)
     assert np.array_equal(idx.cpu().numpy(), ri)
     assert np.array_equal(vals.cpu().numpy(), rv)
-    if not use_lens:   # bit-exact against torch.sort itself on tie-free input
+    if not use_lens:   # bit-exact against torch.sort itself on tie-free rows (torch.sort is not stable)
         tv, ti = torch.sort(torch.from_numpy(preds), dim=1, descending=True)
-        assert np.array_equal(idx.cpu().numpy(), ti.numpy())
+        tie_free = np.array([len(np.unique(row)) == L for row in preds])
+        assert tie_free.any()
+        assert np.array_equal(idx.cpu().numpy()[tie_free], ti.numpy()[tie_free])
+        assert np.array_equal(vals.cpu().numpy(), tv.numpy())
 
 
 # ------------------------------------------------------------------------------------------ properties at BASELINE.json's full sizes

@@ -60,6 +60,9 @@ def test_train_op_matches_cpu_reference_step(name, paras, oracle_fn, okw):
         G.assert_close(loss.item(), ref, f"{name} loss step {step}")
     for (n1, p1), (n2, p2) in zip(ranker.point_sf.named_parameters(), cpu_net.named_parameters()):
         assert n1 == n2
+        if n1 == "ff_5.bias":
+            continue   # every in-scope loss is shift-invariant: this gradient is identically 0 and Adam turns its rounding
+                       # noise into +-lr moves on both sides
         assert torch.allclose(p1.detach().cpu(), p2.detach(), rtol=1e-4, atol=2e-5), n1
 
 
