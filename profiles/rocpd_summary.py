@@ -13,7 +13,7 @@ def main(db_path, out_csv):
         w = csv.writer(f)
         w.writerow(["kernel", "calls", "total_us", "average_us", "percent"])
         for name, calls, total, avg, pct in rows:
-            w.writerow([name, calls, f"{total / 1e3:.3f}", f"{avg / 1e3:.3f}", f"{pct:.3f}"])
+            w.writerow([name, calls, f"{total:.3f}", f"{avg:.3f}", f"{pct:.3f}"])   # the view reports microseconds
     print(f"{out_csv}: {len(rows)} kernels")
 
 
