@@ -22,6 +22,7 @@
 #ifndef PTRANKING_AMD_H
 #define PTRANKING_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -107,6 +108,28 @@ int ptr_metrics_at_ks(const float *preds, const float *labels, const int32_t *le
 /* Deterministic sum of n floats (fixed reduction tree): out[0] = scale * sum(x).  Used for the per-query loss slots
  * and for Evaluator running sums. */
 int ptr_sum_f32(const float *x, int n, float scale, float *out, void *stream);
+
+/* ---- pointwise MLP scorer (`pointsf`) --------------------------------------------------------------------------------
+ * Replaces ptranking/base/point_ranker.py:45-55 (forward of the stacked feed-forward scorer built by
+ * ptranking/base/utils.py:288-356 with AF='R', BN=False, apply_tl_af=False: (Dropout -> Linear -> ReLU) x NL -> Linear), its
+ * autograd backward, and the Adam update of ptranking/base/ranker.py:512-525.  Hidden width is 100 (point_ranker.py:30).
+ * `params` / `grad` are ONE flat fp32 buffer in PyTorch's own order and layouts:
+ *   W1[100][F] b1[100] | W2[100][100] b2[100] | ... (NL hidden layers) | w_out[100] b_out[1]      (ptr_mlp_num_params floats)
+ * X is [R][F] row-major (R = B*L documents), preds [R].  train != 0: dropout p_drop from the counter-based generator
+ * seeded by `seed`, and the post-dropout activations needed by backward are written to acts [NL][R][100].
+ * ptr_mlp_backward: dpreds [R] -> grad (every entry overwritten); dz [NL][R][100] and ws (ptr_mlp_backward_ws_floats)
+ * are caller-provided scratch; p_drop / seed must be the forward call's.  All calls are deterministic. */
+size_t ptr_mlp_num_params(int F, int NL);
+size_t ptr_mlp_backward_ws_floats(int F, int NL);
+int ptr_mlp_forward(const float *X, const float *params, int R, int F, int NL, int train, float p_drop, uint64_t seed,
+                    float *preds, float *acts, void *stream);
+int ptr_mlp_backward(const float *X, const float *params, const float *acts, const float *dpreds, int R, int F, int NL,
+                     float p_drop, uint64_t seed, float *dz, float *ws, float *grad, void *stream);
+/* torch.optim.Adam step (L2 weight decay added to the gradient, bias correction with `step` >= 1) on flat buffers. */
+int ptr_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, void *stream);
+/* Test helper: the dropout keep-mask (1.0 / 0.0) of dropout site `site` for an [R][n_feat] activation. */
+int ptr_mlp_dropout_mask(int R, int n_feat, int site, float p_drop, uint64_t seed, float *out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -31,12 +31,15 @@ SIGNATURES = {
     "ptr_sort_desc": [_vp, _vp, _i, _i, _vp, _vp, _vp],
     "ptr_metrics_at_ks": [_vp, _vp, _vp, _i, _i, C.POINTER(C.c_int32), _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp],
     "ptr_sum_f32": [_vp, _i, _f, _vp, _vp],
+    "ptr_mlp_num_params": [_i, _i],
+    "ptr_mlp_backward_ws_floats": [_i, _i],
     "ptr_mlp_forward": [_vp, _vp, _i, _i, _i, _i, _f, _u64, _vp, _vp, _vp],
-    "ptr_mlp_backward": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _vp, _vp, _vp],
+    "ptr_mlp_backward": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _vp, _vp, _vp, _vp],
     "ptr_adam_step": [_vp, _vp, _vp, _vp, C.c_int64, _f, _f, _f, _f, _f, _i, _vp],
+    "ptr_mlp_dropout_mask": [_i, _i, _i, _f, _u64, _vp, _vp],
 }
-_RESTYPES = {"ptr_last_error": C.c_char_p}
-OPTIONAL = {"ptr_mlp_forward", "ptr_mlp_backward", "ptr_adam_step"}
+_RESTYPES = {"ptr_last_error": C.c_char_p, "ptr_mlp_num_params": C.c_size_t, "ptr_mlp_backward_ws_floats": C.c_size_t}
+OPTIONAL = set()
 
 _lib = None
 
@@ -78,6 +81,11 @@ def has(name):
 # Optional profiling hook (bench.py): TIMING = {} makes call() bracket every entry point with HIP events recorded on
 # torch's current stream (the stream the kernels are enqueued on); TIMING[name] collects (start, end) event pairs.
 TIMING = None
+
+
+def query(name, *args):
+    """Invoke a size-returning helper (no error code)."""
+    return getattr(load(), name)(*args)
 
 
 def call(name, *args):

@@ -1,0 +1,617 @@
+// Fused fp32-MFMA pointwise MLP scorer (the reference's `pointsf`): forward, backward and a flat Adam step.
+//
+// Reference: ptranking/base/point_ranker.py:30-55 (ff_dims = [F] + [100]*num_layers + [1], forward = Sequential(X).view(-1, L)),
+//            ptranking/base/utils.py:288-356 (get_stacked_FFNet with AF='R', BN=False, apply_tl_af=False:
+//            (Dropout(0.1) -> Linear -> ReLU) x num_layers -> Linear), ptranking/base/ranker.py:512-525 (Adam, weight_decay 1e-3).
+// Every document is scored independently, so the batch is a matrix of R = B*L rows x F features.
+//
+// Parameters live in ONE flat fp32 buffer in PyTorch's own order and layouts (Linear.weight is [out][in]):
+//   W1[100][F] b1[100] | W2[100][100] b2[100] | ... | w_out[100] b_out[1]
+// so the optimiser, the data-parallel all-reduce and checkpoints see a single tensor.
+//
+// MFMA formulation (v_mfma_f32_16x16x4_f32: exact fp32, 256 FLOP/clk/CU = the fp32 vector peak, 157 TFLOP/s):
+//   forward, "transposed world":  Z^T[feature][row] = W[feature][k] * A^T[k][row].  A 16x16 output tile leaves lane (j = l&15,
+//   g = l>>4) holding row j's features 16*mt + 4*g + {0..3} — which IS the B-operand layout of the next layer (k may be
+//   visited in any order as long as A and B agree), so activations stay in registers through all layers; LDS only holds
+//   the weights (A operands, read as one ds_read_b128 per 4 k-steps straight from the [out][in] layout).
+//   backward dZ, same world with W^T in LDS:  dA^T[k][row] = W^T[k][out] * dZ^T[out][row].
+//   backward dW, "row-contraction world":     dW[out][in] = sum_rows dZ[row][out] * A[row][in]  streams dZ and A from HBM with
+//   rows as the MFMA k index (lane j = feature, g = row), accumulating the whole 100 x K gradient in registers per wave.
+// Dropout masks come from a counter-based hash of (seed, site, row, feature/4) and are recomputed, never stored.
+//
+// HBM traffic per row (F = 136, 3 hidden layers, training): forward reads 4F, writes 3*400 + 4; dZ reads 3*400 + 4, writes
+// 3*400; dW reads 4F + 5*400.  MFMA work per row: 2*(100F + 2*100*100 + 100) flop forward, about twice that backward.
+#include "ptr_device.h"
+
+namespace ptr {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kH = 100;          // hidden width, hard-wired in the reference (point_ranker.py:30)
+constexpr int kHP = 112;         // padded to 7 MFMA tiles of 16
+constexpr int kMT = 7;
+constexpr int kMaxLayers = 8;
+
+__host__ __device__ inline size_t off_W(int l, int F) { return l == 0 ? 0 : (size_t)kH * F + kH + (size_t)(l - 1) * (kH * kH + kH); }
+__host__ __device__ inline size_t off_b(int l, int F) { return off_W(l, F) + (l == 0 ? (size_t)kH * F : (size_t)kH * kH); }
+__host__ __device__ inline size_t off_wout(int NL, int F) { return off_W(NL, F); }
+__host__ __device__ inline size_t n_params(int NL, int F) { return off_wout(NL, F) + kH + 1; }
+__host__ __device__ inline int ld_w1(int F) { return (F + 3) / 4 * 4 + 4; }   // LDS leading dimension of W1 (bank spread)
+
+// ---------------------------------------------------------------------------------------------- dropout bits
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+// 64 random bits for features [4*fg, 4*fg+3] of `row` at dropout site `site` (site l = the Dropout in front of hidden layer l)
+__device__ __forceinline__ void drop_bits(uint32_t seed_lo, uint32_t seed_hi, int site, int row, int fg, uint32_t &w0, uint32_t &w1) {
+    const uint32_t key = (uint32_t)row * 0x9E3779B1u + (uint32_t)fg * 0x85EBCA77u + (uint32_t)site * 0xC2B2AE3Du;
+    w0 = lowbias32(key ^ seed_lo);
+    w1 = lowbias32(w0 ^ seed_hi ^ 0x68E31DA4u);
+}
+__device__ __forceinline__ f32x4 drop4(f32x4 v, uint32_t w0, uint32_t w1, uint32_t thr, float scale) {
+    f32x4 o;
+    o[0] = (w0 & 0xFFFFu) >= thr ? v[0] * scale : 0.0f;
+    o[1] = (w0 >> 16) >= thr ? v[1] * scale : 0.0f;
+    o[2] = (w1 & 0xFFFFu) >= thr ? v[2] * scale : 0.0f;
+    o[3] = (w1 >> 16) >= thr ? v[3] * scale : 0.0f;
+    return o;
+}
+__device__ __forceinline__ bool drop_keep1(uint32_t seed_lo, uint32_t seed_hi, int site, int row, int k, uint32_t thr) {
+    uint32_t w0, w1;
+    drop_bits(seed_lo, seed_hi, site, row, k >> 2, w0, w1);
+    const uint32_t w = (k & 2) ? w1 : w0;
+    return ((k & 1) ? (w >> 16) : (w & 0xFFFFu)) >= thr;
+}
+
+struct MlpArgs {
+    int R, F, NL;
+    float p_drop;            // 0 => no dropout (eval mode)
+    uint32_t seed_lo, seed_hi;
+};
+
+__device__ __forceinline__ uint32_t drop_thr(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
+
+// Stage a [rows_valid][cols_valid] row-major matrix into LDS as [kHP][ld], zero padded.  transpose: dst[c][r] = src[r][c].
+__device__ __forceinline__ void stage_matrix(float *dst, int ld, const float *src, int rows, int cols, bool transpose, int tid, int nthr) {
+    for (int idx = tid; idx < kHP * ld; idx += nthr) {
+        const int r = idx / ld, c = idx - r * ld;
+        float v = 0.0f;
+        if (!transpose) { if (r < rows && c < cols) v = src[(size_t)r * cols + c]; }
+        else            { if (r < cols && c < rows) v = src[(size_t)c * cols + r]; }
+        dst[idx] = v;
+    }
+}
+__device__ __forceinline__ void stage_vector(float *dst, const float *src, int n, int tid, int nthr) {
+    for (int i = tid; i < kHP; i += nthr) dst[i] = i < n ? src[i] : 0.0f;
+}
+
+// =================================================================================================== forward
+// LDS: W1s [kHP][ld1] | Wh (NL-1) x [kHP][kH] | B NL x [kHP] | Wo [kHP] | bo + pad [16]
+__host__ __device__ inline size_t fwd_lds_floats(int F, int NL) {
+    return (size_t)kHP * ld_w1(F) + (size_t)(NL - 1) * kHP * kH + (size_t)NL * kHP + kHP + 16;
+}
+
+template <int RT, bool TRAIN, bool VEC>
+__global__ void __launch_bounds__(512)
+mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs a, float *__restrict__ preds,
+               float *__restrict__ acts) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int F = a.F, NL = a.NL, R = a.R, ld1 = ld_w1(F);
+    float *W1s = smem;
+    float *Wh = W1s + (size_t)kHP * ld1;
+    float *Bs = Wh + (size_t)(NL - 1) * kHP * kH;
+    float *Wo = Bs + (size_t)NL * kHP;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    stage_matrix(W1s, ld1, P + off_W(0, F), kH, F, false, tid, nthr);
+    for (int l = 1; l < NL; ++l) stage_matrix(Wh + (size_t)(l - 1) * kHP * kH, kH, P + off_W(l, F), kH, kH, false, tid, nthr);
+    for (int l = 0; l < NL; ++l) stage_vector(Bs + (size_t)l * kHP, P + off_b(l, F), kH, tid, nthr);
+    stage_vector(Wo, P + off_wout(NL, F), kH, tid, nthr);
+    if (tid < 16) Wo[kHP + tid] = tid == 0 ? P[off_wout(NL, F) + kH] : 0.0f;
+    __syncthreads();
+    const float b_out = Wo[kHP];
+
+    const int lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int wpb = nthr >> 6, wave = tid >> 6;
+    const int rows_per_tile = 16 * RT;
+    const int ntiles = (R + rows_per_tile - 1) / rows_per_tile;
+    const uint32_t thr = drop_thr(a.p_drop);
+    const float scale = TRAIN ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+    const int nS1 = (F + 15) >> 4;
+
+    for (int tile = blockIdx.x * wpb + wave; tile < ntiles; tile += gridDim.x * wpb) {
+        const int row0 = tile * rows_per_tile;
+        int row[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) row[rt] = row0 + 16 * rt + j;
+
+        auto load_x = [&](int S, f32x4 (&xb)[RT]) {
+            const int k0 = 16 * S + 4 * g;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (row[rt] < R) {
+                    const float *src = X + (size_t)row[rt] * F + k0;
+                    if constexpr (VEC) { if (k0 < F) v = *reinterpret_cast<const f32x4 *>(src); }
+                    else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) if (k0 + c < F) v[c] = src[c];
+                    }
+                    if constexpr (TRAIN) {
+                        uint32_t w0, w1;
+                        drop_bits(a.seed_lo, a.seed_hi, 0, row[rt], k0 >> 2, w0, w1);
+                        v = drop4(v, w0, w1, thr, scale);
+                    }
+                }
+                xb[rt] = v;
+            }
+        };
+
+        // ---- hidden layer 1: K = F, B operand streamed from HBM (X), software-prefetched one super-step ahead
+        f32x4 acc[kMT][RT];
+#pragma unroll
+        for (int mt = 0; mt < kMT; ++mt) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(Bs + 16 * mt + 4 * g);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[mt][rt] = b4;
+        }
+        f32x4 xcur[RT], xnxt[RT];
+        load_x(0, xcur);
+        for (int S = 0; S < nS1; ++S) {
+            if (S + 1 < nS1) load_x(S + 1, xnxt);
+            const int k0 = 16 * S + 4 * g;
+#pragma unroll
+            for (int mt = 0; mt < kMT; ++mt) {
+                const f32x4 wa = *reinterpret_cast<const f32x4 *>(W1s + (size_t)(16 * mt + j) * ld1 + k0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+                        acc[mt][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c], xcur[rt][c], acc[mt][rt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) xcur[rt] = xnxt[rt];
+        }
+
+        // ---- hidden layers 2..NL: B operand = the previous layer's output registers
+        for (int l = 1; l < NL; ++l) {
+            f32x4 hin[kMT][RT];
+#pragma unroll
+            for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    f32x4 h = acc[mt][rt];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) h[c] = fmaxf(h[c], 0.0f);
+                    if constexpr (TRAIN) {
+                        uint32_t w0, w1;
+                        drop_bits(a.seed_lo, a.seed_hi, l, row[rt], 4 * mt + g, w0, w1);
+                        h = drop4(h, w0, w1, thr, scale);
+                        if (row[rt] < R && (mt < kMT - 1 || g == 0))
+                            *reinterpret_cast<f32x4 *>(acts + ((size_t)(l - 1) * R + row[rt]) * kH + 16 * mt + 4 * g) = h;
+                    }
+                    hin[mt][rt] = h;
+                }
+            const float *Wl = Wh + (size_t)(l - 1) * kHP * kH;
+#pragma unroll
+            for (int mt = 0; mt < kMT; ++mt) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(Bs + (size_t)l * kHP + 16 * mt + 4 * g);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[mt][rt] = b4;
+            }
+#pragma unroll
+            for (int S = 0; S < kMT; ++S)
+#pragma unroll
+                for (int mt = 0; mt < kMT; ++mt) {
+                    const f32x4 wa = *reinterpret_cast<const f32x4 *>(Wl + (size_t)(16 * mt + j) * kH + 16 * S + 4 * g);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt)
+                            acc[mt][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c], hin[S][rt][c], acc[mt][rt], 0, 0, 0);
+                }
+        }
+
+        // ---- last hidden activation + output layer (100 -> 1): VALU dot product, reduced over the 4 lane groups
+        float sc[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) sc[rt] = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < kMT; ++mt) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4 *>(Wo + 16 * mt + 4 * g);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                f32x4 h = acc[mt][rt];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { h[c] = fmaxf(h[c], 0.0f); sc[rt] = fmaf(h[c], w4[c], sc[rt]); }
+                if constexpr (TRAIN) {
+                    if (row[rt] < R && (mt < kMT - 1 || g == 0))
+                        *reinterpret_cast<f32x4 *>(acts + ((size_t)(NL - 1) * R + row[rt]) * kH + 16 * mt + 4 * g) = h;
+                }
+            }
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            float s = sc[rt];
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            if (g == 0 && row[rt] < R) preds[row[rt]] = s + b_out;
+        }
+    }
+}
+
+// =================================================================================================== backward: dZ chain
+// LDS: WT (NL-1) x [kHP][kH] (hidden weights TRANSPOSED: WT[k][out]) | Wo [kHP] | red [kHP + 16]
+__host__ __device__ inline size_t dz_lds_floats(int NL) { return (size_t)(NL - 1) * kHP * kH + (kHP + 16) + 8 * (kHP + 16); }
+
+// dz[l] (l = 0..NL-1) = dLoss/d(pre-activation of hidden layer l+1), [NL][R][100].  acts[l] = post-dropout input of hidden
+// layer l+2 (l < NL-1) / last hidden activation (l = NL-1), as the forward kernel stored them.
+// part_out[block][kHP + 16]: per-block partial of d w_out (100) and d b_out (index kHP).
+template <int RT>
+__global__ void __launch_bounds__(512)
+mlp_bwd_dz_kernel(const float *__restrict__ P, const float *__restrict__ acts, const float *__restrict__ dpreds, MlpArgs a,
+                  float *__restrict__ dz, float *__restrict__ part_out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int F = a.F, NL = a.NL, R = a.R;
+    float *WT = smem;
+    float *Wo = WT + (size_t)(NL - 1) * kHP * kH;
+    float *wrow = Wo + kHP + 16;                          // [8 waves][kHP + 16] partial d w_out / d b_out
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    for (int l = 1; l < NL; ++l) stage_matrix(WT + (size_t)(l - 1) * kHP * kH, kH, P + off_W(l, F), kH, kH, true, tid, nthr);
+    stage_vector(Wo, P + off_wout(NL, F), kH, tid, nthr);
+    if (tid < 16) Wo[kHP + tid] = 0.0f;
+    __syncthreads();
+
+    const int lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int wpb = nthr >> 6, wave = tid >> 6;
+    const int rows_per_tile = 16 * RT;
+    const int ntiles = (R + rows_per_tile - 1) / rows_per_tile;
+    const float inv_keep = a.p_drop > 0.0f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+
+    f32x4 dwo[kMT];
+#pragma unroll
+    for (int mt = 0; mt < kMT; ++mt) dwo[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dbo = 0.0f;
+
+    for (int tile = blockIdx.x * wpb + wave; tile < ntiles; tile += gridDim.x * wpb) {
+        const int row0 = tile * rows_per_tile;
+        int row[RT];
+        float ds[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            row[rt] = row0 + 16 * rt + j;
+            ds[rt] = row[rt] < R ? dpreds[row[rt]] : 0.0f;
+            if (g == 0) dbo += ds[rt];
+        }
+        // top: dz_{NL-1} = ds * w_out * [h > 0];  d w_out += h * ds
+        f32x4 cur[kMT][RT];
+#pragma unroll
+        for (int mt = 0; mt < kMT; ++mt) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4 *>(Wo + 16 * mt + 4 * g);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                f32x4 h = {0.f, 0.f, 0.f, 0.f};
+                const bool ok = row[rt] < R && (mt < kMT - 1 || g == 0);
+                const size_t o = ((size_t)(NL - 1) * R + row[rt]) * kH + 16 * mt + 4 * g;
+                if (ok) h = *reinterpret_cast<const f32x4 *>(acts + o);
+                f32x4 d;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { d[c] = h[c] > 0.0f ? ds[rt] * w4[c] : 0.0f; dwo[mt][c] = fmaf(h[c], ds[rt], dwo[mt][c]); }
+                if (ok) *reinterpret_cast<f32x4 *>(dz + o) = d;
+                cur[mt][rt] = d;
+            }
+        }
+        for (int l = NL - 1; l >= 1; --l) {
+            // dA_{l-1}^T[k][row] = sum_out W_l[out][k] * dz_l[row][out]
+            const float *Wl = WT + (size_t)(l - 1) * kHP * kH;
+            f32x4 acc[kMT][RT];
+#pragma unroll
+            for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[mt][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int S = 0; S < kMT; ++S)
+#pragma unroll
+                for (int mt = 0; mt < kMT; ++mt) {
+                    const f32x4 wa = *reinterpret_cast<const f32x4 *>(Wl + (size_t)(16 * mt + j) * kH + 16 * S + 4 * g);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt)
+                            acc[mt][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c], cur[S][rt][c], acc[mt][rt], 0, 0, 0);
+                }
+            // gate with the stored post-dropout activation: a > 0  <=>  kept by dropout AND relu active
+#pragma unroll
+            for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    f32x4 av = {0.f, 0.f, 0.f, 0.f};
+                    const bool ok = row[rt] < R && (mt < kMT - 1 || g == 0);
+                    const size_t o = ((size_t)(l - 1) * R + row[rt]) * kH + 16 * mt + 4 * g;
+                    if (ok) av = *reinterpret_cast<const f32x4 *>(acts + o);
+                    f32x4 d;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) d[c] = av[c] > 0.0f ? acc[mt][rt][c] * inv_keep : 0.0f;
+                    if (ok) *reinterpret_cast<f32x4 *>(dz + o) = d;
+                    cur[mt][rt] = d;
+                }
+        }
+    }
+    // block partial of d w_out / d b_out: butterfly over the 16 row-lanes j, one LDS row per wave, then a fixed-order sum
+#pragma unroll
+    for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v = dwo[mt][c];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            if (j == 0) wrow[(size_t)wave * (kHP + 16) + 16 * mt + 4 * g + c] = v;
+        }
+    {
+        float v = dbo;
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+        if (lane == 0) wrow[(size_t)wave * (kHP + 16) + kHP] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < kHP + 1; i += nthr) {
+        float s = 0.0f;
+        for (int w = 0; w < wpb; ++w) s += wrow[(size_t)w * (kHP + 16) + i];
+        part_out[(size_t)blockIdx.x * (kHP + 16) + i] = s;
+    }
+}
+
+// =================================================================================================== backward: dW (row contraction)
+// One launch per layer.  dW[out][in] = sum_rows dZ[row][out] * A[row][in];  db[out] = sum_rows dZ[row][out].
+// A = X with the input dropout recomputed (layer 0, SITE0) or the stored activation (other layers).  Each wave owns the
+// in-feature tiles nt = wave, wave + 4, ... and all 7 out-feature tiles; a block walks its contiguous chunk of rows 4 at a time.
+// ws[block][100*K + 100]: per-block partial (dW then db), reduced by reduce_partials_kernel.
+template <int NTW, bool SITE0>
+__global__ void __launch_bounds__(256)
+mlp_bwd_dw_kernel(const float *__restrict__ A, const float *__restrict__ dZ, int K, MlpArgs a, float *__restrict__ ws) {
+    const int R = a.R;
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6;
+    const int chunk = ((R + gridDim.x - 1) / gridDim.x + 15) & ~15;
+    const int r_begin = blockIdx.x * chunk, r_end = min(R, r_begin + chunk);
+    const uint32_t thr = drop_thr(a.p_drop);
+    const float scale = (SITE0 && a.p_drop > 0.0f) ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+    const int ntk = (K + 15) >> 4;
+
+    f32x4 acc[NTW][kMT];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int mt = 0; mt < kMT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dbv[kMT];
+#pragma unroll
+    for (int mt = 0; mt < kMT; ++mt) dbv[mt] = 0.0f;
+
+    constexpr int U = 4;                                   // k-steps (of 4 rows) per iteration
+    float av[U][kMT], bv[U][NTW], avn[U][kMT], bvn[U][NTW];
+    auto load = [&](int r0, float (&pa)[U][kMT], float (&pb)[U][NTW]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + 4 * u + g;
+            const bool rok = r < r_end;
+#pragma unroll
+            for (int mt = 0; mt < kMT; ++mt) {
+                const int f = 16 * mt + j;
+                pa[u][mt] = (rok && f < kH) ? dZ[(size_t)r * kH + f] : 0.0f;
+            }
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                const int nt = wave + 4 * t, k = 16 * nt + j;
+                float v = (rok && nt < ntk && k < K) ? A[(size_t)r * K + k] : 0.0f;
+                if constexpr (SITE0) {
+                    if (a.p_drop > 0.0f) v = drop_keep1(a.seed_lo, a.seed_hi, 0, r, k, thr) ? v * scale : 0.0f;
+                }
+                pb[u][t] = v;
+            }
+        }
+    };
+    if (r_begin < r_end) load(r_begin, av, bv);
+    for (int r0 = r_begin; r0 < r_end; r0 += 4 * U) {
+        if (r0 + 4 * U < r_end) load(r0 + 4 * U, avn, bvn);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int mt = 0; mt < kMT; ++mt) dbv[mt] += av[u][mt];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int mt = 0; mt < kMT; ++mt)
+                    acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][mt], bv[u][t], acc[t][mt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int mt = 0; mt < kMT; ++mt) av[u][mt] = avn[u][mt];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) bv[u][t] = bvn[u][t];
+        }
+    }
+    float *out = ws + (size_t)blockIdx.x * ((size_t)kH * K + kH);
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int nt = wave + 4 * t, k = 16 * nt + j;
+#pragma unroll
+        for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int o = 16 * mt + 4 * g + c;
+                if (nt < ntk && k < K && o < kH) out[(size_t)o * K + k] = acc[t][mt][c];
+            }
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int mt = 0; mt < kMT; ++mt) {
+            float v = dbv[mt];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int f = 16 * mt + j;
+            if (g == 0 && f < kH) out[(size_t)kH * K + f] = v;
+        }
+    }
+}
+
+// grad[i] = sum_b ws[b][i] in block order (deterministic).
+__global__ void __launch_bounds__(256)
+reduce_partials_kernel(const float *__restrict__ ws, int nblk, size_t stride, size_t n, float *__restrict__ grad) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.0f;
+    for (int b = 0; b < nblk; ++b) s += ws[(size_t)b * stride + i];
+    grad[i] = s;
+}
+
+// =================================================================================================== Adam (torch.optim.Adam semantics)
+// g = grad + wd*p; m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+__global__ void __launch_bounds__(256)
+adam_kernel(float *__restrict__ p, const float *__restrict__ grad, float *__restrict__ m, float *__restrict__ v, size_t n, float lr,
+            float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float pi = p[i];
+    const float gi = grad[i] + wd * pi;
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+}
+
+// debug / test helper: the dropout keep-mask of one site as floats [R][n_feat]
+__global__ void __launch_bounds__(256)
+dropout_mask_kernel(MlpArgs a, int site, int n_feat, float *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)a.R * n_feat) return;
+    const int row = (int)(i / n_feat), k = (int)(i % n_feat);
+    out[i] = drop_keep1(a.seed_lo, a.seed_hi, site, row, k, drop_thr(a.p_drop)) ? 1.0f : 0.0f;
+}
+
+static int check_mlp(const char *who, int R, int F, int NL, float p) {
+    if (R < 0 || F <= 0 || NL < 1 || NL > kMaxLayers) { set_error("%s: bad shape R=%d F=%d NL=%d", who, R, F, NL); return PTR_ERR_INVALID_ARG; }
+    if (!(p >= 0.0f && p < 1.0f)) { set_error("%s: dropout p=%g out of [0,1)", who, (double)p); return PTR_ERR_INVALID_ARG; }
+    if (fwd_lds_floats(F, NL) * sizeof(float) > 160 * 1024) {
+        set_error("%s: F=%d with %d hidden layers needs %zu KB of LDS for the weights (max 160)", who, F, NL,
+                  fwd_lds_floats(F, NL) * sizeof(float) / 1024);
+        return PTR_ERR_UNSUPPORTED;
+    }
+    return 0;
+}
+
+static int num_cus() {
+    static int n = 0;
+    if (!n) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+}  // namespace ptr
+
+extern "C" size_t ptr_mlp_num_params(int F, int NL) { return ptr::n_params(NL, F); }
+
+// floats of workspace ptr_mlp_backward needs
+extern "C" size_t ptr_mlp_backward_ws_floats(int F, int NL) {
+    const size_t nblk = 2 * (size_t)ptr::num_cus();
+    const size_t kmax = (size_t)(F > ptr::kH ? F : ptr::kH);
+    return nblk * (ptr::kH * kmax + ptr::kH) + (size_t)ptr::num_cus() * (ptr::kHP + 16) + 64;
+}
+
+extern "C" int ptr_mlp_forward(const float *X, const float *params, int R, int F, int NL, int train, float p_drop, uint64_t seed,
+                               float *preds, float *acts, void *stream) {
+    using namespace ptr;
+    const char *who = "ptr_mlp_forward";
+    if (int rc = check_mlp(who, R, F, NL, p_drop)) return rc;
+    if (R > 0 && (!X || !params || !preds || (train && !acts))) { set_error("%s: NULL pointer", who); return PTR_ERR_INVALID_ARG; }
+    if (R == 0) return 0;
+    MlpArgs a{R, F, NL, train ? p_drop : 0.0f, (uint32_t)seed, (uint32_t)(seed >> 32)};
+    const size_t lds = fwd_lds_floats(F, NL) * sizeof(float);
+    const bool vec = (F % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    const int ntiles = (R + 31) / 32;
+    const int grid = ntiles < 8 * num_cus() ? (ntiles + 7) / 8 : num_cus();
+    auto launch = [&](auto kern) -> int {
+        if (int e = allow_lds(kern, lds)) return e;
+        hipLaunchKernelGGL(kern, dim3(grid > 0 ? grid : 1), dim3(512), lds, as_stream(stream), X, params, a, preds, acts);
+        return check_hip(hipGetLastError(), who);
+    };
+    if (train) return vec ? launch(mlp_fwd_kernel<2, true, true>) : launch(mlp_fwd_kernel<2, true, false>);
+    return vec ? launch(mlp_fwd_kernel<2, false, true>) : launch(mlp_fwd_kernel<2, false, false>);
+}
+
+extern "C" int ptr_mlp_backward(const float *X, const float *params, const float *acts, const float *dpreds, int R, int F, int NL,
+                                float p_drop, uint64_t seed, float *dz, float *ws, float *grad, void *stream) {
+    using namespace ptr;
+    const char *who = "ptr_mlp_backward";
+    if (int rc = check_mlp(who, R, F, NL, p_drop)) return rc;
+    if (!X || !params || !acts || !dpreds || !dz || !ws || !grad) { set_error("%s: NULL pointer", who); return PTR_ERR_INVALID_ARG; }
+    hipStream_t st = as_stream(stream);
+    MlpArgs a{R, F, NL, p_drop, (uint32_t)seed, (uint32_t)(seed >> 32)};
+    // 1. dZ chain
+    const int ncu = num_cus();
+    const int ntiles = (R + 31) / 32;
+    const int grid_dz = ntiles < 8 * ncu ? (ntiles + 7) / 8 : ncu;
+    float *part = ws + 2 * (size_t)ncu * ((size_t)kH * (F > kH ? F : kH) + kH);
+    {
+        auto kern = mlp_bwd_dz_kernel<2>;
+        const size_t lds = dz_lds_floats(NL) * sizeof(float);
+        if (int e = allow_lds(kern, lds)) return e;
+        hipLaunchKernelGGL(kern, dim3(grid_dz > 0 ? grid_dz : 1), dim3(512), lds, st, params, acts, dpreds, a, dz, part);
+        if (int e = check_hip(hipGetLastError(), who)) return e;
+    }
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, part, grid_dz > 0 ? grid_dz : 1, (size_t)(kHP + 16), (size_t)kH,
+                       grad + off_wout(NL, F));                       // d w_out
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, part + kHP, grid_dz > 0 ? grid_dz : 1, (size_t)(kHP + 16),
+                       (size_t)1, grad + off_wout(NL, F) + kH);       // d b_out
+    if (int e = check_hip(hipGetLastError(), who)) return e;
+    // 2. dW per layer
+    const int nblk = 2 * ncu;
+    for (int l = 0; l < NL; ++l) {
+        const int K = l == 0 ? F : kH;
+        const float *A = l == 0 ? X : acts + (size_t)(l - 1) * R * kH;
+        const float *dZ = dz + (size_t)l * R * kH;
+        const int ntk = (K + 15) / 16, ntw = (ntk + 3) / 4;
+        const size_t stride = (size_t)kH * K + kH;
+        auto go = [&](auto kern) -> int {
+            hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), 0, st, A, dZ, K, a, ws);
+            return check_hip(hipGetLastError(), who);
+        };
+        int e = 0;
+        if (l == 0) {
+            if (ntw <= 3) e = go(mlp_bwd_dw_kernel<3, true>);
+            else if (ntw <= 6) e = go(mlp_bwd_dw_kernel<6, true>);
+            else if (ntw <= 11) e = go(mlp_bwd_dw_kernel<11, true>);
+            else { set_error("%s: F=%d not supported by the dW kernel", who, F); return PTR_ERR_UNSUPPORTED; }
+        } else {
+            e = go(mlp_bwd_dw_kernel<2, false>);
+        }
+        if (e) return e;
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((stride + 255) / 256)), dim3(256), 0, st, ws, nblk, stride, stride,
+                           grad + off_W(l, F));
+        if (int e2 = check_hip(hipGetLastError(), who)) return e2;
+    }
+    return 0;
+}
+
+extern "C" int ptr_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int step, void *stream) {
+    using namespace ptr;
+    if (n < 0 || step < 1 || (n > 0 && (!param || !grad || !exp_avg || !exp_avg_sq))) { set_error("ptr_adam_step: bad arguments"); return PTR_ERR_INVALID_ARG; }
+    if (n == 0) return 0;
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq,
+                       (size_t)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt);
+    return check_hip(hipGetLastError(), "ptr_adam_step");
+}
+
+extern "C" int ptr_mlp_dropout_mask(int R, int n_feat, int site, float p_drop, uint64_t seed, float *out, void *stream) {
+    using namespace ptr;
+    if (R < 0 || n_feat <= 0 || !out) { set_error("ptr_mlp_dropout_mask: bad arguments"); return PTR_ERR_INVALID_ARG; }
+    MlpArgs a{R, n_feat, 1, p_drop, (uint32_t)seed, (uint32_t)(seed >> 32)};
+    const size_t n = (size_t)R * n_feat;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), a, site, n_feat, out);
+    return check_hip(hipGetLastError(), "ptr_mlp_dropout_mask");
+}

@@ -1,0 +1,192 @@
+"""The reference's pointwise MLP scorer (`pointsf`) on the fused fp32-MFMA HIP kernels.
+
+`FusedPointScorer` is a drop-in for the `nn.Sequential` that ptranking/base/utils.py:288-356 (`get_stacked_FFNet`) builds for
+the configuration AF='R', BN=False, apply_tl_af=False, h_dim=100, out_dim=1 — (Dropout -> Linear -> ReLU) x num_layers -> Linear:
+same initialisation (xavier_normal_ weights, nn.Linear's default bias init), same `state_dict` keys (`ff_2.weight`, ...), same
+call signature `scorer(X[B, L, F]) -> [B, L, 1]`-shaped scores that `PointNeuralRanker.forward` views as [B, L].
+All parameters live in ONE flat tensor (PyTorch order / layouts), which is what `FlatAdam` and the data-parallel all-reduce see.
+Dropout uses a counter-based generator inside the kernels (seeded per call from torch's CPU generator, so `torch.manual_seed`
+still makes runs reproducible); it is statistically, not bit-wise, the same as `nn.Dropout`.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+HIDDEN = 100   # ptranking/base/point_ranker.py:30
+
+
+def fusable(num_features=None, h_dim=100, out_dim=1, num_layers=3, AF='R', TL_AF='S', apply_tl_af=False, BN=True, bn_type=None,
+            bn_affine=False, dropout=0.1, **_):
+    """True when the pointsf configuration is the one the fused kernels implement."""
+    if not (AF == 'R' and not BN and not apply_tl_af and h_dim == HIDDEN and out_dim == 1 and 1 <= num_layers <= 8):
+        return False
+    lds_floats = 112 * ((num_features + 3) // 4 * 4 + 4) + (num_layers - 1) * 112 * 100 + num_layers * 112 + 112 + 16
+    return lds_floats * 4 <= 160 * 1024 and (num_features + 15) // 16 <= 12
+
+
+class _ScorerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X2d, flat, F, NL, p, seed, store):
+        R = X2d.shape[0]
+        dev = X2d.device
+        preds = torch.empty(R, device=dev, dtype=torch.float32)
+        train = bool(store or p > 0.0)
+        acts = torch.empty((NL, R, HIDDEN), device=dev, dtype=torch.float32) if train else None
+        with torch.cuda.device(dev):
+            _lib.call("ptr_mlp_forward", _lib.ptr(X2d), _lib.ptr(flat), R, F, NL, int(train), C.c_float(p), C.c_uint64(seed),
+                      _lib.ptr(preds), _lib.ptr(acts), _lib.current_stream(dev))
+        if store:
+            ctx.save_for_backward(X2d, flat, acts)
+            ctx.meta = (R, F, NL, p, seed)
+        return preds
+
+    @staticmethod
+    def backward(ctx, dpreds):
+        X2d, flat, acts = ctx.saved_tensors
+        R, F, NL, p, seed = ctx.meta
+        dev = X2d.device
+        dpreds = dpreds.contiguous()
+        dz = torch.empty((NL, R, HIDDEN), device=dev, dtype=torch.float32)
+        ws = torch.empty(_lib.query("ptr_mlp_backward_ws_floats", F, NL), device=dev, dtype=torch.float32)
+        grad = torch.empty_like(flat)
+        with torch.cuda.device(dev):
+            _lib.call("ptr_mlp_backward", _lib.ptr(X2d), _lib.ptr(flat), _lib.ptr(acts), _lib.ptr(dpreds), R, F, NL, C.c_float(p),
+                      C.c_uint64(seed), _lib.ptr(dz), _lib.ptr(ws), _lib.ptr(grad), _lib.current_stream(dev))
+        return None, grad, None, None, None, None, None
+
+
+class FusedPointScorer(nn.Module):
+    def __init__(self, num_features, num_layers=3, dropout=0.1):
+        super().__init__()
+        self.num_features, self.num_layers, self.dropout = int(num_features), int(num_layers), float(dropout)
+        n = 100 * self.num_features + 100 + (self.num_layers - 1) * (100 * 100 + 100) + 100 + 1
+        self.flat = nn.Parameter(torch.empty(n, dtype=torch.float32))
+        self.reset_parameters()
+
+    # ---- parameter views, named like the reference's Sequential (base/utils.py:299-322)
+    def layout(self):
+        """[(state_dict key, offset, shape)] in flat order."""
+        F, NL = self.num_features, self.num_layers
+        out, off = [], 0
+        for l in range(NL):
+            k = F if l == 0 else HIDDEN
+            out.append((f"ff_{l + 2}.weight", off, (HIDDEN, k))); off += HIDDEN * k
+            out.append((f"ff_{l + 2}.bias", off, (HIDDEN,))); off += HIDDEN
+        out.append((f"ff_{NL + 2}.weight", off, (1, HIDDEN))); off += HIDDEN
+        out.append((f"ff_{NL + 2}.bias", off, (1,))); off += 1
+        assert off == self.flat.numel()
+        return out
+
+    def views(self, grad=False):
+        src = self.flat.grad if grad else self.flat.data
+        return {k: src[o:o + math.prod(s)].view(s) for k, o, s in self.layout()}
+
+    def reset_parameters(self):
+        with torch.no_grad():
+            for k, v in self.views().items():
+                if k.endswith("weight"):
+                    nn.init.xavier_normal_(v)                      # nr_init, base/utils.py:13,303,321
+                else:
+                    fan_in = self.num_features if k == "ff_2.bias" else HIDDEN
+                    bound = 1.0 / math.sqrt(fan_in)                # nn.Linear's default bias init
+                    nn.init.uniform_(v, -bound, bound)
+
+    # ---- checkpoints interchangeable with the reference's state_dict (point_ranker.py:63-71)
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        for k, v in self.views().items():
+            destination[prefix + k] = v if keep_vars else v.detach().clone()
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        with torch.no_grad():
+            for k, v in self.views().items():
+                key = prefix + k
+                if key in state_dict:
+                    v.copy_(state_dict[key].reshape(v.shape))
+                elif strict:
+                    missing_keys.append(key)
+        known = {prefix + k for k, _, _ in self.layout()}
+        for key in state_dict:
+            if key.startswith(prefix) and key not in known and strict:
+                unexpected_keys.append(key)
+
+    def forward(self, X):
+        if not X.is_cuda:
+            raise RuntimeError(f"FusedPointScorer input is on {X.device}: the fused scorer runs on the MI355X HIP path only")
+        lead = X.shape[:-1]
+        if X.shape[-1] != self.num_features:
+            raise ValueError(f"expected {self.num_features} features, got {X.shape[-1]}")
+        X2d = X.reshape(-1, self.num_features)
+        if X2d.dtype != torch.float32:
+            X2d = X2d.float()
+        X2d = X2d.contiguous()
+        p = self.dropout if self.training else 0.0
+        store = torch.is_grad_enabled() and self.flat.requires_grad
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0     # CPU generator: no device sync
+        preds = _ScorerFn.apply(X2d, self.flat, self.num_features, self.num_layers, p, seed, store)
+        return preds.view(*lead, 1)
+
+    def dropout_mask(self, R, site, seed):
+        """Keep-mask [R, n_feat] of dropout site `site` (0 = on the input features) for the given call seed — test helper."""
+        n_feat = self.num_features if site == 0 else HIDDEN
+        out = torch.empty((R, n_feat), device=self.flat.device, dtype=torch.float32)
+        _lib.call("ptr_mlp_dropout_mask", R, n_feat, site, C.c_float(self.dropout), C.c_uint64(seed), _lib.ptr(out),
+                  _lib.current_stream(out.device))
+        return out
+
+
+class FlatAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (L2 weight decay folded into the gradient, bias correction) as ONE kernel per flat
+    parameter tensor — the update the reference configures in ptranking/base/ranker.py:516-517."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()):
+                    raise RuntimeError("FlatAdam needs contiguous CUDA float32 parameters / gradients")
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                st["step"] += 1
+                with torch.cuda.device(p.device):
+                    _lib.call("ptr_adam_step", _lib.ptr(p), _lib.ptr(p.grad), _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]),
+                              C.c_int64(p.numel()), C.c_float(group["lr"]), C.c_float(b1), C.c_float(b2), C.c_float(group["eps"]),
+                              C.c_float(group["weight_decay"]), int(st["step"]), _lib.current_stream(p.device))
+        return loss
+
+
+class FusedScorerMixin:
+    """Makes a ranker build the fused scorer + FlatAdam whenever its pointsf configuration allows it (otherwise the base
+    class's own torch modules are used).  Set `use_fused_scorer = False` on the class or instance to opt out."""
+
+    use_fused_scorer = True
+
+    def ini_pointsf(self, **kw):
+        on_gpu = bool(getattr(self, "gpu", False)) and torch.cuda.is_available()
+        if self.use_fused_scorer and on_gpu and fusable(**kw):
+            return FusedPointScorer(kw["num_features"], num_layers=kw.get("num_layers", 3), dropout=kw.get("dropout", 0.1))
+        return super().ini_pointsf(**kw)
+
+    def config_optimizer(self):
+        sf = getattr(self, "point_sf", None)
+        if isinstance(sf, FusedPointScorer) and self.opt == 'Adam':
+            self.optimizer = FlatAdam(self.get_parameters(), lr=self.lr, weight_decay=self.weight_decay)
+            self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=20, gamma=0.5)   # ranker.py:525
+        else:
+            super().config_optimizer()

@@ -50,7 +50,8 @@ def test_train_op_matches_cpu_reference_step(name, paras, oracle_fn, okw):
     ranker = _make(name, paras)
     ranker.init()
     ranker.train_mode()
-    cpu_net = copy.deepcopy(ranker.point_sf).cpu()
+    cpu_net = T.build_pointsf(24, dropout=0.0)                       # the torch-CPU restatement of the scorer ...
+    cpu_net.load_state_dict({k: v.cpu() for k, v in ranker.point_sf.state_dict().items()})   # ... with the ranker's weights
     cpu_opt = torch.optim.Adam(cpu_net.parameters(), lr=1e-3, weight_decay=1e-3)
     X, Y = make_data(5, 6, 40, 24)
     for step in range(3):
@@ -58,7 +59,7 @@ def test_train_op_matches_cpu_reference_step(name, paras, oracle_fn, okw):
         ref = T.cpu_train_step(cpu_net, cpu_opt, X, Y, getattr(T, oracle_fn), **okw)
         assert stop is False
         G.assert_close(loss.item(), ref, f"{name} loss step {step}")
-    for (n1, p1), (n2, p2) in zip(ranker.point_sf.named_parameters(), cpu_net.named_parameters()):
+    for (n1, p1), (n2, p2) in zip(ranker.point_sf.state_dict().items(), cpu_net.named_parameters()):
         assert n1 == n2
         if n1 == "ff_5.bias":
             continue   # every in-scope loss is shift-invariant: this gradient is identically 0 and Adam turns its rounding
@@ -153,3 +154,6 @@ def test_device_evaluator_matches_cpu_metric_loop(tmp_path):
     other.load(str(tmp_path) + "/net.pkl", device="cuda:0")
     for a, b in zip(ranker.point_sf.parameters(), other.point_sf.parameters()):
         assert torch.equal(a, b)
+    # a checkpoint written by the fused scorer loads into the plain torch module (reference key names)
+    plain = T.build_pointsf(24, dropout=0.0)
+    plain.load_state_dict(torch.load(str(tmp_path) + "/net.pkl", map_location="cpu"))

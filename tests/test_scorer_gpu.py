@@ -1,0 +1,162 @@
+"""GPU: the fused fp32-MFMA pointsf scorer (forward / backward / FlatAdam) against plain PyTorch fp32 modules built the way
+the reference builds them (ptranking/base/utils.py:288-356), with identical weights and — in training mode — the identical
+dropout masks exported from the kernel's counter-based generator."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def torch_scorer(F, NL):
+    from ptranking_amd.host import build_pointsf
+    return build_pointsf(num_features=F, num_layers=NL, AF="R", BN=False, apply_tl_af=False, dropout=0.0).cuda()
+
+
+def make_pair(F, NL, dropout=0.1, seed=0):
+    from ptranking_amd.scorer import FusedPointScorer
+    torch.manual_seed(seed)
+    fused = FusedPointScorer(F, num_layers=NL, dropout=dropout).cuda()
+    ref = torch_scorer(F, NL)
+    ref.load_state_dict(fused.state_dict())          # reference-named keys: ff_2.weight ... ff_{NL+2}.bias
+    return fused, ref
+
+
+def close(a, b, tol=2e-5):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, f"max|diff|={err:.3e} > {tol * scale:.3e}"
+
+
+@pytest.mark.parametrize("F,NL", [(136, 3), (24, 3), (46, 2), (8, 1), (24, 4), (180, 2)])
+@pytest.mark.parametrize("shape", [(5, 7), (64, 128), (3, 341)])
+def test_eval_forward_matches_torch(F, NL, shape):
+    fused, ref = make_pair(F, NL)
+    fused.eval(); ref.eval()
+    X = torch.randn(*shape, F, device="cuda")
+    with torch.no_grad():
+        out = fused(X)
+        exp = ref(X)
+    assert out.shape == exp.shape == (*shape, 1)
+    close(out, exp)
+
+
+def _train_reference(ref, fused, X2d, seed, p, NL):
+    """Re-run the forward in torch with the kernel's own dropout masks."""
+    R = X2d.shape[0]
+    lin = [m for m in ref if isinstance(m, torch.nn.Linear)]
+    a = X2d * fused.dropout_mask(R, 0, seed) / (1 - p)
+    for l in range(NL):
+        h = torch.relu(lin[l](a))
+        a = h * fused.dropout_mask(R, l + 1, seed) / (1 - p) if l < NL - 1 else h
+    return lin[NL](a)
+
+
+@pytest.mark.parametrize("F,NL,R", [(136, 3, 2048 + 37), (24, 2, 100), (46, 3, 515), (136, 1, 64), (40, 4, 1000), (180, 2, 300)])
+def test_train_forward_backward_match_torch_with_same_masks(F, NL, R, monkeypatch):
+    p = 0.1
+    fused, ref = make_pair(F, NL, dropout=p)
+    fused.train()
+    X = torch.randn(R, F, device="cuda")
+    seed = 123456789 + R
+    monkeypatch.setattr(torch, "randint", lambda *a, **k: torch.tensor([seed]))
+    out = fused(X)
+    monkeypatch.undo()
+    exp = _train_reference(ref, fused, X, seed, p, NL)
+    close(out, exp)
+    w = torch.randn(R, 1, device="cuda")
+    (out * w).sum().backward()
+    (exp * w).sum().backward()
+    got = fused.views(grad=True)
+    for name, prm in ref.named_parameters():
+        close(got[name], prm.grad, tol=5e-5)
+
+
+def test_gradients_without_dropout_and_in_eval_mode():
+    fused, ref = make_pair(136, 3, dropout=0.0)
+    fused.train(); ref.train()
+    X = torch.randn(777, 136, device="cuda")
+    w = torch.randn(777, 1, device="cuda")
+    (fused(X) * w).sum().backward()
+    (ref(X) * w).sum().backward()
+    got = fused.views(grad=True)
+    for name, prm in ref.named_parameters():
+        close(got[name], prm.grad, tol=5e-5)
+
+
+def test_dropout_generator_statistics():
+    from ptranking_amd.scorer import FusedPointScorer
+    f = FusedPointScorer(136, 3, dropout=0.1).cuda()
+    m0 = f.dropout_mask(4096, 0, 42)
+    m1 = f.dropout_mask(4096, 1, 42)
+    m0b = f.dropout_mask(4096, 0, 43)
+    assert abs(m0.mean().item() - 0.9) < 2e-3 and abs(m1.mean().item() - 0.9) < 2e-3
+    assert abs((m0[:, :100] * m1).mean().item() - 0.81) < 3e-3          # sites are independent
+    assert abs((m0 * m0b).mean().item() - 0.81) < 3e-3                  # seeds are independent
+    assert (m0.mean(dim=0) - 0.9).abs().max() < 0.03 and (m0.mean(dim=1) - 0.9).abs().max() < 0.12
+    assert torch.equal(m0, f.dropout_mask(4096, 0, 42))                 # counter-based: reproducible
+    X = torch.randn(64, 136, device="cuda")
+    f.eval()
+    with torch.no_grad():
+        a, b = f(X), f(X)
+    assert torch.equal(a, b)                                            # eval: no dropout
+    f.train()
+    with torch.no_grad():
+        c = f(X)
+    assert not torch.equal(a, c)                                        # train: dropout active
+
+
+def test_flat_adam_matches_torch_adam():
+    from ptranking_amd.scorer import FlatAdam
+    torch.manual_seed(3)
+    p1 = torch.nn.Parameter(torch.randn(34001, device="cuda"))
+    p2 = torch.nn.Parameter(p1.detach().clone())
+    o1 = FlatAdam([p1], lr=1e-3, weight_decay=1e-3)
+    o2 = torch.optim.Adam([p2], lr=1e-3, weight_decay=1e-3)
+    s1 = torch.optim.lr_scheduler.StepLR(o1, step_size=2, gamma=0.5)
+    s2 = torch.optim.lr_scheduler.StepLR(o2, step_size=2, gamma=0.5)
+    for it in range(6):
+        g = torch.randn(34001, device="cuda") * (10.0 ** (it - 3))
+        p1.grad, p2.grad = g.clone(), g.clone()
+        o1.step(); o2.step(); s1.step(); s2.step()
+        assert torch.allclose(p1, p2, rtol=1e-5, atol=1e-7), it
+    assert o1.param_groups[0]["lr"] == o2.param_groups[0]["lr"]
+
+
+def test_state_dict_is_interchangeable_with_the_reference_layout(tmp_path):
+    fused, ref = make_pair(136, 3)
+    sd = fused.state_dict()
+    assert list(sd) == ["ff_2.weight", "ff_2.bias", "ff_3.weight", "ff_3.bias", "ff_4.weight", "ff_4.bias", "ff_5.weight", "ff_5.bias"]
+    assert sd["ff_2.weight"].shape == (100, 136) and sd["ff_5.weight"].shape == (1, 100)
+    torch.save(ref.state_dict(), tmp_path / "net.pkl")          # a checkpoint written by the torch / reference module
+    from ptranking_amd.scorer import FusedPointScorer
+    other = FusedPointScorer(136, 3).cuda()
+    other.load_state_dict(torch.load(tmp_path / "net.pkl", map_location="cuda:0"))
+    assert torch.equal(other.flat, fused.flat)
+    assert sum(p.numel() for p in other.parameters()) == 34001
+    w = sd["ff_3.weight"]                                       # xavier-normal: std = sqrt(2 / (fan_in + fan_out))
+    assert abs(w.std().item() - (2.0 / 200) ** 0.5) < 0.01
+
+
+def test_ranker_uses_the_fused_scorer_and_falls_back_for_other_configs():
+    import ptranking_amd as pa
+    from ptranking_amd.scorer import FusedPointScorer, FlatAdam
+    sf = {"sf_id": "pointsf", "opt": "Adam", "lr": 1e-3,
+          "pointsf": dict(num_features=136, num_layers=3, AF="R", TL_AF="S", apply_tl_af=False, BN=False, bn_type=None, bn_affine=False)}
+    r = pa.LambdaRank(sf_para_dict=sf, model_para_dict={"sigma": 1.0}, gpu=True, device="cuda:0")
+    r.init()
+    assert isinstance(r.point_sf, FusedPointScorer) and isinstance(r.optimizer, FlatAdam)
+    X = torch.randn(8, 32, 136, device="cuda")
+    Y = torch.sort(torch.randint(0, 5, (8, 32), device="cuda").float(), dim=1, descending=True)[0]
+    Y[:, 0] = 2.0
+    r.train_mode()
+    before = r.point_sf.flat.detach().clone()
+    loss, stop = r.train_op(X, Y, epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
+    assert torch.isfinite(loss) and not torch.equal(before, r.point_sf.flat)
+    sf2 = {"sf_id": "pointsf", "opt": "Adam", "lr": 1e-3,
+           "pointsf": dict(num_features=136, num_layers=3, AF="GE", TL_AF="S", apply_tl_af=False, BN=False, bn_type=None, bn_affine=False)}
+    r2 = pa.LambdaRank(sf_para_dict=sf2, model_para_dict={"sigma": 1.0}, gpu=True, device="cuda:0")
+    r2.init()
+    assert isinstance(r2.point_sf, torch.nn.Sequential) and isinstance(r2.optimizer, torch.optim.Adam)
+    loss2, _ = r2.train_op(X, Y, epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
+    assert torch.isfinite(loss2)
