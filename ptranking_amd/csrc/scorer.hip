@@ -50,11 +50,13 @@ __device__ __forceinline__ void drop_bits(uint32_t seed_lo, uint32_t seed_hi, in
     w1 = lowbias32(w0 ^ seed_hi ^ 0x68E31DA4u);
 }
 __device__ __forceinline__ f32x4 drop4(f32x4 v, uint32_t w0, uint32_t w1, uint32_t thr, float scale) {
+    // multiplicative masks on purpose: with a select hipcc sinks the producing global load under the predicate and
+    // serialises it behind a vmcnt(0); x * 0.0f cannot be folded without fast-math, so the load stays unconditional
     f32x4 o;
-    o[0] = (w0 & 0xFFFFu) >= thr ? v[0] * scale : 0.0f;
-    o[1] = (w0 >> 16) >= thr ? v[1] * scale : 0.0f;
-    o[2] = (w1 & 0xFFFFu) >= thr ? v[2] * scale : 0.0f;
-    o[3] = (w1 >> 16) >= thr ? v[3] * scale : 0.0f;
+    o[0] = v[0] * ((w0 & 0xFFFFu) >= thr ? scale : 0.0f);
+    o[1] = v[1] * ((w0 >> 16) >= thr ? scale : 0.0f);
+    o[2] = v[2] * ((w1 & 0xFFFFu) >= thr ? scale : 0.0f);
+    o[3] = v[3] * ((w1 >> 16) >= thr ? scale : 0.0f);
     return o;
 }
 __device__ __forceinline__ bool drop_keep1(uint32_t seed_lo, uint32_t seed_hi, int site, int row, int k, uint32_t thr) {
@@ -125,23 +127,36 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) row[rt] = row0 + 16 * rt + j;
 
+        // X loads are branch-free: out-of-range rows / columns read a clamped (valid) address and are zeroed by a select
+        const float *xrow[RT];
+        bool rok[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            rok[rt] = row[rt] < R;
+            xrow[rt] = X + (size_t)(rok[rt] ? row[rt] : R - 1) * F;
+        }
         auto load_x = [&](int S, f32x4 (&xb)[RT]) {
             const int k0 = 16 * S + 4 * g;
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (row[rt] < R) {
-                    const float *src = X + (size_t)row[rt] * F + k0;
-                    if constexpr (VEC) { if (k0 < F) v = *reinterpret_cast<const f32x4 *>(src); }
-                    else {
+                f32x4 v;
+                if constexpr (VEC) {
+                    const bool kok = k0 < F;
+                    v = *reinterpret_cast<const f32x4 *>(xrow[rt] + (kok ? k0 : 0));
+                    const float okf = (kok && rok[rt]) ? 1.0f : 0.0f;
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) if (k0 + c < F) v[c] = src[c];
+                    for (int c = 0; c < 4; ++c) v[c] *= okf;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float okf = ((k0 + c < F) && rok[rt]) ? 1.0f : 0.0f;
+                        v[c] = xrow[rt][k0 + c < F ? k0 + c : 0] * okf;
                     }
-                    if constexpr (TRAIN) {
-                        uint32_t w0, w1;
-                        drop_bits(a.seed_lo, a.seed_hi, 0, row[rt], k0 >> 2, w0, w1);
-                        v = drop4(v, w0, w1, thr, scale);
-                    }
+                }
+                if constexpr (TRAIN) {
+                    uint32_t w0, w1;
+                    drop_bits(a.seed_lo, a.seed_hi, 0, row[rt], k0 >> 2, w0, w1);
+                    v = drop4(v, w0, w1, thr, scale);
                 }
                 xb[rt] = v;
             }
@@ -246,11 +261,11 @@ __host__ __device__ inline size_t dz_lds_floats(int NL) { return (size_t)(NL - 1
 
 // dz[l] (l = 0..NL-1) = dLoss/d(pre-activation of hidden layer l+1), [NL][R][100].  acts[l] = post-dropout input of hidden
 // layer l+2 (l < NL-1) / last hidden activation (l = NL-1), as the forward kernel stored them.
-// part_out[block][kHP + 16]: per-block partial of d w_out (100) and d b_out (index kHP).
+// ws[block][wout_off ..]: per-block partial of d w_out (100) and d b_out, in the flat parameter layout.
 template <int RT>
 __global__ void __launch_bounds__(512)
 mlp_bwd_dz_kernel(const float *__restrict__ P, const float *__restrict__ acts, const float *__restrict__ dpreds, MlpArgs a,
-                  float *__restrict__ dz, float *__restrict__ part_out) {
+                  float *__restrict__ dz, float *__restrict__ ws, size_t np_stride, size_t wout_off) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int F = a.F, NL = a.NL, R = a.R;
     float *WT = smem;
@@ -290,13 +305,15 @@ mlp_bwd_dz_kernel(const float *__restrict__ P, const float *__restrict__ acts, c
             const f32x4 w4 = *reinterpret_cast<const f32x4 *>(Wo + 16 * mt + 4 * g);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                f32x4 h = {0.f, 0.f, 0.f, 0.f};
                 const bool ok = row[rt] < R && (mt < kMT - 1 || g == 0);
                 const size_t o = ((size_t)(NL - 1) * R + row[rt]) * kH + 16 * mt + 4 * g;
-                if (ok) h = *reinterpret_cast<const f32x4 *>(acts + o);
+                f32x4 h = *reinterpret_cast<const f32x4 *>(acts + (ok ? o : 0));      // clamped address, zeroed below
+                const float okf = ok ? 1.0f : 0.0f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) h[c] *= okf;
                 f32x4 d;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { d[c] = h[c] > 0.0f ? ds[rt] * w4[c] : 0.0f; dwo[mt][c] = fmaf(h[c], ds[rt], dwo[mt][c]); }
+                for (int c = 0; c < 4; ++c) { d[c] = (ds[rt] * w4[c]) * (h[c] > 0.0f ? 1.0f : 0.0f); dwo[mt][c] = fmaf(h[c], ds[rt], dwo[mt][c]); }
                 if (ok) *reinterpret_cast<f32x4 *>(dz + o) = d;
                 cur[mt][rt] = d;
             }
@@ -325,13 +342,12 @@ mlp_bwd_dz_kernel(const float *__restrict__ P, const float *__restrict__ acts, c
             for (int mt = 0; mt < kMT; ++mt)
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
-                    f32x4 av = {0.f, 0.f, 0.f, 0.f};
                     const bool ok = row[rt] < R && (mt < kMT - 1 || g == 0);
                     const size_t o = ((size_t)(l - 1) * R + row[rt]) * kH + 16 * mt + 4 * g;
-                    if (ok) av = *reinterpret_cast<const f32x4 *>(acts + o);
+                    const f32x4 av = *reinterpret_cast<const f32x4 *>(acts + (ok ? o : 0));
                     f32x4 d;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) d[c] = av[c] > 0.0f ? acc[mt][rt][c] * inv_keep : 0.0f;
+                    for (int c = 0; c < 4; ++c) d[c] = acc[mt][rt][c] * ((ok && av[c] > 0.0f) ? inv_keep : 0.0f);
                     if (ok) *reinterpret_cast<f32x4 *>(dz + o) = d;
                     cur[mt][rt] = d;
                 }
@@ -352,10 +368,11 @@ mlp_bwd_dz_kernel(const float *__restrict__ P, const float *__restrict__ acts, c
         if (lane == 0) wrow[(size_t)wave * (kHP + 16) + kHP] = v;
     }
     __syncthreads();
-    for (int i = tid; i < kHP + 1; i += nthr) {
+    for (int i = tid; i < kH + 1; i += nthr) {
+        const int src = i < kH ? i : kHP;                      // d b_out sits behind the padded d w_out row
         float s = 0.0f;
-        for (int w = 0; w < wpb; ++w) s += wrow[(size_t)w * (kHP + 16) + i];
-        part_out[(size_t)blockIdx.x * (kHP + 16) + i] = s;
+        for (int w = 0; w < wpb; ++w) s += wrow[(size_t)w * (kHP + 16) + src];
+        ws[(size_t)blockIdx.x * np_stride + wout_off + i] = s;
     }
 }
 
@@ -363,10 +380,11 @@ mlp_bwd_dz_kernel(const float *__restrict__ P, const float *__restrict__ acts, c
 // One launch per layer.  dW[out][in] = sum_rows dZ[row][out] * A[row][in];  db[out] = sum_rows dZ[row][out].
 // A = X with the input dropout recomputed (layer 0, SITE0) or the stored activation (other layers).  Each wave owns the
 // in-feature tiles nt = wave, wave + 4, ... and all 7 out-feature tiles; a block walks its contiguous chunk of rows 4 at a time.
-// ws[block][100*K + 100]: per-block partial (dW then db), reduced by reduce_partials_kernel.
+// ws[block][n_params]: per-block partial gradient in the flat parameter layout, reduced by reduce_partials_kernel.
 template <int NTW, bool SITE0>
 __global__ void __launch_bounds__(256)
-mlp_bwd_dw_kernel(const float *__restrict__ A, const float *__restrict__ dZ, int K, MlpArgs a, float *__restrict__ ws) {
+mlp_bwd_dw_kernel(const float *__restrict__ A, const float *__restrict__ dZ, int K, MlpArgs a, float *__restrict__ ws,
+                  size_t np_stride, size_t w_off, size_t b_off) {
     const int R = a.R;
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6;
     const int chunk = ((R + gridDim.x - 1) / gridDim.x + 15) & ~15;
@@ -374,6 +392,7 @@ mlp_bwd_dw_kernel(const float *__restrict__ A, const float *__restrict__ dZ, int
     const uint32_t thr = drop_thr(a.p_drop);
     const float scale = (SITE0 && a.p_drop > 0.0f) ? 1.0f / (1.0f - a.p_drop) : 1.0f;
     const int ntk = (K + 15) >> 4;
+    (void)ntk;
 
     f32x4 acc[NTW][kMT];
 #pragma unroll
@@ -385,31 +404,34 @@ mlp_bwd_dw_kernel(const float *__restrict__ A, const float *__restrict__ dZ, int
     for (int mt = 0; mt < kMT; ++mt) dbv[mt] = 0.0f;
 
     constexpr int U = 4;                                   // k-steps (of 4 rows) per iteration
+    // Per-lane column offsets / validity are loop invariant; loads are branch-free (clamped column, select-to-zero).
+    int fa[kMT], kb[NTW];
+    bool fa_ok[kMT], kb_ok[NTW];
+#pragma unroll
+    for (int mt = 0; mt < kMT; ++mt) { const int f = 16 * mt + j; fa_ok[mt] = f < kH; fa[mt] = fa_ok[mt] ? f : 0; }
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) { const int k = 16 * (wave + 4 * t) + j; kb_ok[t] = k < K; kb[t] = kb_ok[t] ? k : 0; }
     float av[U][kMT], bv[U][NTW], avn[U][kMT], bvn[U][NTW];
-    auto load = [&](int r0, float (&pa)[U][kMT], float (&pb)[U][NTW]) {
+    auto load = [&](int r0, bool guard, float (&pa)[U][kMT], float (&pb)[U][NTW]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int r = r0 + 4 * u + g;
-            const bool rok = r < r_end;
+            const bool rok = !guard || r < r_end;
+            const int rc = rok ? r : r_end - 1;
+            const float *dzr = dZ + (size_t)rc * kH;
+            const float *ar = A + (size_t)rc * K;
 #pragma unroll
-            for (int mt = 0; mt < kMT; ++mt) {
-                const int f = 16 * mt + j;
-                pa[u][mt] = (rok && f < kH) ? dZ[(size_t)r * kH + f] : 0.0f;
-            }
+            for (int mt = 0; mt < kMT; ++mt) pa[u][mt] = dzr[fa[mt]] * ((rok & fa_ok[mt]) ? 1.0f : 0.0f);
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
-                const int nt = wave + 4 * t, k = 16 * nt + j;
-                float v = (rok && nt < ntk && k < K) ? A[(size_t)r * K + k] : 0.0f;
-                if constexpr (SITE0) {
-                    if (a.p_drop > 0.0f) v = drop_keep1(a.seed_lo, a.seed_hi, 0, r, k, thr) ? v * scale : 0.0f;
-                }
-                pb[u][t] = v;
+                float v = ar[kb[t]];
+                bool keep = rok & kb_ok[t];
+                if constexpr (SITE0) keep = keep & drop_keep1(a.seed_lo, a.seed_hi, 0, rc, kb[t], thr);   // thr == 0 keeps all
+                pb[u][t] = v * (keep ? scale : 0.0f);
             }
         }
     };
-    if (r_begin < r_end) load(r_begin, av, bv);
-    for (int r0 = r_begin; r0 < r_end; r0 += 4 * U) {
-        if (r0 + 4 * U < r_end) load(r0 + 4 * U, avn, bvn);
+    auto mma = [&]() {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -420,15 +442,26 @@ mlp_bwd_dw_kernel(const float *__restrict__ A, const float *__restrict__ dZ, int
                 for (int mt = 0; mt < kMT; ++mt)
                     acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][mt], bv[u][t], acc[t][mt], 0, 0, 0);
         }
+    };
+    const int n_full = r_end > r_begin ? (r_end - r_begin) / (4 * U) : 0;     // iterations with every row valid
+    int r0 = r_begin;
+    if (n_full > 0) {
+        load(r0, false, av, bv);
+        for (int it = 0; it < n_full; ++it, r0 += 4 * U) {
+            if (it + 1 < n_full) load(r0 + 4 * U, false, avn, bvn);
+            mma();
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+            for (int u = 0; u < U; ++u) {
 #pragma unroll
-            for (int mt = 0; mt < kMT; ++mt) av[u][mt] = avn[u][mt];
+                for (int mt = 0; mt < kMT; ++mt) av[u][mt] = avn[u][mt];
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) bv[u][t] = bvn[u][t];
+                for (int t = 0; t < NTW; ++t) bv[u][t] = bvn[u][t];
+            }
         }
     }
-    float *out = ws + (size_t)blockIdx.x * ((size_t)kH * K + kH);
+    if (r0 < r_end) { load(r0, true, av, bv); mma(); }               // guarded tail (< 16 rows)
+    float *out = ws + (size_t)blockIdx.x * np_stride + w_off;
+    float *outb = ws + (size_t)blockIdx.x * np_stride + b_off;
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
         const int nt = wave + 4 * t, k = 16 * nt + j;
@@ -447,19 +480,40 @@ mlp_bwd_dw_kernel(const float *__restrict__ A, const float *__restrict__ dZ, int
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
             const int f = 16 * mt + j;
-            if (g == 0 && f < kH) out[(size_t)kH * K + f] = v;
+            if (g == 0 && f < kH) outb[f] = v;
         }
     }
 }
 
-// grad[i] = sum_b ws[b][i] in block order (deterministic).
-__global__ void __launch_bounds__(256)
-reduce_partials_kernel(const float *__restrict__ ws, int nblk, size_t stride, size_t n, float *__restrict__ grad) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.0f;
-    for (int b = 0; b < nblk; ++b) s += ws[(size_t)b * stride + i];
-    grad[i] = s;
+// grad[i] = sum_b ws[b][i], fixed order.  A 1024-thread workgroup owns 64 consecutive i: wave w sums the partials
+// b = w, w+16, ... (4 independent accumulators keep 4 loads in flight), then one wave adds the 16 wave totals in order.
+// Entries i >= tail_begin (d w_out, d b_out: written by the dZ kernel's smaller grid) only have nblk_tail partials.
+__global__ void __launch_bounds__(1024)
+reduce_partials_kernel(const float *__restrict__ ws, int nblk, int nblk_tail, size_t tail_begin, size_t stride, size_t n,
+                       float *__restrict__ grad) {
+    __shared__ float part[16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + lane;
+    const bool ok = i < n;
+    const size_t ic = ok ? i : n - 1;
+    const int nb = ic >= tail_begin ? nblk_tail : nblk;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = w;
+    for (; b + 48 < nb; b += 64) {
+        s0 += ws[(size_t)b * stride + ic];
+        s1 += ws[(size_t)(b + 16) * stride + ic];
+        s2 += ws[(size_t)(b + 32) * stride + ic];
+        s3 += ws[(size_t)(b + 48) * stride + ic];
+    }
+    for (; b < nb; b += 16) s0 += ws[(size_t)b * stride + ic];
+    part[w][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (w == 0 && ok) {
+        float s = part[0][lane];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) s += part[k][lane];
+        grad[i] = s;
+    }
 }
 
 // =================================================================================================== Adam (torch.optim.Adam semantics)
@@ -515,9 +569,7 @@ extern "C" size_t ptr_mlp_num_params(int F, int NL) { return ptr::n_params(NL, F
 
 // floats of workspace ptr_mlp_backward needs
 extern "C" size_t ptr_mlp_backward_ws_floats(int F, int NL) {
-    const size_t nblk = 2 * (size_t)ptr::num_cus();
-    const size_t kmax = (size_t)(F > ptr::kH ? F : ptr::kH);
-    return nblk * (ptr::kH * kmax + ptr::kH) + (size_t)ptr::num_cus() * (ptr::kHP + 16) + 64;
+    return 2 * (size_t)ptr::num_cus() * ptr::n_params(NL, F);
 }
 
 extern "C" int ptr_mlp_forward(const float *X, const float *params, int R, int F, int NL, int train, float p_drop, uint64_t seed,
@@ -549,50 +601,44 @@ extern "C" int ptr_mlp_backward(const float *X, const float *params, const float
     if (!X || !params || !acts || !dpreds || !dz || !ws || !grad) { set_error("%s: NULL pointer", who); return PTR_ERR_INVALID_ARG; }
     hipStream_t st = as_stream(stream);
     MlpArgs a{R, F, NL, p_drop, (uint32_t)seed, (uint32_t)(seed >> 32)};
-    // 1. dZ chain
+    // 1. dZ chain (+ partial d w_out / d b_out)
     const int ncu = num_cus();
+    const int nblk = 2 * ncu;
+    const size_t NP = n_params(NL, F);
     const int ntiles = (R + 31) / 32;
-    const int grid_dz = ntiles < 8 * ncu ? (ntiles + 7) / 8 : ncu;
-    float *part = ws + 2 * (size_t)ncu * ((size_t)kH * (F > kH ? F : kH) + kH);
+    int grid_dz = ntiles < 8 * ncu ? (ntiles + 7) / 8 : ncu;
+    if (grid_dz < 1) grid_dz = 1;
     {
         auto kern = mlp_bwd_dz_kernel<2>;
         const size_t lds = dz_lds_floats(NL) * sizeof(float);
         if (int e = allow_lds(kern, lds)) return e;
-        hipLaunchKernelGGL(kern, dim3(grid_dz > 0 ? grid_dz : 1), dim3(512), lds, st, params, acts, dpreds, a, dz, part);
+        hipLaunchKernelGGL(kern, dim3(grid_dz), dim3(512), lds, st, params, acts, dpreds, a, dz, ws, NP, off_wout(NL, F));
         if (int e = check_hip(hipGetLastError(), who)) return e;
     }
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, part, grid_dz > 0 ? grid_dz : 1, (size_t)(kHP + 16), (size_t)kH,
-                       grad + off_wout(NL, F));                       // d w_out
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, part + kHP, grid_dz > 0 ? grid_dz : 1, (size_t)(kHP + 16),
-                       (size_t)1, grad + off_wout(NL, F) + kH);       // d b_out
-    if (int e = check_hip(hipGetLastError(), who)) return e;
-    // 2. dW per layer
-    const int nblk = 2 * ncu;
+    // 2. dW per layer (row contraction), every block writes its partial into ws[block][flat parameter layout]
     for (int l = 0; l < NL; ++l) {
         const int K = l == 0 ? F : kH;
         const float *A = l == 0 ? X : acts + (size_t)(l - 1) * R * kH;
         const float *dZ = dz + (size_t)l * R * kH;
         const int ntk = (K + 15) / 16, ntw = (ntk + 3) / 4;
-        const size_t stride = (size_t)kH * K + kH;
         auto go = [&](auto kern) -> int {
-            hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), 0, st, A, dZ, K, a, ws);
+            hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), 0, st, A, dZ, K, a, ws, NP, off_W(l, F), off_b(l, F));
             return check_hip(hipGetLastError(), who);
         };
         int e = 0;
         if (l == 0) {
             if (ntw <= 3) e = go(mlp_bwd_dw_kernel<3, true>);
             else if (ntw <= 6) e = go(mlp_bwd_dw_kernel<6, true>);
-            else if (ntw <= 11) e = go(mlp_bwd_dw_kernel<11, true>);
             else { set_error("%s: F=%d not supported by the dW kernel", who, F); return PTR_ERR_UNSUPPORTED; }
         } else {
             e = go(mlp_bwd_dw_kernel<2, false>);
         }
         if (e) return e;
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((stride + 255) / 256)), dim3(256), 0, st, ws, nblk, stride, stride,
-                           grad + off_W(l, F));
-        if (int e2 = check_hip(hipGetLastError(), who)) return e2;
     }
-    return 0;
+    // 3. one deterministic reduction of all partials into the flat gradient
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((NP + 63) / 64)), dim3(1024), 0, st, ws, nblk, grid_dz, off_wout(NL, F), NP, NP,
+                       grad);
+    return check_hip(hipGetLastError(), who);
 }
 
 extern "C" int ptr_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
