@@ -32,6 +32,7 @@ extern "C" {
 #define PTR_ABI_VERSION 1
 #define PTR_MAX_LIST_LEN 4096
 #define PTR_MAX_CUTOFFS 32
+#define PTR_MLP_ACT_LD 112
 
 #define PTR_ERR_INVALID_ARG 1001   /* NULL pointer, negative size, bad enum value               */
 #define PTR_ERR_UNSUPPORTED 1002   /* L > PTR_MAX_LIST_LEN, nk > PTR_MAX_CUTOFFS, ...            */
@@ -116,8 +117,9 @@ int ptr_sum_f32(const float *x, int n, float scale, float *out, void *stream);
  * `params` / `grad` are ONE flat fp32 buffer in PyTorch's own order and layouts:
  *   W1[100][F] b1[100] | W2[100][100] b2[100] | ... (NL hidden layers) | w_out[100] b_out[1]      (ptr_mlp_num_params floats)
  * X is [R][F] row-major (R = B*L documents), preds [R].  train != 0: dropout p_drop from the counter-based generator
- * seeded by `seed`, and the post-dropout activations needed by backward are written to acts [NL][R][100].
- * ptr_mlp_backward: dpreds [R] -> grad (every entry overwritten); dz [NL][R][100] and ws (ptr_mlp_backward_ws_floats)
+ * seeded by `seed`, and the post-dropout activations needed by backward are written to acts [NL][R][PTR_MLP_ACT_LD]
+ * (rows padded to 112 floats = 7 aligned 64-byte sectors).
+ * ptr_mlp_backward: dpreds [R] -> grad (every entry overwritten); dz [NL][R][PTR_MLP_ACT_LD] and ws (ptr_mlp_backward_ws_floats)
  * are caller-provided scratch; p_drop / seed must be the forward call's.  All calls are deterministic. */
 size_t ptr_mlp_num_params(int F, int NL);
 size_t ptr_mlp_backward_ws_floats(int F, int NL);

@@ -90,7 +90,7 @@ approxndcg_kernel(const float *__restrict__ preds, const float *__restrict__ lab
                 float ya, yb;
                 robust_pair(S_id[b] - sa[m], alpha, ya, yb);
                 pia[m] += ya;
-                atomicAdd(&aw[b], yb);
+                aw[b] += yb;                                  // per-wave row, distinct b per lane (no atomics needed)
             }
         }
     }
@@ -103,7 +103,7 @@ approxndcg_kernel(const float *__restrict__ preds, const float *__restrict__ lab
                 float ya, yb;
                 robust_pair(S_id[a + d] - sa[m], alpha, ya, yb);
                 pia[m] += ya;
-                atomicAdd(&aw[a + d], yb);
+                aw[a + d] += yb;
             }
         }
     }
@@ -152,7 +152,7 @@ approxndcg_kernel(const float *__restrict__ preds, const float *__restrict__ lab
         const float cb = Y_id[b];
         const float flow = cb * dba - ca[m] * dab;            // d loss / d s_a from this pair
         ga[m] += flow;
-        atomicAdd(&aw[b], -flow);
+        aw[b] -= flow;
     };
     for (int d = 1; d <= half; ++d) {
 #pragma unroll

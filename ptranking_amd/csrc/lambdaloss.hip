@@ -125,7 +125,7 @@ lambdaloss_kernel(const float *__restrict__ preds, const float *__restrict__ lab
         if (p0 >= eps && wp_ok) g = -(w * sigma * (1.0f - p0)) * inv_ln2;  // d/ds_winner; loser gets -g
         const float ga_ = a_wins ? g : -g;
         ga[m] += ga_;
-        atomicAdd(&gw[b], -ga_);
+        gw[b] -= ga_;                                                      // per-wave row, distinct b per lane: race-free
     };
 
     const int half = (kk - 1) >> 1;

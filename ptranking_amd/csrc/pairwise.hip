@@ -8,9 +8,10 @@
 //
 // Pair schedule ("circulant"): with n documents at rank positions 0..n-1, step d = 1..floor((n-1)/2) visits the pair
 // (a, (a+d) mod n) for every a — each unordered pair exactly once (for even n the step d = n/2 is visited by
-// a < n/2 only).  Lane a keeps its own gradient in a register; the partner's share goes to LDS with a no-return
-// ds_add_f32 into a per-WAVE accumulator row (distinct lanes hit distinct addresses within one instruction, and one
-// wave's LDS ops execute in program order), so the result is run-to-run bit-stable.
+// a < n/2 only).  Lane a keeps its own gradient in a register; the partner's share is accumulated in a per-WAVE LDS row
+// with a plain ds_read / add / ds_write (within one step all lanes of a wave hit distinct positions, a wave's LDS
+// operations execute in program order, and no other wave touches the row), so there are no float atomics at all —
+// LDS fp32 atomics measured ~10x slower than the whole rest of the pair body — and results are run-to-run bit-stable.
 //
 // Arithmetic follows what the reference executes in ATen (SURVEY.md §7 i-ii):
 //   p = sigmoid(sigma*(s_i - s_j)) rounded to fp32; BCE with the -100 log clamp; backward w*(p-t)/max(p(1-p),1e-12)
@@ -101,16 +102,19 @@ pairwise_bce_kernel(const float *__restrict__ preds, const float *__restrict__ l
     float lacc = 0.0f;
     float *gw = gacc + (size_t)wv * Lp;
 
-    auto pair = [&](int m, int a, int d) {
-        int b = a + d;
-        if (b >= n) b -= n;
-        const bool fwd = b > a;                       // lo = a, hi = b (no wrap) — else lo = b, hi = a
+    // The pair body is branch-free: lanes without a document (a >= n) or outside the half step run on a clamped index
+    // with activity factor 0, so the DPT independent chains of a lane can be interleaved by the scheduler.
+    auto pair = [&](int m, int a_eff, int d, float act) {
+        int b = a_eff + d;
+        b -= b >= n ? n : 0;
+        const bool fwd = b > a_eff;                   // lo = a, hi = b (no wrap) — else lo = b, hi = a
         const float4 o = pk[b];
+        const float gold = gw[b];                               // partner accumulator: plain read-modify-write, see header
         const float ds = fwd ? me[m].x - o.x : o.x - me[m].x;   // s_lo - s_hi
         const float dy = fwd ? me[m].y - o.y : o.y - me[m].y;   // gain (or label) of lo minus hi
         float lam;
         if constexpr (WEIGHTED) {
-            const float w = fabsf(dy) * fabsf(me[m].z - o.z);   // |G_i - G_j| * |D_i - D_j|, metric_utils.py:43
+            const float w = (fabsf(dy) * fabsf(me[m].z - o.z)) * act;   // |G_i - G_j| * |D_i - D_j|, metric_utils.py:43
             const float x = sigma * ds;                         // >= 0 in predicted order
             const float e = __expf(-x);
             const float dd = 1.0f + e;
@@ -129,29 +133,37 @@ pairwise_bce_kernel(const float *__restrict__ preds, const float *__restrict__ l
             const float p = 1.0f / (1.0f + expf(-x));           // IEEE division: p may legitimately hit 0 / 1
             const float qv = 1.0f - p;
             const float l1 = fmaxf(logf(p), -100.0f), l0 = fmaxf(logf(qv), -100.0f);
-            lacc += (tt - 1.0f) * l0 - tt * l1;
+            lacc += ((tt - 1.0f) * l0 - tt * l1) * act;
             const float den = qv * p;
-            lam = sigma * (((p - tt) / fmaxf(den, 1e-12f)) * den);
+            lam = (sigma * (((p - tt) / fmaxf(den, 1e-12f)) * den)) * act;
         }
         const float sl = fwd ? lam : -lam;
         ga[m] += sl;
-        atomicAdd(&gw[b], -sl);                                 // ds_add_f32, per-wave row => deterministic
+        if (act != 0.0f) gw[b] = gold - sl;                     // active lanes hit distinct b: race-free; idle lanes (clamped
+                                                                // index) must not write back a stale value
     };
 
-    const int half = (n - 1) >> 1;
-    for (int d = 1; d <= half; ++d) {
+    int aeff[DPT];
+    float act[DPT];
 #pragma unroll
-        for (int m = 0; m < DPT; ++m) {
-            const int a = t + m * G;
-            if (a < n) pair(m, a, d);
-        }
+    for (int m = 0; m < DPT; ++m) {
+        const int a = t + m * G;
+        act[m] = a < n ? 1.0f : 0.0f;
+        aeff[m] = a < n ? a : 0;
     }
-    if (n > 0 && (n & 1) == 0) {
-        const int d = n >> 1;
+    const int half = (n - 1) >> 1;
+    if (n > 1) {
+        for (int d = 1; d <= half; ++d) {
 #pragma unroll
-        for (int m = 0; m < DPT; ++m) {
-            const int a = t + m * G;
-            if (a < d) pair(m, a, d);
+            for (int m = 0; m < DPT; ++m) pair(m, aeff[m], d, act[m]);
+        }
+        if ((n & 1) == 0) {
+            const int d = n >> 1;
+#pragma unroll
+            for (int m = 0; m < DPT; ++m) {
+                const int a = t + m * G;
+                pair(m, a < d ? a : 0, d, a < d ? 1.0f : 0.0f);
+            }
         }
     }
     __syncthreads();

@@ -145,21 +145,36 @@ __device__ __forceinline__ float gain_of(float label) { return exp2f(label) - 1.
 // keys[] is in LDS, padded with -inf up to a multiple of 4 (float4 broadcast reads).  own[m] / index t + m*G.
 template <int G, int DPT>
 __device__ __forceinline__ void count_ranks(const float *keys, int n, int t, const float (&own)[DPT], int (&rk)[DPT]) {
+    // Fast path (tie-free lists, the common case): rank = #{j : k_j > k_i} — one compare + one add-with-carry per pair.
+    // #{j : k_j >= k_i} is counted alongside; a lane whose two counts differ by more than its own element has a tie, and
+    // only then the wave takes the slow pass that adds #{j < i : k_j == k_i} (original index breaks ties).
+    int ge[DPT];
 #pragma unroll
-    for (int m = 0; m < DPT; ++m) rk[m] = 0;
+    for (int m = 0; m < DPT; ++m) { rk[m] = 0; ge[m] = 0; }
     const float4 *k4 = reinterpret_cast<const float4 *>(keys);
     const int n4 = (n + 3) >> 2;
     for (int j4 = 0; j4 < n4; ++j4) {
         const float4 v = k4[j4];
-        const int j = j4 << 2;
+#pragma unroll
+        for (int m = 0; m < DPT; ++m) {
+            const float s = own[m];
+            rk[m] += (v.x > s) + (v.y > s) + (v.z > s) + (v.w > s);
+            ge[m] += (v.x >= s) + (v.y >= s) + (v.z >= s) + (v.w >= s);
+        }
+    }
+    bool tie = false;
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) tie |= (t + m * G < n) && (ge[m] - rk[m] != 1);
+    if (__any(tie)) {
 #pragma unroll
         for (int m = 0; m < DPT; ++m) {
             const int i = t + m * G;
             const float s = own[m];
-            rk[m] += (v.x > s || (v.x == s && j + 0 < i)) ? 1 : 0;
-            rk[m] += (v.y > s || (v.y == s && j + 1 < i)) ? 1 : 0;
-            rk[m] += (v.z > s || (v.z == s && j + 2 < i)) ? 1 : 0;
-            rk[m] += (v.w > s || (v.w == s && j + 3 < i)) ? 1 : 0;
+            if (i < n && ge[m] - rk[m] != 1) {
+                int extra = 0;
+                for (int j = 0; j < i; ++j) extra += keys[j] == s ? 1 : 0;
+                rk[m] += extra;
+            }
         }
     }
 }

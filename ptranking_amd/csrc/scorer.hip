@@ -21,6 +21,8 @@
 //
 // HBM traffic per row (F = 136, 3 hidden layers, training): forward reads 4F, writes 3*400 + 4; dZ reads 3*400 + 4, writes
 // 3*400; dW reads 4F + 5*400.  MFMA work per row: 2*(100F + 2*100*100 + 100) flop forward, about twice that backward.
+#include <stdlib.h>
+
 #include "ptr_device.h"
 
 namespace ptr {
@@ -31,6 +33,8 @@ constexpr int kH = 100;          // hidden width, hard-wired in the reference (p
 constexpr int kHP = 112;         // padded to 7 MFMA tiles of 16
 constexpr int kMT = 7;
 constexpr int kMaxLayers = 8;
+constexpr int kAL = 112;         // leading dimension of the stored activations / dZ: rows are 448 B = 7 aligned 64-B sectors,
+                                 // one per (row, 16-feature tile); features 100..111 are zero padding
 
 __host__ __device__ inline size_t off_W(int l, int F) { return l == 0 ? 0 : (size_t)kH * F + kH + (size_t)(l - 1) * (kH * kH + kH); }
 __host__ __device__ inline size_t off_b(int l, int F) { return off_W(l, F) + (l == 0 ? (size_t)kH * F : (size_t)kH * kH); }
@@ -202,8 +206,8 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
                         uint32_t w0, w1;
                         drop_bits(a.seed_lo, a.seed_hi, l, row[rt], 4 * mt + g, w0, w1);
                         h = drop4(h, w0, w1, thr, scale);
-                        if (row[rt] < R && (mt < kMT - 1 || g == 0))
-                            *reinterpret_cast<f32x4 *>(acts + ((size_t)(l - 1) * R + row[rt]) * kH + 16 * mt + 4 * g) = h;
+                        if (row[rt] < R)
+                            *reinterpret_cast<f32x4 *>(acts + ((size_t)(l - 1) * R + row[rt]) * kAL + 16 * mt + 4 * g) = h;
                     }
                     hin[mt][rt] = h;
                 }
@@ -240,8 +244,8 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { h[c] = fmaxf(h[c], 0.0f); sc[rt] = fmaf(h[c], w4[c], sc[rt]); }
                 if constexpr (TRAIN) {
-                    if (row[rt] < R && (mt < kMT - 1 || g == 0))
-                        *reinterpret_cast<f32x4 *>(acts + ((size_t)(NL - 1) * R + row[rt]) * kH + 16 * mt + 4 * g) = h;
+                    if (row[rt] < R)
+                        *reinterpret_cast<f32x4 *>(acts + ((size_t)(NL - 1) * R + row[rt]) * kAL + 16 * mt + 4 * g) = h;
                 }
             }
         }
@@ -305,8 +309,8 @@ mlp_bwd_dz_kernel(const float *__restrict__ P, const float *__restrict__ acts, c
             const f32x4 w4 = *reinterpret_cast<const f32x4 *>(Wo + 16 * mt + 4 * g);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                const bool ok = row[rt] < R && (mt < kMT - 1 || g == 0);
-                const size_t o = ((size_t)(NL - 1) * R + row[rt]) * kH + 16 * mt + 4 * g;
+                const bool ok = row[rt] < R;
+                const size_t o = ((size_t)(NL - 1) * R + row[rt]) * kAL + 16 * mt + 4 * g;
                 f32x4 h = *reinterpret_cast<const f32x4 *>(acts + (ok ? o : 0));      // clamped address, zeroed below
                 const float okf = ok ? 1.0f : 0.0f;
 #pragma unroll
@@ -321,6 +325,17 @@ mlp_bwd_dz_kernel(const float *__restrict__ P, const float *__restrict__ acts, c
         for (int l = NL - 1; l >= 1; --l) {
             // dA_{l-1}^T[k][row] = sum_out W_l[out][k] * dz_l[row][out]
             const float *Wl = WT + (size_t)(l - 1) * kHP * kH;
+            // the gate (stored post-dropout activation of layer l-1) is fetched BEFORE the MFMA chain so that its HBM latency
+            // hides under the 7x7 tile products
+            f32x4 gate[kMT][RT];
+#pragma unroll
+            for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const bool ok = row[rt] < R;
+                    const size_t o = ((size_t)(l - 1) * R + row[rt]) * kAL + 16 * mt + 4 * g;
+                    gate[mt][rt] = *reinterpret_cast<const f32x4 *>(acts + (ok ? o : 0));
+                }
             f32x4 acc[kMT][RT];
 #pragma unroll
             for (int mt = 0; mt < kMT; ++mt)
@@ -337,17 +352,16 @@ mlp_bwd_dz_kernel(const float *__restrict__ P, const float *__restrict__ acts, c
                         for (int rt = 0; rt < RT; ++rt)
                             acc[mt][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c], cur[S][rt][c], acc[mt][rt], 0, 0, 0);
                 }
-            // gate with the stored post-dropout activation: a > 0  <=>  kept by dropout AND relu active
+            // gate: a > 0  <=>  kept by dropout AND relu active
 #pragma unroll
             for (int mt = 0; mt < kMT; ++mt)
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
-                    const bool ok = row[rt] < R && (mt < kMT - 1 || g == 0);
-                    const size_t o = ((size_t)(l - 1) * R + row[rt]) * kH + 16 * mt + 4 * g;
-                    const f32x4 av = *reinterpret_cast<const f32x4 *>(acts + (ok ? o : 0));
+                    const bool ok = row[rt] < R;
+                    const size_t o = ((size_t)(l - 1) * R + row[rt]) * kAL + 16 * mt + 4 * g;
                     f32x4 d;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) d[c] = acc[mt][rt][c] * ((ok && av[c] > 0.0f) ? inv_keep : 0.0f);
+                    for (int c = 0; c < 4; ++c) d[c] = acc[mt][rt][c] * ((ok && gate[mt][rt][c] > 0.0f) ? inv_keep : 0.0f);
                     if (ok) *reinterpret_cast<f32x4 *>(dz + o) = d;
                     cur[mt][rt] = d;
                 }
@@ -383,7 +397,7 @@ mlp_bwd_dz_kernel(const float *__restrict__ P, const float *__restrict__ acts, c
 // ws[block][n_params]: per-block partial gradient in the flat parameter layout, reduced by reduce_partials_kernel.
 template <int NTW, bool SITE0>
 __global__ void __launch_bounds__(256)
-mlp_bwd_dw_kernel(const float *__restrict__ A, const float *__restrict__ dZ, int K, MlpArgs a, float *__restrict__ ws,
+mlp_bwd_dw_kernel(const float *__restrict__ A, int lda, const float *__restrict__ dZ, int K, MlpArgs a, float *__restrict__ ws,
                   size_t np_stride, size_t w_off, size_t b_off) {
     const int R = a.R;
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6;
@@ -408,7 +422,7 @@ mlp_bwd_dw_kernel(const float *__restrict__ A, const float *__restrict__ dZ, int
     int fa[kMT], kb[NTW];
     bool fa_ok[kMT], kb_ok[NTW];
 #pragma unroll
-    for (int mt = 0; mt < kMT; ++mt) { const int f = 16 * mt + j; fa_ok[mt] = f < kH; fa[mt] = fa_ok[mt] ? f : 0; }
+    for (int mt = 0; mt < kMT; ++mt) { const int f = 16 * mt + j; fa_ok[mt] = true; fa[mt] = f; }   // padded: always in range
 #pragma unroll
     for (int t = 0; t < NTW; ++t) { const int k = 16 * (wave + 4 * t) + j; kb_ok[t] = k < K; kb[t] = kb_ok[t] ? k : 0; }
     float av[U][kMT], bv[U][NTW], avn[U][kMT], bvn[U][NTW];
@@ -418,8 +432,8 @@ mlp_bwd_dw_kernel(const float *__restrict__ A, const float *__restrict__ dZ, int
             const int r = r0 + 4 * u + g;
             const bool rok = !guard || r < r_end;
             const int rc = rok ? r : r_end - 1;
-            const float *dzr = dZ + (size_t)rc * kH;
-            const float *ar = A + (size_t)rc * K;
+            const float *dzr = dZ + (size_t)rc * kAL;
+            const float *ar = A + (size_t)rc * lda;
 #pragma unroll
             for (int mt = 0; mt < kMT; ++mt) pa[u][mt] = dzr[fa[mt]] * ((rok & fa_ok[mt]) ? 1.0f : 0.0f);
 #pragma unroll
@@ -552,6 +566,12 @@ static int check_mlp(const char *who, int R, int F, int NL, float p) {
     return 0;
 }
 
+static int dw_blocks_per_cu() {
+    static int v = 0;
+    if (!v) { const char *e = getenv("PTR_DW_BLOCKS_PER_CU"); v = e ? atoi(e) : 2; if (v < 1 || v > 8) v = 2; }
+    return v;
+}
+
 static int num_cus() {
     static int n = 0;
     if (!n) {
@@ -569,7 +589,7 @@ extern "C" size_t ptr_mlp_num_params(int F, int NL) { return ptr::n_params(NL, F
 
 // floats of workspace ptr_mlp_backward needs
 extern "C" size_t ptr_mlp_backward_ws_floats(int F, int NL) {
-    return 2 * (size_t)ptr::num_cus() * ptr::n_params(NL, F);
+    return (size_t)ptr::dw_blocks_per_cu() * ptr::num_cus() * ptr::n_params(NL, F);
 }
 
 extern "C" int ptr_mlp_forward(const float *X, const float *params, int R, int F, int NL, int train, float p_drop, uint64_t seed,
@@ -603,13 +623,13 @@ extern "C" int ptr_mlp_backward(const float *X, const float *params, const float
     MlpArgs a{R, F, NL, p_drop, (uint32_t)seed, (uint32_t)(seed >> 32)};
     // 1. dZ chain (+ partial d w_out / d b_out)
     const int ncu = num_cus();
-    const int nblk = 2 * ncu;
+    const int nblk = dw_blocks_per_cu() * ncu;
     const size_t NP = n_params(NL, F);
-    const int ntiles = (R + 31) / 32;
+    const int ntiles = (R + 15) / 16;
     int grid_dz = ntiles < 8 * ncu ? (ntiles + 7) / 8 : ncu;
     if (grid_dz < 1) grid_dz = 1;
     {
-        auto kern = mlp_bwd_dz_kernel<2>;
+        auto kern = mlp_bwd_dz_kernel<1>;
         const size_t lds = dz_lds_floats(NL) * sizeof(float);
         if (int e = allow_lds(kern, lds)) return e;
         hipLaunchKernelGGL(kern, dim3(grid_dz), dim3(512), lds, st, params, acts, dpreds, a, dz, ws, NP, off_wout(NL, F));
@@ -618,11 +638,12 @@ extern "C" int ptr_mlp_backward(const float *X, const float *params, const float
     // 2. dW per layer (row contraction), every block writes its partial into ws[block][flat parameter layout]
     for (int l = 0; l < NL; ++l) {
         const int K = l == 0 ? F : kH;
-        const float *A = l == 0 ? X : acts + (size_t)(l - 1) * R * kH;
-        const float *dZ = dz + (size_t)l * R * kH;
+        const float *A = l == 0 ? X : acts + (size_t)(l - 1) * R * kAL;
+        const int lda = l == 0 ? F : kAL;
+        const float *dZ = dz + (size_t)l * R * kAL;
         const int ntk = (K + 15) / 16, ntw = (ntk + 3) / 4;
         auto go = [&](auto kern) -> int {
-            hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), 0, st, A, dZ, K, a, ws, NP, off_W(l, F), off_b(l, F));
+            hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), 0, st, A, lda, dZ, K, a, ws, NP, off_W(l, F), off_b(l, F));
             return check_hip(hipGetLastError(), who);
         };
         int e = 0;

@@ -17,6 +17,7 @@ import torch.nn as nn
 from . import _lib
 
 HIDDEN = 100   # ptranking/base/point_ranker.py:30
+ACT_LD = 112   # PTR_MLP_ACT_LD: leading dimension of the stored activations / dZ scratch
 
 
 def fusable(num_features=None, h_dim=100, out_dim=1, num_layers=3, AF='R', TL_AF='S', apply_tl_af=False, BN=True, bn_type=None,
@@ -35,7 +36,7 @@ class _ScorerFn(torch.autograd.Function):
         dev = X2d.device
         preds = torch.empty(R, device=dev, dtype=torch.float32)
         train = bool(store or p > 0.0)
-        acts = torch.empty((NL, R, HIDDEN), device=dev, dtype=torch.float32) if train else None
+        acts = torch.empty((NL, R, ACT_LD), device=dev, dtype=torch.float32) if train else None
         with torch.cuda.device(dev):
             _lib.call("ptr_mlp_forward", _lib.ptr(X2d), _lib.ptr(flat), R, F, NL, int(train), C.c_float(p), C.c_uint64(seed),
                       _lib.ptr(preds), _lib.ptr(acts), _lib.current_stream(dev))
@@ -50,7 +51,7 @@ class _ScorerFn(torch.autograd.Function):
         R, F, NL, p, seed = ctx.meta
         dev = X2d.device
         dpreds = dpreds.contiguous()
-        dz = torch.empty((NL, R, HIDDEN), device=dev, dtype=torch.float32)
+        dz = torch.empty((NL, R, ACT_LD), device=dev, dtype=torch.float32)
         ws = torch.empty(_lib.query("ptr_mlp_backward_ws_floats", F, NL), device=dev, dtype=torch.float32)
         grad = torch.empty_like(flat)
         with torch.cuda.device(dev):
