@@ -8,8 +8,10 @@ configs[1]).  One process per GPU:
         bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline      the fused LambdaRank kernel: algorithmic bytes (12*L+4 per query) / its average launch
-                duration measured with HIP events on the launch stream during the timed region, vs HBM peak 8 TB/s
+  roofline      the dominant kernel of the step (the fused fp32-MFMA scorer forward): algorithmic flops per launch / its
+                average launch duration measured with HIP events on the launch stream during the timed region, vs the
+                157.3 TFLOP/s fp32 MFMA peak; `kernels.lambdarank_loss_grad` carries the same for the north-star loss kernel
+                against the HBM roofline (12*L+4 bytes per query)
   cpu_baseline  the oracle's torch-CPU restatement of the reference train step, timed on this box's host cores on a
                 bounded sample of the same workload (rank 0, N=1 only)
 Inputs are resident in HBM before the timed region; a step does no host synchronisation.
@@ -30,6 +32,7 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFLOPS = 157.3      # dense fp32-input MFMA peak = fp32 vector peak (same guide)
 MSLR_P = [0.5147, 0.3250, 0.1339, 0.0183, 0.0081]   # label histogram of MSLR-WEB30K
 SEED = 137                        # ptranking/ltr_global.py:7
 
@@ -139,25 +142,67 @@ def main():
         raise SystemExit(f"non-finite loss {final_loss}")
 
     if rank == 0:
-        ev = timing.get("ptr_lambdarank_fwd_bwd", [])
-        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
-        algo_bytes = B * (12 * L + 4)
-        achieved = algo_bytes / (kern_ms * 1e-3) / 1e9 if ev else float("nan")
+        def avg_ms(name):
+            ev = timing.get(name, [])
+            return float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else None
+
+        R = B * L
+        NL = 3
+        fwd_flop = 2.0 * (100 * F + (NL - 1) * 100 * 100 + 100) * R          # algorithmic: 2*(100F + 2*100*100 + 100) per document
+        step_ms = 1e3 * elapsed / args.steps
+        t_fwd, t_loss, t_bwd, t_adam = (avg_ms(n) for n in ("ptr_mlp_forward", "ptr_lambdarank_fwd_bwd", "ptr_mlp_backward", "ptr_adam_step"))
+        pmc = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                j = json.load(f)
+            if j["config"] == {"queries_per_gpu_per_step": B, "list_len": L, "features": F}:
+                pmc = {k: v["hbm_bytes_per_launch"] for k, v in j["kernels"].items()}
+        except (OSError, KeyError, ValueError):
+            pass
+
+        def pmc_bytes(prefix):
+            for k, v in pmc.items():
+                if k.startswith(prefix):
+                    return v
+            return None
+
+        loss_bytes = B * (12 * L + 4)
+        kernels = {}
+        if t_loss:
+            gbps = loss_bytes / (t_loss * 1e-3) / 1e9
+            kernels["lambdarank_loss_grad"] = {
+                "kernel": "pairwise_bce_kernel<64,2,WEIGHTED> (fused LambdaRank dNDCG loss + gradient)", "bound": "hbm",
+                "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                "traffic": pmc_bytes("ptr::pairwise_bce_kernel"), "avg_launch_ms": t_loss, "algorithmic_bytes_per_launch": loss_bytes,
+                "pairs_per_s": B * (L * (L - 1) // 2) / (t_loss * 1e-3),
+                "note": "O(L^2) pair work per 12L+4 bytes: VALU/transcendental-bound by construction (DESIGN.md 3.1)"}
+        if t_bwd:
+            kernels["scorer_backward"] = {"kernels": "mlp_bwd_dz + 3 x mlp_bwd_dw + reduce_partials", "avg_call_ms": t_bwd,
+                                          "algorithmic_flop_per_call": 2.0 * fwd_flop - 2.0 * 100 * F * R,
+                                          "achieved_TFLOPs": (2.0 * fwd_flop - 2.0 * 100 * F * R) / (t_bwd * 1e-3) / 1e12}
+        if t_adam:
+            kernels["adam"] = {"avg_launch_ms": t_adam}
+        if t_fwd:
+            tf = fwd_flop / (t_fwd * 1e-3) / 1e12
+            roofline = {"kernel": "mlp_fwd_kernel<2,TRAIN,VEC> (fused pointsf scorer forward, fp32 MFMA 16x16x4, dropout in-kernel)",
+                        "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
+                        "traffic": pmc_bytes("ptr::mlp_fwd_kernel"), "avg_launch_ms": t_fwd, "algorithmic_flop_per_launch": fwd_flop,
+                        "algorithmic_bytes_per_launch": R * (4 * F + 4) + NL * R * 448,
+                        "note": "dominant kernel of the step by time; traffic = PMC FETCH_SIZE(x2 on gfx950)+WRITE_SIZE from profiles/r01_pmc_traffic.json"}
+        else:   # scorer configuration not fusable: the north-star loss kernel is the only kernel of ours in the step
+            roofline = dict(kernels.get("lambdarank_loss_grad", {}))
         qps = world * B * args.steps / elapsed
         out = {
             "metric": "queries/sec fwd+bwd LambdaRank, MSLR-WEB30K-shaped list_len=128",
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"LambdaRank dNDCG train step (pointsf 3x100 ReLU scorer, dropout 0.1, Adam), "
                                    f"MSLR-WEB30K-shaped synthetic, {F} feats, list_len={L}",
                        "queries_per_gpu_per_step": B, "global_batch": world * B, "list_len": L, "features": F,
                        "parallelism": f"dp{world}", "resident_batches": len(batches)},
-            "roofline": {"kernel": "pairwise_bce_kernel<WEIGHTED> (fused LambdaRank loss+grad)", "bound": "hbm",
-                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None, "avg_launch_ms": kern_ms, "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "O(L^2) pair work: VALU/transcendental-bound, not HBM-bound (DESIGN.md)"},
-            "loss_kernel_share_of_step": kern_ms / (1e3 * elapsed / args.steps) if ev else None,
+            "roofline": roofline,
+            "kernels": kernels,
             "final_epoch_loss": final_loss,
         }
         if world == 1 and not args.no_cpu_baseline:
