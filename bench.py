@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--nbatches", type=int, default=4, help="distinct HBM-resident batches cycled through (> L3 capacity)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--loss", default="LambdaRank", choices=["RankNet", "LambdaRank", "LambdaLoss", "ApproxNDCG", "ListNet", "ListMLE"],
+                    help="ranker of the train step (the headline metric is LambdaRank; the others cover BASELINE.json configs 3-5)")
     args = ap.parse_args()
 
     import ptranking_amd as pa
@@ -104,8 +106,13 @@ def main():
     B, L, F = args.batch, args.list_len, args.features
 
     torch.manual_seed(SEED)                       # identical initial weights on every rank
-    ranker = pa.LambdaRank(sf_para_dict=sf_para_dict(F), model_para_dict={"model_id": "LambdaRank", "sigma": 1.0},
-                           gpu=True, device=device)
+    cls = getattr(pa, args.loss)
+    if args.loss == "ListNet":
+        ranker = cls(sf_para_dict=sf_para_dict(F), gpu=True, device=device)
+    else:
+        ranker = cls(sf_para_dict=sf_para_dict(F), model_para_dict=dict(pa.DEFAULT_PARAS[args.loss]), gpu=True, device=device)
+    if args.loss == "ListMLE":
+        ranker.tie_shuffle = "device"             # the reference's B host-side randperm calls per step would dominate
     ranker.init()
     ranker.train_mode()                           # dropout 0.1 active, exactly like the reference's train()
     gen = torch.Generator(device=device).manual_seed(SEED + 1000 * rank)   # every rank owns different queries
@@ -150,7 +157,9 @@ def main():
         NL = 3
         fwd_flop = 2.0 * (100 * F + (NL - 1) * 100 * 100 + 100) * R          # algorithmic: 2*(100F + 2*100*100 + 100) per document
         step_ms = 1e3 * elapsed / args.steps
-        t_fwd, t_loss, t_bwd, t_adam = (avg_ms(n) for n in ("ptr_mlp_forward", "ptr_lambdarank_fwd_bwd", "ptr_mlp_backward", "ptr_adam_step"))
+        loss_entry = {"RankNet": "ptr_ranknet_fwd_bwd", "LambdaRank": "ptr_lambdarank_fwd_bwd", "LambdaLoss": "ptr_lambdaloss_fwd_bwd",
+                      "ApproxNDCG": "ptr_approxndcg_fwd_bwd", "ListNet": "ptr_listnet_fwd_bwd", "ListMLE": "ptr_listmle_fwd_bwd"}[args.loss]
+        t_fwd, t_loss, t_bwd, t_adam = (avg_ms(n) for n in ("ptr_mlp_forward", loss_entry, "ptr_mlp_backward", "ptr_adam_step"))
         pmc = {}
         try:
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
@@ -170,8 +179,9 @@ def main():
         kernels = {}
         if t_loss:
             gbps = loss_bytes / (t_loss * 1e-3) / 1e9
-            kernels["lambdarank_loss_grad"] = {
-                "kernel": "pairwise_bce_kernel<64,2,WEIGHTED> (fused LambdaRank dNDCG loss + gradient)", "bound": "hbm",
+            kernels["lambdarank_loss_grad" if args.loss == "LambdaRank" else "loss_grad"] = {
+                "kernel": ("pairwise_bce_kernel<64,2,WEIGHTED> (fused LambdaRank dNDCG loss + gradient)" if args.loss == "LambdaRank"
+                           else f"{loss_entry} (fused {args.loss} loss + gradient)"), "bound": "hbm",
                 "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
                 "traffic": pmc_bytes("ptr::pairwise_bce_kernel"), "avg_launch_ms": t_loss, "algorithmic_bytes_per_launch": loss_bytes,
                 "pairs_per_s": B * (L * (L - 1) // 2) / (t_loss * 1e-3),
@@ -190,14 +200,15 @@ def main():
                         "algorithmic_bytes_per_launch": R * (4 * F + 4) + NL * R * 448,
                         "note": "dominant kernel of the step by time; traffic = PMC FETCH_SIZE(x2 on gfx950)+WRITE_SIZE from profiles/r01_pmc_traffic.json"}
         else:   # scorer configuration not fusable: the north-star loss kernel is the only kernel of ours in the step
-            roofline = dict(kernels.get("lambdarank_loss_grad", {}))
+            roofline = dict(kernels.get("lambdarank_loss_grad", kernels.get("loss_grad", {})))
         qps = world * B * args.steps / elapsed
         out = {
-            "metric": "queries/sec fwd+bwd LambdaRank, MSLR-WEB30K-shaped list_len=128",
+            "metric": ("queries/sec fwd+bwd LambdaRank, MSLR-WEB30K-shaped list_len=128" if (args.loss, L, F) == ("LambdaRank", 128, 136)
+                       else f"queries/sec fwd+bwd {args.loss}, synthetic list_len={L}, {F} feats"),
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"LambdaRank dNDCG train step (pointsf 3x100 ReLU scorer, dropout 0.1, Adam), "
+            "config": {"workload": f"{args.loss} train step (pointsf 3x100 ReLU scorer, dropout 0.1, Adam), "
                                    f"MSLR-WEB30K-shaped synthetic, {F} feats, list_len={L}",
                        "queries_per_gpu_per_step": B, "global_batch": world * B, "list_len": L, "features": F,
                        "parallelism": f"dp{world}", "resident_batches": len(batches)},

@@ -98,8 +98,8 @@ __host__ __device__ inline size_t fwd_lds_floats(int F, int NL) {
     return (size_t)kHP * ld_w1(F) + (size_t)(NL - 1) * kHP * kH + (size_t)NL * kHP + kHP + 16;
 }
 
-template <int RT, bool TRAIN, bool VEC>
-__global__ void __launch_bounds__(512)
+template <int RT, int NTHR, bool TRAIN, bool VEC>
+__global__ void __launch_bounds__(NTHR)
 mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs a, float *__restrict__ preds,
                float *__restrict__ acts) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -261,20 +261,20 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
 
 // =================================================================================================== backward: dZ chain
 // LDS: WT (NL-1) x [kHP][kH] (hidden weights TRANSPOSED: WT[k][out]) | Wo [kHP] | red [kHP + 16]
-__host__ __device__ inline size_t dz_lds_floats(int NL) { return (size_t)(NL - 1) * kHP * kH + (kHP + 16) + 8 * (kHP + 16); }
+__host__ __device__ inline size_t dz_lds_floats(int NL) { return (size_t)(NL - 1) * kHP * kH + (kHP + 16) + 16 * (kHP + 16); }
 
 // dz[l] (l = 0..NL-1) = dLoss/d(pre-activation of hidden layer l+1), [NL][R][100].  acts[l] = post-dropout input of hidden
 // layer l+2 (l < NL-1) / last hidden activation (l = NL-1), as the forward kernel stored them.
 // ws[block][wout_off ..]: per-block partial of d w_out (100) and d b_out, in the flat parameter layout.
-template <int RT>
-__global__ void __launch_bounds__(512)
+template <int RT, int NTHR>
+__global__ void __launch_bounds__(NTHR)
 mlp_bwd_dz_kernel(const float *__restrict__ P, const float *__restrict__ acts, const float *__restrict__ dpreds, MlpArgs a,
                   float *__restrict__ dz, float *__restrict__ ws, size_t np_stride, size_t wout_off) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int F = a.F, NL = a.NL, R = a.R;
     float *WT = smem;
     float *Wo = WT + (size_t)(NL - 1) * kHP * kH;
-    float *wrow = Wo + kHP + 16;                          // [8 waves][kHP + 16] partial d w_out / d b_out
+    float *wrow = Wo + kHP + 16;                          // [<= 16 waves][kHP + 16] partial d w_out / d b_out
     const int tid = threadIdx.x, nthr = blockDim.x;
     for (int l = 1; l < NL; ++l) stage_matrix(WT + (size_t)(l - 1) * kHP * kH, kH, P + off_W(l, F), kH, kH, true, tid, nthr);
     stage_vector(Wo, P + off_wout(NL, F), kH, tid, nthr);
@@ -572,6 +572,12 @@ static int dw_blocks_per_cu() {
     return v;
 }
 
+static int scorer_variant() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("PTR_SCORER_VARIANT"); v = e ? atoi(e) : 0; if (v < 0 || v > 1) v = 0; }
+    return v;
+}
+
 static int num_cus() {
     static int n = 0;
     if (!n) {
@@ -602,15 +608,21 @@ extern "C" int ptr_mlp_forward(const float *X, const float *params, int R, int F
     MlpArgs a{R, F, NL, train ? p_drop : 0.0f, (uint32_t)seed, (uint32_t)(seed >> 32)};
     const size_t lds = fwd_lds_floats(F, NL) * sizeof(float);
     const bool vec = (F % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
-    const int ntiles = (R + 31) / 32;
-    const int grid = ntiles < 8 * num_cus() ? (ntiles + 7) / 8 : num_cus();
+    const bool wide = scorer_variant() == 0;      // 0: 16 waves x 16-row tiles (4 waves/SIMD), 1: 8 waves x 32-row tiles
+    const int rows_per_tile = wide ? 16 : 32, wpb = wide ? 16 : 8;
+    const int ntiles = (R + rows_per_tile - 1) / rows_per_tile;
+    const int grid = ntiles < wpb * num_cus() ? (ntiles + wpb - 1) / wpb : num_cus();
     auto launch = [&](auto kern) -> int {
         if (int e = allow_lds(kern, lds)) return e;
-        hipLaunchKernelGGL(kern, dim3(grid > 0 ? grid : 1), dim3(512), lds, as_stream(stream), X, params, a, preds, acts);
+        hipLaunchKernelGGL(kern, dim3(grid > 0 ? grid : 1), dim3(wpb * 64), lds, as_stream(stream), X, params, a, preds, acts);
         return check_hip(hipGetLastError(), who);
     };
-    if (train) return vec ? launch(mlp_fwd_kernel<2, true, true>) : launch(mlp_fwd_kernel<2, true, false>);
-    return vec ? launch(mlp_fwd_kernel<2, false, true>) : launch(mlp_fwd_kernel<2, false, false>);
+    if (wide) {
+        if (train) return vec ? launch(mlp_fwd_kernel<1, 1024, true, true>) : launch(mlp_fwd_kernel<1, 1024, true, false>);
+        return vec ? launch(mlp_fwd_kernel<1, 1024, false, true>) : launch(mlp_fwd_kernel<1, 1024, false, false>);
+    }
+    if (train) return vec ? launch(mlp_fwd_kernel<2, 512, true, true>) : launch(mlp_fwd_kernel<2, 512, true, false>);
+    return vec ? launch(mlp_fwd_kernel<2, 512, false, true>) : launch(mlp_fwd_kernel<2, 512, false, false>);
 }
 
 extern "C" int ptr_mlp_backward(const float *X, const float *params, const float *acts, const float *dpreds, int R, int F, int NL,
@@ -625,15 +637,19 @@ extern "C" int ptr_mlp_backward(const float *X, const float *params, const float
     const int ncu = num_cus();
     const int nblk = dw_blocks_per_cu() * ncu;
     const size_t NP = n_params(NL, F);
+    const bool wide = scorer_variant() == 0;
+    const int wpb = wide ? 16 : 8;
     const int ntiles = (R + 15) / 16;
-    int grid_dz = ntiles < 8 * ncu ? (ntiles + 7) / 8 : ncu;
+    int grid_dz = ntiles < wpb * ncu ? (ntiles + wpb - 1) / wpb : ncu;
     if (grid_dz < 1) grid_dz = 1;
     {
-        auto kern = mlp_bwd_dz_kernel<1>;
         const size_t lds = dz_lds_floats(NL) * sizeof(float);
-        if (int e = allow_lds(kern, lds)) return e;
-        hipLaunchKernelGGL(kern, dim3(grid_dz), dim3(512), lds, st, params, acts, dpreds, a, dz, ws, NP, off_wout(NL, F));
-        if (int e = check_hip(hipGetLastError(), who)) return e;
+        auto go = [&](auto kern) -> int {
+            if (int e = allow_lds(kern, lds)) return e;
+            hipLaunchKernelGGL(kern, dim3(grid_dz), dim3(wpb * 64), lds, st, params, acts, dpreds, a, dz, ws, NP, off_wout(NL, F));
+            return check_hip(hipGetLastError(), who);
+        };
+        if (int e = wide ? go(mlp_bwd_dz_kernel<1, 1024>) : go(mlp_bwd_dz_kernel<1, 512>)) return e;
     }
     // 2. dW per layer (row contraction), every block writes its partial into ws[block][flat parameter layout]
     for (int l = 0; l < NL; ++l) {
