@@ -572,11 +572,14 @@ static int dw_blocks_per_cu() {
     return v;
 }
 
-static int scorer_variant() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("PTR_SCORER_VARIANT"); v = e ? atoi(e) : 0; if (v < 0 || v > 1) v = 0; }
-    return v;
+// Tile-shape knobs (measured on MI355X, B*L = 524288 rows, F = 136): forward 16 waves x 16-row tiles 432 us vs 8 waves x
+// 32-row tiles 461 us; dZ 8 waves 400 us vs 16 waves (spills at the 128-VGPR cap) 415 us.
+static int env_flag(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? (atoi(e) != 0) : dflt;
 }
+static int fwd_wide() { static int v = -1; if (v < 0) v = env_flag("PTR_FWD_WIDE", 1); return v; }
+static int dz_wide() { static int v = -1; if (v < 0) v = env_flag("PTR_DZ_WIDE", 0); return v; }
 
 static int num_cus() {
     static int n = 0;
@@ -608,7 +611,7 @@ extern "C" int ptr_mlp_forward(const float *X, const float *params, int R, int F
     MlpArgs a{R, F, NL, train ? p_drop : 0.0f, (uint32_t)seed, (uint32_t)(seed >> 32)};
     const size_t lds = fwd_lds_floats(F, NL) * sizeof(float);
     const bool vec = (F % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
-    const bool wide = scorer_variant() == 0;      // 0: 16 waves x 16-row tiles (4 waves/SIMD), 1: 8 waves x 32-row tiles
+    const bool wide = fwd_wide() != 0;            // 16 waves x 16-row tiles (4 waves/SIMD) or 8 waves x 32-row tiles
     const int rows_per_tile = wide ? 16 : 32, wpb = wide ? 16 : 8;
     const int ntiles = (R + rows_per_tile - 1) / rows_per_tile;
     const int grid = ntiles < wpb * num_cus() ? (ntiles + wpb - 1) / wpb : num_cus();
@@ -637,7 +640,7 @@ extern "C" int ptr_mlp_backward(const float *X, const float *params, const float
     const int ncu = num_cus();
     const int nblk = dw_blocks_per_cu() * ncu;
     const size_t NP = n_params(NL, F);
-    const bool wide = scorer_variant() == 0;
+    const bool wide = dz_wide() != 0;
     const int wpb = wide ? 16 : 8;
     const int ntiles = (R + 15) / 16;
     int grid_dz = ntiles < wpb * ncu ? (ntiles + wpb - 1) / wpb : ncu;
