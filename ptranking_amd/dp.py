@@ -35,13 +35,14 @@ def init_from_env(backend=None):
     rk = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if torch.cuda.is_available():
+        local = local % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local)
     if ws > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:   # PTR_DP_BACKEND=gloo lets several ranks share one GPU (tests); production = nccl (RCCL over xGMI)
+            backend = os.environ.get("PTR_DP_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
             kw["device_id"] = torch.device("cuda", local)

@@ -1,0 +1,72 @@
+"""GPU: the data-parallel step on the REAL kernels — two ranks sharing cuda:0 over gloo (RCCL cannot place two ranks on one
+device; the exchange logic is backend-agnostic).  Replicas must stay bit-identical and the exchanged gradient must equal the
+single-process full-batch gradient (the reference's losses are sums over queries)."""
+import copy
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+SF = {"sf_id": "pointsf", "opt": "Adam", "lr": 1e-3,
+      "pointsf": dict(num_features=136, num_layers=3, AF="R", TL_AF="S", apply_tl_af=False, BN=False, bn_type=None,
+                      bn_affine=False, dropout=0.0)}
+
+
+def _data(B=12, L=64, F=136):
+    rng = np.random.default_rng(5)
+    X = torch.from_numpy(rng.standard_normal((B, L, F)).astype(np.float32))
+    Y = rng.choice(5, size=(B, L), p=[0.5, 0.3, 0.15, 0.03, 0.02]).astype(np.float32)
+    Y[:, 0] = np.maximum(Y[:, 0], 1)
+    return X, torch.from_numpy(-np.sort(-Y, axis=1).copy())
+
+
+def _make(name):
+    import ptranking_amd as pa
+    torch.manual_seed(21)
+    paras = dict(pa.DEFAULT_PARAS[name])
+    r = getattr(pa, name)(sf_para_dict=copy.deepcopy(SF), model_para_dict=paras, gpu=True, device="cuda:0")
+    r.init()
+    r.train_mode()
+    return r
+
+
+def _worker(rank, world, port, name, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      PTR_DP_BACKEND="gloo")
+    import ptranking_amd as pa
+    from ptranking_amd import dp
+    dp.init_from_env()
+    X, Y = _data()
+    lo, hi = dp.shard_queries(X.size(0))
+    r = _make(name)
+    grads = None
+    for step in range(2):
+        loss, _ = r.train_op(X[lo:hi].cuda(), Y[lo:hi].cuda(), epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
+        if step == 0:
+            grads = r.point_sf.flat.grad.detach().cpu().clone()
+    torch.save({"flat": r.point_sf.flat.detach().cpu(), "grads": grads, "loss": float(loss.detach())},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["LambdaRank", "ApproxNDCG"])
+def test_two_ranks_on_one_gpu_match_the_full_batch(name, tmp_path):
+    import ptranking_amd as pa
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker, args=(2, port, name, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"rank{i}.pt") for i in range(2))
+    assert torch.equal(r0["flat"], r1["flat"]), "replicas diverged"
+    assert torch.equal(r0["grads"], r1["grads"])
+    X, Y = _data()
+    r = _make(name)
+    loss, _ = r.train_op(X.cuda(), Y.cuda(), epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
+    ref = r.point_sf.flat.grad.detach().cpu()
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((r0["grads"] - ref).abs().max()) <= 2e-5 * scale
