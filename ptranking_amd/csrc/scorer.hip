@@ -33,6 +33,9 @@ constexpr int kH = 100;          // hidden width, hard-wired in the reference (p
 constexpr int kHP = 112;         // padded to 7 MFMA tiles of 16
 constexpr int kMT = 7;
 constexpr int kMaxLayers = 8;
+#ifndef DW_U
+#define DW_U 4
+#endif
 constexpr int kAL = 112;         // leading dimension of the stored activations / dZ: rows are 448 B = 7 aligned 64-B sectors,
                                  // one per (row, 16-feature tile); features 100..111 are zero padding
 
@@ -401,7 +404,7 @@ mlp_bwd_dw_kernel(const float *__restrict__ A, int lda, const float *__restrict_
                   size_t np_stride, size_t w_off, size_t b_off) {
     const int R = a.R;
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6;
-    const int chunk = ((R + gridDim.x - 1) / gridDim.x + 15) & ~15;
+    const int chunk = ((R + gridDim.x - 1) / gridDim.x + 4 * DW_U - 1) / (4 * DW_U) * (4 * DW_U);
     const int r_begin = blockIdx.x * chunk, r_end = min(R, r_begin + chunk);
     const uint32_t thr = drop_thr(a.p_drop);
     const float scale = (SITE0 && a.p_drop > 0.0f) ? 1.0f / (1.0f - a.p_drop) : 1.0f;
@@ -417,7 +420,7 @@ mlp_bwd_dw_kernel(const float *__restrict__ A, int lda, const float *__restrict_
 #pragma unroll
     for (int mt = 0; mt < kMT; ++mt) dbv[mt] = 0.0f;
 
-    constexpr int U = 4;                                   // k-steps (of 4 rows) per iteration
+    constexpr int U = DW_U;                                // k-steps (of 4 rows) per iteration (prefetch depth)
     // Per-lane column offsets / validity are loop invariant; loads are branch-free (clamped column, select-to-zero).
     int fa[kMT], kb[NTW];
     bool fa_ok[kMT], kb_ok[NTW];
