@@ -97,22 +97,24 @@ __device__ __forceinline__ void stage_vector(float *dst, const float *src, int n
 
 // =================================================================================================== forward
 // LDS: W1s [kHP][ld1] | Wh (NL-1) x [kHP][kH] | B NL x [kHP] | Wo [kHP] | bo + pad [16]
-__host__ __device__ inline size_t fwd_lds_floats(int F, int NL) {
-    return (size_t)kHP * ld_w1(F) + (size_t)(NL - 1) * kHP * kH + (size_t)NL * kHP + kHP + 16;
+// w1_global: the first-layer weights stay in global memory (L2-resident) when they do not fit next to the hidden weights.
+__host__ __device__ inline size_t fwd_lds_floats(int F, int NL, bool w1_global) {
+    return (w1_global ? 0 : (size_t)kHP * ld_w1(F)) + (size_t)(NL - 1) * kHP * kH + (size_t)NL * kHP + kHP + 16;
 }
+__host__ __device__ inline bool fwd_needs_global_w1(int F, int NL) { return fwd_lds_floats(F, NL, false) * sizeof(float) > 160 * 1024; }
 
-template <int RT, int NTHR, bool TRAIN, bool VEC>
+template <int RT, int NTHR, bool TRAIN, bool VEC, bool W1G>
 __global__ void __launch_bounds__(NTHR)
 mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs a, float *__restrict__ preds,
                float *__restrict__ acts) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int F = a.F, NL = a.NL, R = a.R, ld1 = ld_w1(F);
     float *W1s = smem;
-    float *Wh = W1s + (size_t)kHP * ld1;
+    float *Wh = W1s + (W1G ? 0 : (size_t)kHP * ld1);
     float *Bs = Wh + (size_t)(NL - 1) * kHP * kH;
     float *Wo = Bs + (size_t)NL * kHP;
     const int tid = threadIdx.x, nthr = blockDim.x;
-    stage_matrix(W1s, ld1, P + off_W(0, F), kH, F, false, tid, nthr);
+    if constexpr (!W1G) stage_matrix(W1s, ld1, P + off_W(0, F), kH, F, false, tid, nthr);
     for (int l = 1; l < NL; ++l) stage_matrix(Wh + (size_t)(l - 1) * kHP * kH, kH, P + off_W(l, F), kH, kH, false, tid, nthr);
     for (int l = 0; l < NL; ++l) stage_vector(Bs + (size_t)l * kHP, P + off_b(l, F), kH, tid, nthr);
     stage_vector(Wo, P + off_wout(NL, F), kH, tid, nthr);
@@ -184,7 +186,16 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
             const int k0 = 16 * S + 4 * g;
 #pragma unroll
             for (int mt = 0; mt < kMT; ++mt) {
-                const f32x4 wa = *reinterpret_cast<const f32x4 *>(W1s + (size_t)(16 * mt + j) * ld1 + k0);
+                f32x4 wa;
+                if constexpr (W1G) {   // [100][F] in global memory: clamp the padded rows 100..111 and zero them
+                    const int wr = 16 * mt + j;
+                    const float rok1 = wr < kH ? 1.0f : 0.0f;
+                    wa = *reinterpret_cast<const f32x4 *>(P + (size_t)(wr < kH ? wr : kH - 1) * F + (k0 < F ? k0 : 0));
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) wa[c] *= rok1;
+                } else {
+                    wa = *reinterpret_cast<const f32x4 *>(W1s + (size_t)(16 * mt + j) * ld1 + k0);
+                }
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -398,10 +409,10 @@ mlp_bwd_dz_kernel(const float *__restrict__ P, const float *__restrict__ acts, c
 // A = X with the input dropout recomputed (layer 0, SITE0) or the stored activation (other layers).  Each wave owns the
 // in-feature tiles nt = wave, wave + 4, ... and all 7 out-feature tiles; a block walks its contiguous chunk of rows 4 at a time.
 // ws[block][n_params]: per-block partial gradient in the flat parameter layout, reduced by reduce_partials_kernel.
-template <int NTW, bool SITE0>
-__global__ void __launch_bounds__(256)
-mlp_bwd_dw_kernel(const float *__restrict__ A, int lda, const float *__restrict__ dZ, int K, MlpArgs a, float *__restrict__ ws,
-                  size_t np_stride, size_t w_off, size_t b_off) {
+template <int NTW, bool SITE0, int NWV>
+__global__ void __launch_bounds__(NWV * 64)
+mlp_bwd_dw_kernel(const float *__restrict__ A, int lda, const float *__restrict__ dZ, int K, int nt_base, MlpArgs a,
+                  float *__restrict__ ws, size_t np_stride, size_t w_off, size_t b_off) {
     const int R = a.R;
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6;
     const int chunk = ((R + gridDim.x - 1) / gridDim.x + 4 * DW_U - 1) / (4 * DW_U) * (4 * DW_U);
@@ -427,7 +438,7 @@ mlp_bwd_dw_kernel(const float *__restrict__ A, int lda, const float *__restrict_
 #pragma unroll
     for (int mt = 0; mt < kMT; ++mt) { const int f = 16 * mt + j; fa_ok[mt] = true; fa[mt] = f; }   // padded: always in range
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) { const int k = 16 * (wave + 4 * t) + j; kb_ok[t] = k < K; kb[t] = kb_ok[t] ? k : 0; }
+    for (int t = 0; t < NTW; ++t) { const int k = 16 * (nt_base + wave + NWV * t) + j; kb_ok[t] = k < K; kb[t] = kb_ok[t] ? k : 0; }
     float av[U][kMT], bv[U][NTW], avn[U][kMT], bvn[U][NTW];
     auto load = [&](int r0, bool guard, float (&pa)[U][kMT], float (&pb)[U][NTW]) {
 #pragma unroll
@@ -481,7 +492,7 @@ mlp_bwd_dw_kernel(const float *__restrict__ A, int lda, const float *__restrict_
     float *outb = ws + (size_t)blockIdx.x * np_stride + b_off;
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
-        const int nt = wave + 4 * t, k = 16 * nt + j;
+        const int nt = nt_base + wave + NWV * t, k = 16 * nt + j;
 #pragma unroll
         for (int mt = 0; mt < kMT; ++mt)
 #pragma unroll
@@ -490,7 +501,7 @@ mlp_bwd_dw_kernel(const float *__restrict__ A, int lda, const float *__restrict_
                 if (nt < ntk && k < K && o < kH) out[(size_t)o * K + k] = acc[t][mt][c];
             }
     }
-    if (wave == 0) {
+    if (wave == 0 && nt_base == 0) {
 #pragma unroll
         for (int mt = 0; mt < kMT; ++mt) {
             float v = dbv[mt];
@@ -561,9 +572,10 @@ dropout_mask_kernel(MlpArgs a, int site, int n_feat, float *__restrict__ out) {
 static int check_mlp(const char *who, int R, int F, int NL, float p) {
     if (R < 0 || F <= 0 || NL < 1 || NL > kMaxLayers) { set_error("%s: bad shape R=%d F=%d NL=%d", who, R, F, NL); return PTR_ERR_INVALID_ARG; }
     if (!(p >= 0.0f && p < 1.0f)) { set_error("%s: dropout p=%g out of [0,1)", who, (double)p); return PTR_ERR_INVALID_ARG; }
-    if (fwd_lds_floats(F, NL) * sizeof(float) > 160 * 1024) {
-        set_error("%s: F=%d with %d hidden layers needs %zu KB of LDS for the weights (max 160)", who, F, NL,
-                  fwd_lds_floats(F, NL) * sizeof(float) / 1024);
+    const bool w1g = fwd_needs_global_w1(F, NL);
+    if (fwd_lds_floats(F, NL, w1g) * sizeof(float) > 160 * 1024 || (w1g && F % 4 != 0) || (F + 15) / 16 > 48) {
+        set_error("%s: F=%d with %d hidden layers is outside the fused scorer's range (LDS %zu KB, max 160; F %% 4 == 0 needed "
+                  "above ~157 features; F <= 768)", who, F, NL, fwd_lds_floats(F, NL, w1g) * sizeof(float) / 1024);
         return PTR_ERR_UNSUPPORTED;
     }
     return 0;
@@ -612,7 +624,8 @@ extern "C" int ptr_mlp_forward(const float *X, const float *params, int R, int F
     if (R > 0 && (!X || !params || !preds || (train && !acts))) { set_error("%s: NULL pointer", who); return PTR_ERR_INVALID_ARG; }
     if (R == 0) return 0;
     MlpArgs a{R, F, NL, train ? p_drop : 0.0f, (uint32_t)seed, (uint32_t)(seed >> 32)};
-    const size_t lds = fwd_lds_floats(F, NL) * sizeof(float);
+    const bool w1g = fwd_needs_global_w1(F, NL);
+    const size_t lds = fwd_lds_floats(F, NL, w1g) * sizeof(float);
     const bool vec = (F % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
     const bool wide = fwd_wide() != 0;            // 16 waves x 16-row tiles (4 waves/SIMD) or 8 waves x 32-row tiles
     const int rows_per_tile = wide ? 16 : 32, wpb = wide ? 16 : 8;
@@ -623,12 +636,17 @@ extern "C" int ptr_mlp_forward(const float *X, const float *params, int R, int F
         hipLaunchKernelGGL(kern, dim3(grid > 0 ? grid : 1), dim3(wpb * 64), lds, as_stream(stream), X, params, a, preds, acts);
         return check_hip(hipGetLastError(), who);
     };
-    if (wide) {
-        if (train) return vec ? launch(mlp_fwd_kernel<1, 1024, true, true>) : launch(mlp_fwd_kernel<1, 1024, true, false>);
-        return vec ? launch(mlp_fwd_kernel<1, 1024, false, true>) : launch(mlp_fwd_kernel<1, 1024, false, false>);
+    if (w1g) {   // large F (e.g. Yahoo's 700): W1 streamed from L2, F % 4 == 0 guaranteed by check_mlp
+        if (!vec) { set_error("%s: X must be 16-byte aligned for F=%d", who, F); return PTR_ERR_INVALID_ARG; }
+        if (wide) return train ? launch(mlp_fwd_kernel<1, 1024, true, true, true>) : launch(mlp_fwd_kernel<1, 1024, false, true, true>);
+        return train ? launch(mlp_fwd_kernel<2, 512, true, true, true>) : launch(mlp_fwd_kernel<2, 512, false, true, true>);
     }
-    if (train) return vec ? launch(mlp_fwd_kernel<2, 512, true, true>) : launch(mlp_fwd_kernel<2, 512, true, false>);
-    return vec ? launch(mlp_fwd_kernel<2, 512, false, true>) : launch(mlp_fwd_kernel<2, 512, false, false>);
+    if (wide) {
+        if (train) return vec ? launch(mlp_fwd_kernel<1, 1024, true, true, false>) : launch(mlp_fwd_kernel<1, 1024, true, false, false>);
+        return vec ? launch(mlp_fwd_kernel<1, 1024, false, true, false>) : launch(mlp_fwd_kernel<1, 1024, false, false, false>);
+    }
+    if (train) return vec ? launch(mlp_fwd_kernel<2, 512, true, true, false>) : launch(mlp_fwd_kernel<2, 512, true, false, false>);
+    return vec ? launch(mlp_fwd_kernel<2, 512, false, true, false>) : launch(mlp_fwd_kernel<2, 512, false, false, false>);
 }
 
 extern "C" int ptr_mlp_backward(const float *X, const float *params, const float *acts, const float *dpreds, int R, int F, int NL,
@@ -663,18 +681,19 @@ extern "C" int ptr_mlp_backward(const float *X, const float *params, const float
         const float *A = l == 0 ? X : acts + (size_t)(l - 1) * R * kAL;
         const int lda = l == 0 ? F : kAL;
         const float *dZ = dz + (size_t)l * R * kAL;
-        const int ntk = (K + 15) / 16, ntw = (ntk + 3) / 4;
-        auto go = [&](auto kern) -> int {
-            hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), 0, st, A, lda, dZ, K, a, ws, NP, off_W(l, F), off_b(l, F));
+        const int ntk = (K + 15) / 16;
+        auto go = [&](auto kern, int nt_base) -> int {
+            hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), 0, st, A, lda, dZ, K, nt_base, a, ws, NP, off_W(l, F), off_b(l, F));
             return check_hip(hipGetLastError(), who);
         };
         int e = 0;
-        if (l == 0) {
-            if (ntw <= 3) e = go(mlp_bwd_dw_kernel<3, true>);
-            else if (ntw <= 6) e = go(mlp_bwd_dw_kernel<6, true>);
+        if (l == 0) {   // in-feature tiles per wave: 3 (F <= 192) or 6 (F <= 384); above that two passes of 24 tiles (F <= 768)
+            if (ntk <= 12) e = go(mlp_bwd_dw_kernel<3, true, 4>, 0);
+            else if (ntk <= 24) e = go(mlp_bwd_dw_kernel<6, true, 4>, 0);
+            else if (ntk <= 48) { e = go(mlp_bwd_dw_kernel<6, true, 4>, 0); if (!e) e = go(mlp_bwd_dw_kernel<6, true, 4>, 24); }
             else { set_error("%s: F=%d not supported by the dW kernel", who, F); return PTR_ERR_UNSUPPORTED; }
         } else {
-            e = go(mlp_bwd_dw_kernel<2, false>);
+            e = go(mlp_bwd_dw_kernel<2, false, 4>, 0);
         }
         if (e) return e;
     }

@@ -25,8 +25,12 @@ def fusable(num_features=None, h_dim=100, out_dim=1, num_layers=3, AF='R', TL_AF
     """True when the pointsf configuration is the one the fused kernels implement."""
     if not (AF == 'R' and not BN and not apply_tl_af and h_dim == HIDDEN and out_dim == 1 and 1 <= num_layers <= 8):
         return False
-    lds_floats = 112 * ((num_features + 3) // 4 * 4 + 4) + (num_layers - 1) * 112 * 100 + num_layers * 112 + 112 + 16
-    return lds_floats * 4 <= 160 * 1024 and (num_features + 15) // 16 <= 24
+    hidden = (num_layers - 1) * 112 * 100 + num_layers * 112 + 112 + 16
+    w1 = 112 * ((num_features + 3) // 4 * 4 + 4)
+    if (w1 + hidden) * 4 <= 160 * 1024:
+        return True                      # all weights in LDS
+    # large F (Yahoo: 700): W1 streams from L2 — needs 16-byte aligned rows and at most 48 in-feature tiles
+    return hidden * 4 <= 160 * 1024 and num_features % 4 == 0 and (num_features + 15) // 16 <= 48
 
 
 class _ScorerFn(torch.autograd.Function):

@@ -28,7 +28,7 @@ def close(a, b, tol=2e-5):
     assert err <= tol * scale, f"max|diff|={err:.3e} > {tol * scale:.3e}"
 
 
-@pytest.mark.parametrize("F,NL", [(136, 3), (24, 3), (46, 2), (8, 1), (24, 4), (180, 2)])
+@pytest.mark.parametrize("F,NL", [(136, 3), (24, 3), (46, 2), (8, 1), (24, 4), (180, 2), (700, 3), (256, 3)])
 @pytest.mark.parametrize("shape", [(5, 7), (64, 128), (3, 341)])
 def test_eval_forward_matches_torch(F, NL, shape):
     fused, ref = make_pair(F, NL)
@@ -52,7 +52,8 @@ def _train_reference(ref, fused, X2d, seed, p, NL):
     return lin[NL](a)
 
 
-@pytest.mark.parametrize("F,NL,R", [(136, 3, 2048 + 37), (24, 2, 100), (46, 3, 515), (136, 1, 64), (40, 4, 1000), (180, 2, 300)])
+@pytest.mark.parametrize("F,NL,R", [(136, 3, 2048 + 37), (24, 2, 100), (46, 3, 515), (136, 1, 64), (40, 4, 1000), (180, 2, 300), (700, 3, 1111), (256, 3, 640),
+                                    (400, 2, 333)])
 def test_train_forward_backward_match_torch_with_same_masks(F, NL, R, monkeypatch):
     p = 0.1
     fused, ref = make_pair(F, NL, dropout=p)
