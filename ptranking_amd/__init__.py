@@ -4,13 +4,15 @@
     rankers     RankNet / LambdaRank / LambdaLoss / ApproxNDCG / ListNet / ListMLE with the reference's plugin surface
     host        LABEL_TYPE, DeviceEvaluator, DeviceTrainLoop, the stand-alone pointsf base ranker
     scorer      the pointsf MLP scorer on fused fp32-MFMA kernels (FusedPointScorer) + FlatAdam
+    batching    PaddedQueryBatches: device-resident padded query batches (+ lens) replacing the reference's loader stack
     dp          data-parallel gradient exchange (one RCCL all-reduce per step)
     install()   rebinds the six ranker names inside an installed ptranking so LTREvaluator uses them unchanged
 
 The only compute implementation is the HIP library ptranking_amd/libptranking_amd.so (C ABI: include/ptranking_amd.h);
 there is no CPU fallback.  Build it with `python -m ptranking_amd.build`.
 """
-from . import _lib, dp, functional, host, rankers, scorer   # noqa: F401
+from . import _lib, batching, dp, functional, host, rankers, scorer   # noqa: F401
+from .batching import PaddedQueryBatches            # noqa: F401
 from .host import LABEL_TYPE, DeviceEvaluator       # noqa: F401
 from .install import install, uninstall             # noqa: F401
 from .rankers import (ApproxNDCG, LambdaLoss, LambdaRank, ListMLE, ListNet, RankNet,  # noqa: F401

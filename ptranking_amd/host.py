@@ -21,6 +21,7 @@ import torch.optim as optim
 from torch.optim.lr_scheduler import StepLR
 
 from . import functional as F_
+from .batching import unpack_batch
 
 
 @unique
@@ -45,22 +46,35 @@ class DeviceEvaluator:
         return t.to(self.device, non_blocking=True) if t.device != torch.device(self.device) else t
 
     def _run_eval(self, test_data, ks, presort, which, max_label=None, min_len=None, need_per_q=False):
+        """Shared loop of every Evaluator method.  Accepts the reference's (ids, X, Y) batches (all lists of a batch have the
+        same length) and PaddedQueryBatches' (ids, X, Y, lens).  min_len: the single-cut-off methods skip queries with
+        fewer than k documents (ranker.py:41-42) — per batch for the reference's loaders, per query for padded batches."""
         self.eval_mode()
         num_queries = 0
         sums = None
         per_q = {m: [] for m in which} if need_per_q else None
-        for batch_ids, batch_q_doc_vectors, batch_std_labels in test_data:
-            if min_len is not None and batch_std_labels.size(1) < min_len:
+        for batch in test_data:
+            batch_ids, batch_q_doc_vectors, batch_std_labels, lens = unpack_batch(batch)
+            if min_len is not None and lens is None and batch_std_labels.size(1) < min_len:
                 continue  # skip if the number of documents is smaller than k (ranker.py:41-42)
-            num_queries += len(batch_ids)
             batch_preds = self.predict(self._to_dev(batch_q_doc_vectors))
+            lens_d = None if lens is None else self._to_dev(lens).to(torch.int32)
             out = F_.metrics_at_ks(batch_preds.detach(), self._to_dev(batch_std_labels).float(), ks, presort=presort,
-                                   max_label=max_label, which=which)
+                                   max_label=max_label, which=which, lens=lens_d)
             if sums is None:
                 sums = {m: torch.zeros(len(ks), device=batch_preds.device) for m in which}
-            for m in which:
-                sums[m] += out[m].sum(dim=0)
-                if need_per_q:
+            if min_len is not None and lens_d is not None:
+                keep = (lens_d >= min_len)
+                n_kept = keep.sum()
+                for m in which:
+                    sums[m] += (out[m] * keep.unsqueeze(1)).sum(dim=0)
+                num_queries = num_queries + n_kept          # stays on the device until the end
+            else:
+                num_queries = num_queries + len(batch_ids)
+                for m in which:
+                    sums[m] += out[m].sum(dim=0)
+            if need_per_q:
+                for m in which:
                     per_q[m].append(out[m].cpu())
         if sums is None:   # nothing evaluated: the reference divides 0 by 0 here
             avg = {m: torch.zeros(len(ks)) / 0.0 for m in which}
@@ -133,12 +147,14 @@ class DeviceTrainLoop:
         num_queries = 0
         epoch_loss = torch.zeros(1, device=self.device)
         stop_training = False
-        for batch_ids, batch_q_doc_vectors, batch_std_labels in train_data:
+        for batch in train_data:
+            batch_ids, batch_q_doc_vectors, batch_std_labels, lens = unpack_batch(batch)   # lens: padded batches only
             num_queries += len(batch_ids)
             batch_q_doc_vectors = batch_q_doc_vectors.to(self.device, non_blocking=True)
             batch_std_labels = batch_std_labels.to(self.device, non_blocking=True)
+            extra = {} if lens is None else {"lens": lens.to(self.device, non_blocking=True).to(torch.int32)}
             batch_loss, stop_training = self.train_op(batch_q_doc_vectors, batch_std_labels, batch_ids=batch_ids,
-                                                      epoch_k=epoch_k, presort=presort, label_type=label_type)
+                                                      epoch_k=epoch_k, presort=presort, label_type=label_type, **extra)
             if stop_training:
                 break
             epoch_loss += batch_loss.detach().reshape(-1)[:1]

@@ -57,7 +57,7 @@ class FusedStepMixin:
 class RankNetLoss(FusedStepMixin):
     def custom_loss_function(self, batch_preds, batch_std_labels, **kwargs):
         """ptranking/ltr_adhoc/pairwise/ranknet.py:25-42"""
-        return self._fused_step(F_.ranknet_loss(batch_preds, batch_std_labels, sigma=self.sigma))
+        return self._fused_step(F_.ranknet_loss(batch_preds, batch_std_labels, sigma=self.sigma, lens=kwargs.get('lens')))
 
 
 class LambdaRankLoss(FusedStepMixin):
@@ -65,7 +65,7 @@ class LambdaRankLoss(FusedStepMixin):
         """ptranking/ltr_adhoc/listwise/lambdarank.py:27-62"""
         assert 'label_type' in kwargs and is_multilabel(kwargs['label_type'])
         assert 'presort' in kwargs and kwargs['presort'] is True  # aiming for direct usage of ideal ranking
-        return self._fused_step(F_.lambdarank_loss(batch_preds, batch_std_labels, sigma=self.sigma))
+        return self._fused_step(F_.lambdarank_loss(batch_preds, batch_std_labels, sigma=self.sigma, lens=kwargs.get('lens')))
 
 
 class LambdaLossLoss(FusedStepMixin):
@@ -74,7 +74,7 @@ class LambdaLossLoss(FusedStepMixin):
         assert is_multilabel(kwargs['label_type'])
         presort = bool('presort' in kwargs and kwargs['presort'])
         loss = F_.lambdaloss_loss(batch_preds, batch_std_labels, k=self.k, sigma=self.sigma, mu=getattr(self, 'mu', 5.0),
-                                  loss_type=self.loss_type, presort=presort)
+                                  loss_type=self.loss_type, presort=presort, lens=kwargs.get('lens'))
         return self._fused_step(loss)
 
 
@@ -93,13 +93,13 @@ class ApproxNDCGLoss(FusedStepMixin):
         presort = bool('presort' in kwargs and kwargs['presort'])
         if not (self.data_parallel and dp.is_distributed() and self.couple_batch):
             loss = F_.approxndcg_loss(batch_preds, batch_std_labels, alpha=self.alpha, presort=presort,
-                                      couple_batch=self.couple_batch)
+                                      couple_batch=self.couple_batch, lens=kwargs.get('lens'))
             return self._fused_step(loss)
         # Data parallel + batch coupling: the global loss is -(sum_all DCG)(sum_all 1/IDCG).  Every rank back-propagates
         # with scale 1, ships its local S = sum 1/IDCG and D = sum DCG in the gradient bucket, and rescales by the global S
         # after the single all-reduce (gradients are linear in S) — SURVEY.md §8e.
         loss1, parts = F_.approxndcg_loss(batch_preds, batch_std_labels, alpha=self.alpha, presort=presort,
-                                          couple_batch=True, grad_scale_override=1.0, return_parts=True)
+                                          couple_batch=True, grad_scale_override=1.0, return_parts=True, lens=kwargs.get('lens'))
         bucket = self._bucket(extra=2)
         bucket.zero()
         loss1.backward()
@@ -115,7 +115,7 @@ class ApproxNDCGLoss(FusedStepMixin):
 class ListNetLoss(FusedStepMixin):
     def custom_loss_function(self, batch_preds, batch_std_labels, **kwargs):
         """ptranking/ltr_adhoc/listwise/listnet.py:22-45"""
-        return self._fused_step(F_.listnet_loss(batch_preds, batch_std_labels))
+        return self._fused_step(F_.listnet_loss(batch_preds, batch_std_labels, lens=kwargs.get('lens')))
 
 
 class ListMLELoss(FusedStepMixin):
@@ -123,10 +123,10 @@ class ListMLELoss(FusedStepMixin):
     _tie_seed = 137           # ptranking/ltr_global.py:7
     _tie_calls = 0
 
-    def _shuffle_ties(self, batch_std_labels):
-        if self.tie_shuffle == "device":
+    def _shuffle_ties(self, batch_std_labels, lens=None):
+        if self.tie_shuffle == "device" or lens is not None:     # padded batches: the device kernel honours `lens`
             self._tie_calls += 1
-            return F_.shuffle_ties_order(batch_std_labels, seed=self._tie_seed * 0x9E3779B1 + self._tie_calls)
+            return F_.shuffle_ties_order(batch_std_labels, seed=self._tie_seed * 0x9E3779B1 + self._tie_calls, lens=lens)
         # ptranking/ltr_adhoc/util/sampling_utils.py:13-28, batched: one randperm per query from the global torch RNG
         B, L = batch_std_labels.shape
         dev = batch_std_labels.device
@@ -140,8 +140,9 @@ class ListMLELoss(FusedStepMixin):
 
     def custom_loss_function(self, batch_preds, batch_std_labels, **kwargs):
         """ptranking/ltr_adhoc/listwise/listmle.py:73-104"""
-        perm = self._shuffle_ties(batch_std_labels)   # shuffle per epoch rather than using the same order for a query
-        return self._fused_step(F_.listmle_loss(batch_preds, perm))
+        lens = kwargs.get('lens')
+        perm = self._shuffle_ties(batch_std_labels, lens)   # shuffle per epoch rather than using the same order for a query
+        return self._fused_step(F_.listmle_loss(batch_preds, perm, lens=lens))
 
 
 def make_ranker_classes(base=PointScorerRanker):
