@@ -128,41 +128,79 @@ __device__ __forceinline__ uint32_t mix64(uint64_t x) {      // splitmix64 final
     return (uint32_t)(x >> 16);
 }
 
-// perm = argsort by (label descending, random key ascending, index ascending): a uniformly random order inside
-// every group of equal labels — the distribution arg_shuffle_ties draws from (sampling_utils.py:13-28).
+// perm = argsort by (label descending, random key ascending, index ascending): a uniformly random order inside every
+// group of equal labels — the distribution arg_shuffle_ties draws from (sampling_utils.py:13-28).
+// Integer grades in [0, 63] (MultiLabel) take the fast path: label and an 18-bit random field are packed into ONE float key
+// (exact below 2^24) and ranked by the shared counting sort; field collisions fall back to index order inside count_ranks'
+// tie pass.  Anything else ranks with the exact three-way comparison.
+template <int G, int DPT>
 __global__ void __launch_bounds__(kBlock)
 shuffle_ties_kernel(const float *__restrict__ labels, const int32_t *__restrict__ lens, int B, int L, int Lp, uint64_t seed,
                     int64_t *__restrict__ perm) {
+    constexpr int QPB = kBlock / G;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
-    const int q = blockIdx.x * wpb + wv;
-    if (q >= B) return;
-    const int n = query_len(lens, q, L);
-    float *y = smem + (size_t)wv * 3 * Lp;
-    uint32_t *r = reinterpret_cast<uint32_t *>(y + Lp);
-    int *out = reinterpret_cast<int *>(y + 2 * Lp);
-    for (int i = lane; i < n; i += 64) {
-        y[i] = labels[(size_t)q * L + i];
-        r[i] = mix64(seed ^ ((uint64_t)q * 0x100000001B3ull + (uint64_t)i) * 0xD6E8FEB86659FD93ull);
+    const int tid = threadIdx.x, grp = tid / G, t = tid % G;
+    const int q = blockIdx.x * QPB + grp;
+    const bool valid = q < B;
+    const int n = valid ? query_len(lens, q, L) : 0;
+    float *keys = smem + (size_t)grp * 3 * Lp;                 // packed keys (fast path) / labels (general path)
+    uint32_t *rnd = reinterpret_cast<uint32_t *>(keys + Lp);
+    int *out = reinterpret_cast<int *>(keys + 2 * Lp);
+    float y[DPT], key[DPT];
+    uint32_t r[DPT];
+    bool small_int = true;
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int i = t + m * G;
+        const bool in = i < n;
+        y[m] = in ? labels[(size_t)q * L + i] : 0.0f;
+        r[m] = mix64(seed ^ ((uint64_t)q * 0x100000001B3ull + (uint64_t)i) * 0xD6E8FEB86659FD93ull);
+        small_int &= !in || (y[m] >= 0.0f && y[m] < 64.0f && y[m] == floorf(y[m]));
+        key[m] = in ? y[m] * 262144.0f + (float)(262143u - (r[m] >> 14)) : -INFINITY;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    for (int i = lane; i < n; i += 64) {
-        const float yi = y[i];
-        const uint32_t ri = r[i];
-        int rank = 0;
-        for (int j = 0; j < n; ++j) {
-            const float yj = y[j];
-            const uint32_t rj = r[j];
-            rank += (yj > yi || (yj == yi && (rj < ri || (rj == ri && j < i)))) ? 1 : 0;
+    // one decision per workgroup keeps the barriers below uniform
+    int *all_small = reinterpret_cast<int *>(smem + (size_t)QPB * 3 * Lp);   // carved from the dynamic region (no static LDS in
+    if (tid == 0) *all_small = 1;                                            // front of it: keeps the float4 tiles 16-byte aligned)
+    __syncthreads();
+    if (!small_int) *all_small = 0;
+    __syncthreads();
+    const bool fast = *all_small != 0;
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int i = t + m * G;
+        if (i < Lp) { keys[i] = fast ? key[m] : (i < n ? y[m] : -INFINITY); rnd[i] = r[m]; }
+    }
+    __syncthreads();
+    int rk[DPT];
+    if (fast) {
+        count_ranks<G, DPT>(keys, n, t, key, rk);
+    } else {
+#pragma unroll
+        for (int m = 0; m < DPT; ++m) {
+            const int i = t + m * G;
+            int c = 0;
+            if (i < n)
+                for (int j = 0; j < n; ++j) {
+                    const float yj = keys[j];
+                    const uint32_t rj = rnd[j];
+                    c += (yj > y[m] || (yj == y[m] && (rj < r[m] || (rj == r[m] && j < i)))) ? 1 : 0;
+                }
+            rk[m] = c;
         }
-        out[rank] = i;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    for (int i = lane; i < L; i += 64) perm[(size_t)q * L + i] = i < n ? (int64_t)out[i] : (int64_t)i;
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int i = t + m * G;
+        if (i < n) out[rk[m]] = i;
+    }
+    __syncthreads();
+    if (valid) {
+#pragma unroll
+        for (int m = 0; m < DPT; ++m) {
+            const int i = t + m * G;
+            if (i < L) perm[(size_t)q * L + i] = i < n ? (int64_t)out[i] : (int64_t)i;
+        }
+    }
 }
 
 }  // namespace ptr
@@ -208,14 +246,14 @@ extern "C" int ptr_shuffle_ties_order(const float *labels, const int32_t *lens, 
     using namespace ptr;
     const char *who = "ptr_shuffle_ties_order";
     if (int rc = check_batch(labels, perm, B, L, who)) return rc;
-    if (B > 0) {
-        const int Lp = round_up(L, 4);
-        const size_t per_q = 3 * (size_t)Lp * sizeof(float);
-        const int wpb = waves_per_block(per_q);
-        if (int e = allow_lds(shuffle_ties_kernel, wpb * per_q)) return e;
-        hipLaunchKernelGGL(shuffle_ties_kernel, dim3((B + wpb - 1) / wpb), dim3(wpb * kWave), wpb * per_q, as_stream(stream), labels, lens,
-                           B, L, Lp, seed, perm);
-        if (int rc = check_hip(hipGetLastError(), who)) return rc;
-    }
-    return 0;
+    if (B == 0) return 0;
+    const int Lp = round_up(L, 4);
+    return dispatch_tiling(L, [&]<int G, int DPT>() -> int {
+        constexpr int QPB = kBlock / G;
+        auto kern = shuffle_ties_kernel<G, DPT>;
+        const size_t lds = ((size_t)QPB * 3 * Lp + 4) * sizeof(float);
+        if (int e = allow_lds(kern, lds)) return e;
+        hipLaunchKernelGGL(kern, dim3((B + QPB - 1) / QPB), dim3(kBlock), lds, as_stream(stream), labels, lens, B, L, Lp, seed, perm);
+        return check_hip(hipGetLastError(), who);
+    });
 }

@@ -57,17 +57,21 @@ sort_desc_kernel(const float *__restrict__ preds, const int32_t *__restrict__ le
 }
 
 // ------------------------------------------------------------------------------------------------ batch max (nERR normaliser)
+// torch.max(batch_ideal_rankings) (adhoc_metric.py:174-175).  Grid-wide: block maxima are merged with an integer atomicMax
+// on an order-preserving encoding of the float (max is exact and order-independent, so the result is deterministic).
+__device__ __forceinline__ int float_to_ordered(float f) { const int b = __float_as_int(f); return b >= 0 ? b : b ^ 0x7FFFFFFF; }
+__device__ __forceinline__ float ordered_to_float(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF); }
+
 __global__ void __launch_bounds__(kBlock)
-batch_max_kernel(const float *__restrict__ labels, const int32_t *__restrict__ lens, int B, int L, float *__restrict__ out) {
+batch_max_kernel(const float *__restrict__ labels, const int32_t *__restrict__ lens, int B, int L, int *__restrict__ out_key) {
     __shared__ float red[4];
     float mx = -INFINITY;
-    const size_t total = (size_t)B * L;
-    for (size_t e = threadIdx.x; e < total; e += kBlock) {
-        const int q = (int)(e / L), i = (int)(e % L);
-        if (i < query_len(lens, q, L)) mx = fmaxf(mx, labels[e]);
+    for (int q = blockIdx.x; q < B; q += gridDim.x) {
+        const int n = query_len(lens, q, L);
+        for (int i = threadIdx.x; i < n; i += kBlock) mx = fmaxf(mx, labels[(size_t)q * L + i]);
     }
     mx = group_max<kBlock>(mx, red, threadIdx.x);
-    if (threadIdx.x == 0) out[0] = mx;
+    if (threadIdx.x == 0) atomicMax(out_key, float_to_ordered(mx));
 }
 
 // ------------------------------------------------------------------------------------------------ metrics
@@ -115,7 +119,7 @@ metrics_kernel(const float *__restrict__ preds, const float *__restrict__ labels
     // ---- wave 0 of the group walks the two rankings
     if (valid && t < kWave) {
         const int lane = t;
-        const float max_label = max_label_dev ? max_label_dev[0] : max_label_host;
+        const float max_label = max_label_dev ? ordered_to_float(reinterpret_cast<const int *>(max_label_dev)[0]) : max_label_host;
         const float pow_max = exp2f(max_label);              // adhoc_metric.py:133
         float *r_ndcg = o_ndcg ? o_ndcg + (size_t)q * ck.nk : nullptr;
         float *r_nerr = o_nerr ? o_nerr + (size_t)q * ck.nk : nullptr;
@@ -213,7 +217,9 @@ extern "C" int ptr_metrics_at_ks(const float *preds, const float *labels, const 
     hipStream_t st = as_stream(stream);
     const float *ml_dev = nullptr;
     if (nerr && max_label < 0.0f) {
-        hipLaunchKernelGGL(batch_max_kernel, dim3(1), dim3(kBlock), 0, st, labels, lens, B, L, max_label_ws);
+        if (int rc = check_hip(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(max_label_ws), (int)0x80000000, 1, st), who)) return rc;
+        hipLaunchKernelGGL(batch_max_kernel, dim3(B < 2048 ? B : 2048), dim3(kBlock), 0, st, labels, lens, B, L,
+                           reinterpret_cast<int *>(max_label_ws));
         if (int rc = check_hip(hipGetLastError(), who)) return rc;
         ml_dev = max_label_ws;
     }
