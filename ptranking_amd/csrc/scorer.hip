@@ -513,6 +513,153 @@ mlp_bwd_dw_kernel(const float *__restrict__ A, int lda, const float *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// LDS-staged variant of the dW kernel (used whenever rows are 16-byte aligned, i.e. lda % 4 == 0).
+// The direct variant above lets all four waves of a block fetch the same dZ tiles (4x redundant, dword-wide loads): only
+// ~1/4 of the bytes in flight are unique and the kernel sits at 1.8-2.8 TB/s.  Here the workgroup loads each 16-row
+// slab of dZ and of its A column slice ONCE with 16-byte loads (one dropout hash per float4 for the input site), double
+// buffers it in LDS, and the waves read their MFMA operands (lane j = feature, g = row) back with ds_read_b32; row strides
+// are = 16 (mod 32) floats so the two 16-lane halves of a read hit disjoint banks.
+// One pass covers the A columns [64*NTW*pass, 64*NTW*(pass+1)); wave w owns in-feature tiles w, w+4, ...
+template <int NTW, bool SITE0, int RB>
+__global__ void __launch_bounds__(256)
+mlp_bwd_dw_lds_kernel(const float *__restrict__ A, int lda, const float *__restrict__ dZ, int K, int nt_base, MlpArgs a,
+                      float *__restrict__ ws, size_t np_stride, size_t w_off, size_t b_off) {
+    // RB = rows per slab (RB/4 MFMA k-steps per barrier)
+    constexpr int WA4 = 16 * NTW;                  // float4 per A-slice row (64*NTW columns)
+    constexpr int LDA = 64 * NTW + 16;             // LDS row strides: = 16 (mod 32)
+    constexpr int LDZ = kAL;                       // 112 = 16 (mod 32)
+    constexpr int SA = RB * WA4 / 256;             // float4 load slots per thread for the A slab (NTW)
+    constexpr int SZ = (RB * (kAL / 4) + 255) / 256;   // ... for the dZ slab (2, second one half used)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    auto zb = [&](int b) -> float * { return smem + b * (RB * LDZ); };
+    auto ab = [&](int b) -> float * { return smem + 2 * RB * LDZ + b * (RB * LDA); };
+
+    const int R = a.R;
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6;
+    const int chunk = ((R + gridDim.x - 1) / gridDim.x + RB - 1) / RB * RB;
+    const int r_begin = blockIdx.x * chunk, r_end = min(R, r_begin + chunk);
+    const uint32_t thr = drop_thr(a.p_drop);
+    const float scale = (SITE0 && a.p_drop > 0.0f) ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+    const int col0 = 16 * nt_base;                 // first A column of this pass
+
+    // loop-invariant slot geometry
+    int a_row[SA], a_col[SA], z_row[SZ], z_col[SZ];
+    bool a_ok[SA], z_ok[SZ];
+#pragma unroll
+    for (int s_ = 0; s_ < SA; ++s_) {
+        const int idx = s_ * 256 + tid;
+        a_row[s_] = idx / WA4;
+        a_col[s_] = col0 + 4 * (idx % WA4);
+        a_ok[s_] = a_col[s_] < K;
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < SZ; ++s_) {
+        const int idx = s_ * 256 + tid;
+        z_ok[s_] = idx < RB * (kAL / 4);
+        z_row[s_] = z_ok[s_] ? idx / (kAL / 4) : 0;
+        z_col[s_] = z_ok[s_] ? 4 * (idx % (kAL / 4)) : 0;
+    }
+    f32x4 ra[SA], rz[SZ];
+    auto gload = [&](int r0) {                      // global -> registers (masks applied multiplicatively, loads stay unconditional)
+#pragma unroll
+        for (int s_ = 0; s_ < SA; ++s_) {
+            const int r = r0 + a_row[s_];
+            const bool rok = r < r_end;
+            const int rc = rok ? r : r_end - 1;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(A + (size_t)rc * lda + (a_ok[s_] ? a_col[s_] : 0));
+            const float okf = (rok & a_ok[s_]) ? 1.0f : 0.0f;
+            if constexpr (SITE0) {
+                uint32_t w0, w1;
+                drop_bits(a.seed_lo, a.seed_hi, 0, rc, a_col[s_] >> 2, w0, w1);
+                v = drop4(v, w0, w1, thr, scale);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] *= okf;
+            ra[s_] = v;
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < SZ; ++s_) {
+            const int r = r0 + z_row[s_];
+            const bool rok = r < r_end;
+            const int rc = rok ? r : r_end - 1;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(dZ + (size_t)rc * kAL + z_col[s_]);
+            const float okf = (rok & z_ok[s_]) ? 1.0f : 0.0f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] *= okf;
+            rz[s_] = v;
+        }
+    };
+    auto lstore = [&](int buf) {                    // registers -> LDS slab
+#pragma unroll
+        for (int s_ = 0; s_ < SA; ++s_)
+            *reinterpret_cast<f32x4 *>(ab(buf) + a_row[s_] * LDA + (a_col[s_] - col0)) = ra[s_];
+#pragma unroll
+        for (int s_ = 0; s_ < SZ; ++s_)
+            if (z_ok[s_]) *reinterpret_cast<f32x4 *>(zb(buf) + z_row[s_] * LDZ + z_col[s_]) = rz[s_];
+    };
+
+    f32x4 acc[NTW][kMT];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int mt = 0; mt < kMT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dbv[kMT];
+#pragma unroll
+    for (int mt = 0; mt < kMT; ++mt) dbv[mt] = 0.0f;
+
+    if (r_begin < r_end) {
+        gload(r_begin);
+        lstore(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int r0 = r_begin; r0 < r_end; r0 += RB, buf ^= 1) {
+        const bool more = r0 + RB < r_end;
+        if (more) gload(r0 + RB);                   // next slab in flight while this one is multiplied
+        const float *zs = zb(buf), *as = ab(buf);
+#pragma unroll
+        for (int u = 0; u < RB / 4; ++u) {
+            float av[kMT], bv[NTW];
+#pragma unroll
+            for (int mt = 0; mt < kMT; ++mt) { av[mt] = zs[(4 * u + g) * LDZ + 16 * mt + j]; dbv[mt] += av[mt]; }
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) bv[t] = as[(4 * u + g) * LDA + 16 * (wave + 4 * t) + j];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int mt = 0; mt < kMT; ++mt)
+                    acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[t], acc[t][mt], 0, 0, 0);
+        }
+        if (more) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    float *out = ws + (size_t)blockIdx.x * np_stride + w_off;
+    float *outb = ws + (size_t)blockIdx.x * np_stride + b_off;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int k = col0 + 16 * (wave + 4 * t) + j;
+#pragma unroll
+        for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int o = 16 * mt + 4 * g + c;
+                if (k < K && o < kH) out[(size_t)o * K + k] = acc[t][mt][c];
+            }
+    }
+    if (wave == 0 && nt_base == 0) {
+#pragma unroll
+        for (int mt = 0; mt < kMT; ++mt) {
+            float v = dbv[mt];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int f = 16 * mt + j;
+            if (g == 0 && f < kH) outb[f] = v;
+        }
+    }
+}
+__host__ __device__ constexpr size_t dw_lds_bytes(int NTW, int RB) { return (size_t)(2 * RB * kAL + 2 * RB * (64 * NTW + 16)) * sizeof(float); }
+
 // grad[i] = sum_b ws[b][i], fixed order.  A 1024-thread workgroup owns 64 consecutive i: wave w sums the partials
 // b = w, w+16, ... (4 independent accumulators keep 4 loads in flight), then one wave adds the 16 wave totals in order.
 // Entries i >= tail_begin (d w_out, d b_out: written by the dZ kernel's smaller grid) only have nblk_tail partials.
@@ -594,6 +741,8 @@ static int env_flag(const char *name, int dflt) {
     return e ? (atoi(e) != 0) : dflt;
 }
 static int fwd_wide() { static int v = -1; if (v < 0) v = env_flag("PTR_FWD_WIDE", 1); return v; }
+static int dw_staged() { static int v = -1; if (v < 0) v = env_flag("PTR_DW_STAGED", 1); return v; }
+static int dw_rb() { static int v = -1; if (v < 0) { const char *e = getenv("PTR_DW_RB"); v = (e && atoi(e) == 32) ? 32 : 16; } return v; }   // 16 measured best (32: 1.09 vs 1.05 ms backward)
 static int dz_wide() { static int v = -1; if (v < 0) v = env_flag("PTR_DZ_WIDE", 0); return v; }
 
 static int num_cus() {
@@ -686,14 +835,25 @@ extern "C" int ptr_mlp_backward(const float *X, const float *params, const float
             hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), 0, st, A, lda, dZ, K, nt_base, a, ws, NP, off_W(l, F), off_b(l, F));
             return check_hip(hipGetLastError(), who);
         };
+        auto go_lds = [&](auto kern, int ntw, int rb, int nt_base) -> int {
+            if (int e0 = allow_lds(kern, dw_lds_bytes(ntw, rb))) return e0;
+            hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), dw_lds_bytes(ntw, rb), st, A, lda, dZ, K, nt_base, a, ws, NP, off_W(l, F),
+                               off_b(l, F));
+            return check_hip(hipGetLastError(), who);
+        };
+        const bool aligned = (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && dw_staged();
         int e = 0;
-        if (l == 0) {   // in-feature tiles per wave: 3 (F <= 192) or 6 (F <= 384); above that two passes of 24 tiles (F <= 768)
-            if (ntk <= 12) e = go(mlp_bwd_dw_kernel<3, true, 4>, 0);
+        if (l == 0) {   // in-feature tiles per wave and pass: 3 (192 columns) or 6 (384 columns)
+            if (aligned) {
+                if (ntk <= 12) e = dw_rb() == 32 ? go_lds(mlp_bwd_dw_lds_kernel<3, true, 32>, 3, 32, 0) : go_lds(mlp_bwd_dw_lds_kernel<3, true, 16>, 3, 16, 0);
+                else for (int base = 0; base < ntk && !e; base += 24) e = go_lds(mlp_bwd_dw_lds_kernel<6, true, 16>, 6, 16, base);
+            } else if (ntk <= 12) e = go(mlp_bwd_dw_kernel<3, true, 4>, 0);
             else if (ntk <= 24) e = go(mlp_bwd_dw_kernel<6, true, 4>, 0);
             else if (ntk <= 48) { e = go(mlp_bwd_dw_kernel<6, true, 4>, 0); if (!e) e = go(mlp_bwd_dw_kernel<6, true, 4>, 24); }
             else { set_error("%s: F=%d not supported by the dW kernel", who, F); return PTR_ERR_UNSUPPORTED; }
         } else {
-            e = go(mlp_bwd_dw_kernel<2, false, 4>, 0);
+            if (!aligned) e = go(mlp_bwd_dw_kernel<2, false, 4>, 0);
+            else e = dw_rb() == 32 ? go_lds(mlp_bwd_dw_lds_kernel<2, false, 32>, 2, 32, 0) : go_lds(mlp_bwd_dw_lds_kernel<2, false, 16>, 2, 16, 0);
         }
         if (e) return e;
     }
