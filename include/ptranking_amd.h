@@ -80,6 +80,20 @@ int ptr_approxndcg_fwd_bwd(const float *preds, const float *labels, const int32_
 int ptr_listnet_fwd_bwd(const float *preds, const float *labels, const int32_t *lens, int B, int L, float *loss_out,
                         float *loss_q, float *grad, void *stream);
 
+/* ---- sibling losses served by the same listwise machinery ----
+ * STListNet — replaces ptranking/ltr_adhoc/listwise/st_listnet.py:41-49: ListNet on (preds + gumbel)/temperature with
+ * gumbel = -log(-log(u + 1e-20) + 1e-20); `unif` [B,L] holds the uniform draws u (the reference: torch.rand). */
+int ptr_stlistnet_fwd_bwd(const float *preds, const float *labels, const float *unif, const int32_t *lens, int B, int L,
+                          float temperature, float *loss_out, float *loss_q, float *grad, void *stream);
+/* RankMSE — replaces ptranking/ltr_adhoc/pointwise/rank_mse.py:13-22: mean over the B queries of sum_i (s_i - y_i)^2
+ * (loss_q holds the per-query sums; loss_out and grad carry the 1/B). */
+int ptr_rankmse_fwd_bwd(const float *preds, const float *labels, const int32_t *lens, int B, int L, float *loss_out,
+                        float *loss_q, float *grad, void *stream);
+/* RankCosine — replaces ptranking/ltr_adhoc/listwise/rank_cosine.py:15,32: sum_q (1 - cos(s_q, y_q)) / 0.5,
+ * nn.CosineSimilarity(dim=1, eps=1e-8). */
+int ptr_rankcosine_fwd_bwd(const float *preds, const float *labels, const int32_t *lens, int B, int L, float *loss_out,
+                           float *loss_q, float *grad, void *stream);
+
 /* ListMLE — replaces ptranking/ltr_adhoc/listwise/listmle.py:82,92-97 and its backward.  `perm` (int64[B,L]) is
  * the tie-shuffled label-descending order the reference obtains from arg_shuffle_ties
  * (ptranking/ltr_adhoc/util/sampling_utils.py:13-28); row q holds a permutation of 0..len_q-1 in its first len_q

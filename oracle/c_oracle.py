@@ -91,6 +91,23 @@ def listnet(preds, labels, lens=None):
     return _pair_loss(lib().orc_listnet, preds, labels, lens)
 
 
+def stlistnet(preds, labels, unif, temperature=1.0, lens=None):
+    preds, labels, unif = _f(preds), _f(labels), _f(unif); B, L = preds.shape; lens = _lens(lens)
+    loss_q = np.empty(B, np.float32); grad = np.empty((B, L), np.float32)
+    _chk(lib().orc_stlistnet(_p(preds), _p(labels), _p(unif), _p(lens, _i32p), B, L, C.c_float(temperature), _p(loss_q), _p(grad)),
+         "stlistnet")
+    return loss_q, grad
+
+
+def rankmse(preds, labels, lens=None):
+    """-> (per-query sums of squared errors [B] — the batch loss is their mean —, grad incl. the 1/B)"""
+    return _pair_loss(lib().orc_rankmse, preds, labels, lens)
+
+
+def rankcosine(preds, labels, lens=None):
+    return _pair_loss(lib().orc_rankcosine, preds, labels, lens)
+
+
 def listmle(preds, perm, lens=None):
     preds = _f(preds); B, L = preds.shape; lens = _lens(lens)
     perm = np.ascontiguousarray(perm, dtype=np.int64)

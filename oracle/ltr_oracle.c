@@ -311,6 +311,72 @@ int orc_listnet(const float *preds, const float *labels, const int32_t *lens, in
     return ORC_OK;
 }
 
+/* STListNet — ptranking/ltr_adhoc/listwise/st_listnet.py:41-49 with the uniform draws `unif` supplied by the caller. */
+int orc_stlistnet(const float *preds, const float *labels, const float *unif, const int32_t *lens, int B, int L, float temperature,
+                  float *loss_q, float *grad) {
+    float *z = (float *)malloc(sizeof(float) * (size_t)(L > 0 ? L : 1));
+    if (!z) return ORC_ENOMEM;
+    for (int q = 0; q < B; ++q) {
+        const float *s = preds + (size_t)q * L, *y = labels + (size_t)q * L, *u = unif + (size_t)q * L;
+        float *g = grad + (size_t)q * L;
+        int n = qlen(lens, q, L);
+        memset(g, 0, sizeof(float) * (size_t)L);
+        if (n == 0) { loss_q[q] = 0.0f; continue; }
+        float mz = -INFINITY, my = -INFINITY;
+        for (int i = 0; i < n; ++i) {
+            z[i] = (s[i] + -logf(-logf(u[i] + 1e-20f) + 1e-20f)) / temperature;
+            if (z[i] > mz) mz = z[i];
+            if (y[i] > my) my = y[i];
+        }
+        double zsd = 0.0, zyd = 0.0, loss = 0.0;
+        for (int i = 0; i < n; ++i) { zsd += expf(z[i] - mz); zyd += expf(y[i] - my); }
+        float lzs = logf((float)zsd), zy = (float)zyd;
+        for (int i = 0; i < n; ++i) {
+            float py = expf(y[i] - my) / zy, lsm = (z[i] - mz) - lzs;
+            loss -= py * lsm;
+            g[i] = (expf(lsm) - py) / temperature;
+        }
+        loss_q[q] = (float)loss;
+    }
+    free(z);
+    return ORC_OK;
+}
+
+/* RankMSE — ptranking/ltr_adhoc/pointwise/rank_mse.py:13-22: loss_q = per-query sum of squared errors (the batch loss is
+ * their MEAN over the B queries), grad = 2 (s - y) / B. */
+int orc_rankmse(const float *preds, const float *labels, const int32_t *lens, int B, int L, float *loss_q, float *grad) {
+    for (int q = 0; q < B; ++q) {
+        int n = qlen(lens, q, L);
+        double acc = 0.0;
+        for (int i = 0; i < L; ++i) {
+            size_t o = (size_t)q * L + i;
+            grad[o] = 0.0f;
+            if (i < n) { float d = preds[o] - labels[o]; acc += (double)d * d; grad[o] = 2.0f * d / (float)B; }
+        }
+        loss_q[q] = (float)acc;
+    }
+    return ORC_OK;
+}
+
+/* RankCosine — ptranking/ltr_adhoc/listwise/rank_cosine.py:15,32; nn.CosineSimilarity(dim=1, eps=1e-8). */
+int orc_rankcosine(const float *preds, const float *labels, const int32_t *lens, int B, int L, float *loss_q, float *grad) {
+    const float eps = 1e-8f;
+    for (int q = 0; q < B; ++q) {
+        const float *s = preds + (size_t)q * L, *y = labels + (size_t)q * L;
+        float *g = grad + (size_t)q * L;
+        int n = qlen(lens, q, L);
+        double sy = 0.0, ss = 0.0, yy = 0.0;
+        for (int i = 0; i < n; ++i) { sy += (double)s[i] * y[i]; ss += (double)s[i] * s[i]; yy += (double)y[i] * y[i]; }
+        float ns = sqrtf((float)ss), ny = sqrtf((float)yy);
+        float ds = ns > eps ? ns : eps, dy = ny > eps ? ny : eps;
+        float c = (float)sy / (ds * dy);
+        for (int i = 0; i < L; ++i)
+            g[i] = i < n ? -2.0f * (y[i] / (ds * dy) - (ns > eps ? c * s[i] / (float)ss : 0.0f)) : 0.0f;
+        loss_q[q] = (1.0f - c) / 0.5f;
+    }
+    return ORC_OK;
+}
+
 /* ListMLE — ptranking/ltr_adhoc/listwise/listmle.py:81-97 with the tie-shuffled permutation `perm`
  * (int64, what arg_shuffle_ties returns, ptranking/ltr_adhoc/util/sampling_utils.py:13-28) supplied by the caller. */
 int orc_listmle(const float *preds, const int64_t *perm, const int32_t *lens, int B, int L, float *loss_q, float *grad) {

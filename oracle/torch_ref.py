@@ -153,6 +153,27 @@ def listnet_loss(preds, labels):
     return torch.sum(-torch.sum(F.softmax(labels, dim=1) * F.log_softmax(preds, dim=1), dim=1))
 
 
+def gumbel_from_uniform(unif):
+    """ptranking/ltr_adhoc/listwise/st_listnet.py:18,43 (EPS = 1e-20)."""
+    return -torch.log(-torch.log(unif + 1e-20) + 1e-20)
+
+
+def stlistnet_loss(preds, labels, unif, temperature=1.0):
+    """ptranking/ltr_adhoc/listwise/st_listnet.py:41-49 with the uniform draws supplied by the caller."""
+    z = (preds + gumbel_from_uniform(unif)) / temperature
+    return torch.sum(-torch.sum(F.softmax(labels, dim=1) * F.log_softmax(z, dim=1), dim=1))
+
+
+def rankmse_loss(preds, labels):
+    """ptranking/ltr_adhoc/pointwise/rank_mse.py:13-22."""
+    return torch.mean(torch.sum(F.mse_loss(preds, labels, reduction="none"), dim=1))
+
+
+def rankcosine_loss(preds, labels):
+    """ptranking/ltr_adhoc/listwise/rank_cosine.py:15,32."""
+    return torch.sum((1.0 - torch.nn.CosineSimilarity(dim=1)(preds, labels)) / 0.5)
+
+
 def arg_shuffle_ties(labels, generator=None):
     """Random tie-broken descending order; ptranking/ltr_adhoc/util/sampling_utils.py:13-28."""
     B, L = labels.shape

@@ -27,6 +27,9 @@ SIGNATURES = {
     "ptr_approxndcg_fwd_bwd": [_vp, _vp, _vp, _i, _i, _f, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp],
     "ptr_listnet_fwd_bwd": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
     "ptr_listmle_fwd_bwd": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
+    "ptr_stlistnet_fwd_bwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp],
+    "ptr_rankmse_fwd_bwd": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
+    "ptr_rankcosine_fwd_bwd": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
     "ptr_shuffle_ties_order": [_vp, _vp, _i, _i, _u64, _vp, _vp],
     "ptr_sort_desc": [_vp, _vp, _i, _i, _vp, _vp, _vp],
     "ptr_metrics_at_ks": [_vp, _vp, _vp, _i, _i, C.POINTER(C.c_int32), _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -17,9 +17,13 @@ static inline int waves_per_block(size_t bytes_per_query) {
 
 // ------------------------------------------------------------------------------------------------ ListNet
 // loss_q = -sum_i softmax(labels)_i * log_softmax(preds)_i ; grad_i = softmax(preds)_i * sum_j softmax(labels)_j - softmax(labels)_i
+// STListNet (ptranking/ltr_adhoc/listwise/st_listnet.py:41-49): the same loss on (preds + gumbel) / temperature with
+// gumbel = -log(-log(u + 1e-20) + 1e-20), u = `unif` (the reference draws it with torch.rand); unif == nullptr, inv_temp == 1
+// is plain ListNet.  d loss / d preds picks up the 1/temperature factor.
 __global__ void __launch_bounds__(kBlock)
-listnet_kernel(const float *__restrict__ preds, const float *__restrict__ labels, const int32_t *__restrict__ lens, int B, int L,
-               int Lp, float *__restrict__ loss_q, float *__restrict__ grad) {
+listnet_kernel(const float *__restrict__ preds, const float *__restrict__ labels, const float *__restrict__ unif,
+               const int32_t *__restrict__ lens, int B, int L, int Lp, float inv_temp, float *__restrict__ loss_q,
+               float *__restrict__ grad) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
     const int q = blockIdx.x * wpb + wv;
@@ -30,7 +34,12 @@ listnet_kernel(const float *__restrict__ preds, const float *__restrict__ labels
 
     float ms = -INFINITY, my = -INFINITY;
     for (int i = lane; i < n; i += 64) {
-        const float a = ps[i], b = py[i];
+        float a = ps[i];
+        const float b = py[i];
+        if (unif) {
+            const float u = unif[(size_t)q * L + i];
+            a = (a + -logf(-logf(u + 1e-20f) + 1e-20f)) * inv_temp;      // st_listnet.py:41-45 ((x + g) / T as a multiply by 1/T)
+        }
         s[i] = a; y[i] = b;
         ms = fmaxf(ms, a); my = fmaxf(my, b);
     }
@@ -53,7 +62,7 @@ listnet_kernel(const float *__restrict__ preds, const float *__restrict__ labels
     }
     loss = wave_sum(loss); sumpy = wave_sum(sumpy);
     float *g = grad + (size_t)q * L;
-    for (int i = lane; i < L; i += 64) g[i] = i < n ? expf(s[i]) * sumpy - y[i] : 0.0f;   // log_softmax backward
+    for (int i = lane; i < L; i += 64) g[i] = i < n ? (expf(s[i]) * sumpy - y[i]) * inv_temp : 0.0f;   // log_softmax backward
     if (lane == 0) loss_q[q] = loss;
 }
 
@@ -117,6 +126,57 @@ listmle_kernel(const float *__restrict__ preds, const int64_t *__restrict__ perm
     float *g = grad + (size_t)q * L;
     for (int i = lane; i < L; i += 64) g[i] = i < n ? s[i] : 0.0f;
     if (lane == 0) loss_q[q] = loss;
+}
+
+// ------------------------------------------------------------------------------------------------ RankMSE / RankCosine
+// RankMSE (ptranking/ltr_adhoc/pointwise/rank_mse.py:13-22): mean over queries of sum_i (s_i - y_i)^2.  loss_q holds the
+// per-query sums; the caller's reduction applies 1/B, the gradient 2 (s - y) / B is written here.
+__global__ void __launch_bounds__(kBlock)
+rankmse_kernel(const float *__restrict__ preds, const float *__restrict__ labels, const int32_t *__restrict__ lens, int B, int L,
+               float inv_b, float *__restrict__ loss_q, float *__restrict__ grad) {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    const int q = blockIdx.x * wpb + wv;
+    if (q >= B) return;
+    const int n = query_len(lens, q, L);
+    float acc = 0.0f;
+    for (int i = lane; i < L; i += 64) {
+        float gi = 0.0f;
+        if (i < n) {
+            const float d = preds[(size_t)q * L + i] - labels[(size_t)q * L + i];
+            acc = fmaf(d, d, acc);
+            gi = 2.0f * d * inv_b;
+        }
+        grad[(size_t)q * L + i] = gi;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) loss_q[q] = acc;
+}
+
+// RankCosine (ptranking/ltr_adhoc/listwise/rank_cosine.py:15,32): sum over queries of (1 - cos(s, y)) / 0.5 with
+// nn.CosineSimilarity(dim=1, eps=1e-8) = <s,y> / (max(|s|, eps) * max(|y|, eps)).
+__global__ void __launch_bounds__(kBlock)
+rankcosine_kernel(const float *__restrict__ preds, const float *__restrict__ labels, const int32_t *__restrict__ lens, int B, int L,
+                  float *__restrict__ loss_q, float *__restrict__ grad) {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    const int q = blockIdx.x * wpb + wv;
+    if (q >= B) return;
+    const int n = query_len(lens, q, L);
+    const float *ps = preds + (size_t)q * L, *py = labels + (size_t)q * L;
+    float sy = 0.0f, ss = 0.0f, yy = 0.0f;
+    for (int i = lane; i < n; i += 64) {
+        const float a = ps[i], b = py[i];
+        sy = fmaf(a, b, sy); ss = fmaf(a, a, ss); yy = fmaf(b, b, yy);
+    }
+    sy = wave_sum(sy); ss = wave_sum(ss); yy = wave_sum(yy);
+    const float eps = 1e-8f;
+    const float ns = sqrtf(ss), ny = sqrtf(yy);
+    const float ds = fmaxf(ns, eps), dy = fmaxf(ny, eps);
+    const float c = sy / (ds * dy);
+    // d cos / d s_i = y_i / (ds dy) - [ns > eps] * cos * s_i / ns^2
+    const float k1 = 1.0f / (ds * dy), k2 = ns > eps ? c / ss : 0.0f;
+    float *g = grad + (size_t)q * L;
+    for (int i = lane; i < L; i += 64) g[i] = i < n ? -2.0f * (py[i] * k1 - k2 * ps[i]) : 0.0f;
+    if (lane == 0) loss_q[q] = (1.0f - c) / 0.5f;
 }
 
 // ------------------------------------------------------------------------------------------------ tie shuffle
@@ -217,7 +277,53 @@ extern "C" int ptr_listnet_fwd_bwd(const float *preds, const float *labels, cons
         const int wpb = waves_per_block(per_q);
         if (int e = allow_lds(listnet_kernel, wpb * per_q)) return e;
         hipLaunchKernelGGL(listnet_kernel, dim3((B + wpb - 1) / wpb), dim3(wpb * kWave), wpb * per_q, as_stream(stream), preds, labels,
-                           lens, B, L, Lp, loss_q, grad);
+                           (const float *)nullptr, lens, B, L, Lp, 1.0f, loss_q, grad);
+        if (int rc = check_hip(hipGetLastError(), who)) return rc;
+    }
+    return loss_out ? ptr_sum_f32(loss_q, B, 1.0f, loss_out, stream) : 0;
+}
+
+extern "C" int ptr_stlistnet_fwd_bwd(const float *preds, const float *labels, const float *unif, const int32_t *lens, int B, int L,
+                                     float temperature, float *loss_out, float *loss_q, float *grad, void *stream) {
+    using namespace ptr;
+    const char *who = "ptr_stlistnet_fwd_bwd";
+    if (int rc = check_batch(preds, labels, B, L, who)) return rc;
+    if (B > 0 && (!loss_q || !grad || !unif)) { set_error("%s: NULL pointer", who); return PTR_ERR_INVALID_ARG; }
+    if (!(temperature > 0.0f)) { set_error("%s: temperature must be > 0 (got %g)", who, (double)temperature); return PTR_ERR_INVALID_ARG; }
+    if (B > 0) {
+        const int Lp = round_up(L, 4);
+        const size_t per_q = 2 * (size_t)Lp * sizeof(float);
+        const int wpb = waves_per_block(per_q);
+        if (int e = allow_lds(listnet_kernel, wpb * per_q)) return e;
+        hipLaunchKernelGGL(listnet_kernel, dim3((B + wpb - 1) / wpb), dim3(wpb * kWave), wpb * per_q, as_stream(stream), preds, labels,
+                           unif, lens, B, L, Lp, 1.0f / temperature, loss_q, grad);
+        if (int rc = check_hip(hipGetLastError(), who)) return rc;
+    }
+    return loss_out ? ptr_sum_f32(loss_q, B, 1.0f, loss_out, stream) : 0;
+}
+
+extern "C" int ptr_rankmse_fwd_bwd(const float *preds, const float *labels, const int32_t *lens, int B, int L, float *loss_out,
+                                   float *loss_q, float *grad, void *stream) {
+    using namespace ptr;
+    const char *who = "ptr_rankmse_fwd_bwd";
+    if (int rc = check_batch(preds, labels, B, L, who)) return rc;
+    if (B > 0 && (!loss_q || !grad)) { set_error("%s: NULL output pointer", who); return PTR_ERR_INVALID_ARG; }
+    if (B > 0) {
+        hipLaunchKernelGGL(rankmse_kernel, dim3((B + 3) / 4), dim3(kBlock), 0, as_stream(stream), preds, labels, lens, B, L, 1.0f / (float)B,
+                           loss_q, grad);
+        if (int rc = check_hip(hipGetLastError(), who)) return rc;
+    }
+    return loss_out ? ptr_sum_f32(loss_q, B, B > 0 ? 1.0f / (float)B : 0.0f, loss_out, stream) : 0;
+}
+
+extern "C" int ptr_rankcosine_fwd_bwd(const float *preds, const float *labels, const int32_t *lens, int B, int L, float *loss_out,
+                                      float *loss_q, float *grad, void *stream) {
+    using namespace ptr;
+    const char *who = "ptr_rankcosine_fwd_bwd";
+    if (int rc = check_batch(preds, labels, B, L, who)) return rc;
+    if (B > 0 && (!loss_q || !grad)) { set_error("%s: NULL output pointer", who); return PTR_ERR_INVALID_ARG; }
+    if (B > 0) {
+        hipLaunchKernelGGL(rankcosine_kernel, dim3((B + 3) / 4), dim3(kBlock), 0, as_stream(stream), preds, labels, lens, B, L, loss_q, grad);
         if (int rc = check_hip(hipGetLastError(), who)) return rc;
     }
     return loss_out ? ptr_sum_f32(loss_q, B, 1.0f, loss_out, stream) : 0;

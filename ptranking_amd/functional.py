@@ -13,6 +13,7 @@ import torch
 from . import _lib
 
 __all__ = ["ranknet_loss", "lambdarank_loss", "lambdaloss_loss", "approxndcg_loss", "listnet_loss", "listmle_loss",
+           "stlistnet_loss", "rankmse_loss", "rankcosine_loss",
            "shuffle_ties_order", "sort_desc", "metrics_at_ks", "sum_f32", "LAMBDALOSS_TYPES"]
 
 LAMBDALOSS_TYPES = {"NDCG_Loss2": 1, "NDCG_Loss2++": 2}   # ptranking/ltr_adhoc/listwise/lambdaloss.py:27
@@ -106,6 +107,52 @@ def lambdaloss_loss(preds, labels, k=5, sigma=1.0, mu=5.0, loss_type="NDCG_Loss2
 def listnet_loss(preds, labels, lens=None):
     """ListNet, ptranking/ltr_adhoc/listwise/listnet.py:39."""
     return _simple("ptr_listnet_fwd_bwd", preds, labels, lens)
+
+
+def rankmse_loss(preds, labels, lens=None):
+    """RankMSE, ptranking/ltr_adhoc/pointwise/rank_mse.py:13-22 (mean over queries of the per-query squared error sums)."""
+    preds_c, labels, lens, B, L = _batch(preds.detach(), labels, lens)
+    dev = preds_c.device
+
+    def launch(p):
+        loss_q = torch.empty(max(B, 1), device=dev, dtype=torch.float32)
+        grad = torch.empty((B, L), device=dev, dtype=torch.float32)
+        out = torch.empty(1, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.call("ptr_rankmse_fwd_bwd", _lib.ptr(p), _lib.ptr(labels), _lib.ptr(lens), B, L, _lib.ptr(out), _lib.ptr(loss_q),
+                      _lib.ptr(grad), _lib.current_stream(dev))
+        return out.reshape(()), grad
+
+    if preds.requires_grad:
+        return _FusedLoss.apply(preds if preds.is_contiguous() else preds.contiguous(), lambda p: launch(p.detach()))
+    return launch(preds_c)[0]
+
+
+def rankcosine_loss(preds, labels, lens=None):
+    """RankCosine, ptranking/ltr_adhoc/listwise/rank_cosine.py:32."""
+    return _simple("ptr_rankcosine_fwd_bwd", preds, labels, lens)
+
+
+def stlistnet_loss(preds, labels, temperature=1.0, unif=None, lens=None):
+    """STListNet, ptranking/ltr_adhoc/listwise/st_listnet.py:41-49.  `unif` = the uniform draws the Gumbel noise is made of
+    (default: torch.rand on the device, as the reference does)."""
+    preds_c, labels, lens, B, L = _batch(preds.detach(), labels, lens)
+    dev = preds_c.device
+    if unif is None:
+        unif = torch.rand((B, L), device=dev)
+    unif = _check("unif", unif, torch.float32, (B, L))
+
+    def launch(p):
+        loss_q = torch.empty(max(B, 1), device=dev, dtype=torch.float32)
+        grad = torch.empty((B, L), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.call("ptr_stlistnet_fwd_bwd", _lib.ptr(p), _lib.ptr(labels), _lib.ptr(unif), _lib.ptr(lens), B, L,
+                      C.c_float(float(temperature)), None, _lib.ptr(loss_q), _lib.ptr(grad), _lib.current_stream(dev))
+            return _reduce(loss_q, B, dev), grad
+
+    if preds.requires_grad:
+        return _FusedLoss.apply(preds if preds.is_contiguous() else preds.contiguous(), lambda p: launch(p.detach()))
+    return launch(preds_c)[0]
 
 
 def listmle_loss(preds, perm, lens=None):

@@ -1,4 +1,4 @@
-"""The six ltr_adhoc rankers of the hot path as drop-in replacements for the reference classes of the same name.
+"""The ltr_adhoc rankers of the hot path (the six losses of the north star + the sibling losses of SURVEY.md §8 f-4) as drop-in replacements for the reference classes of the same name.
 
 Each class keeps the reference's constructor signature and `custom_loss_function` contract (consume `batch_preds`
 attached to the scorer graph + `batch_std_labels`, do zero_grad -> backward -> optimizer.step itself, return the scalar
@@ -16,7 +16,7 @@ from . import functional as F_
 from .host import DeviceEvaluator, DeviceTrainLoop, PointScorerRanker, is_multilabel
 from .scorer import FusedScorerMixin
 
-RANKER_NAMES = ("RankNet", "LambdaRank", "LambdaLoss", "ApproxNDCG", "ListNet", "ListMLE")
+RANKER_NAMES = ("RankNet", "LambdaRank", "LambdaLoss", "ApproxNDCG", "ListNet", "ListMLE", "STListNet", "RankCosine", "RankMSE")
 
 # default hyper-parameters = the reference's `default_para_dict()`s
 DEFAULT_PARAS = {
@@ -26,6 +26,9 @@ DEFAULT_PARAS = {
     "ApproxNDCG": dict(model_id="ApproxNDCG", alpha=10),                               # listwise/approxNDCG.py:131
     "ListNet": dict(model_id="ListNet"),
     "ListMLE": dict(model_id="ListMLE"),
+    "STListNet": dict(model_id="STListNet", temperature=1.0),                          # listwise/st_listnet.py:70
+    "RankCosine": dict(model_id="RankCosine"),
+    "RankMSE": dict(model_id="RankMSE"),
 }
 
 
@@ -118,6 +121,26 @@ class ListNetLoss(FusedStepMixin):
         return self._fused_step(F_.listnet_loss(batch_preds, batch_std_labels, lens=kwargs.get('lens')))
 
 
+class STListNetLoss(FusedStepMixin):
+    def custom_loss_function(self, batch_preds, batch_std_labels, **kwargs):
+        """ptranking/ltr_adhoc/listwise/st_listnet.py:33-55"""
+        unif = torch.rand(batch_preds.size(), device=batch_preds.device)  # [batch_size, ranking_size]
+        return self._fused_step(F_.stlistnet_loss(batch_preds, batch_std_labels, temperature=self.temperature, unif=unif,
+                                                  lens=kwargs.get('lens')))
+
+
+class RankCosineLoss(FusedStepMixin):
+    def custom_loss_function(self, batch_preds, batch_std_labels, **kwargs):
+        """ptranking/ltr_adhoc/listwise/rank_cosine.py:24-38"""
+        return self._fused_step(F_.rankcosine_loss(batch_preds, batch_std_labels, lens=kwargs.get('lens')))
+
+
+class RankMSELoss(FusedStepMixin):
+    def custom_loss_function(self, batch_preds, batch_std_labels, **kwargs):
+        """ptranking/ltr_adhoc/pointwise/rank_mse.py:29-40"""
+        return self._fused_step(F_.rankmse_loss(batch_preds, batch_std_labels, lens=kwargs.get('lens')))
+
+
 class ListMLELoss(FusedStepMixin):
     tie_shuffle = "torch"     # "torch": the reference's randperm stream (parity); "device": counter-based HIP kernel
     _tie_seed = 137           # ptranking/ltr_global.py:7
@@ -181,8 +204,21 @@ def make_ranker_classes(base=PointScorerRanker):
         def __init__(self, sf_para_dict=None, model_para_dict=None, gpu=False, device=None):
             base.__init__(self, id='ListMLE', sf_para_dict=sf_para_dict, gpu=gpu, device=device)
 
+    class STListNet(STListNetLoss, FusedScorerMixin, DeviceTrainLoop, DeviceEvaluator, base):
+        def __init__(self, sf_para_dict=None, model_para_dict=None, gpu=False, device=None):
+            base.__init__(self, id='STListNet', sf_para_dict=sf_para_dict, gpu=gpu, device=device)
+            self.temperature = model_para_dict['temperature']
+
+    class RankCosine(RankCosineLoss, FusedScorerMixin, DeviceTrainLoop, DeviceEvaluator, base):
+        def __init__(self, sf_para_dict=None, gpu=False, device=None):
+            base.__init__(self, id='RankCosine', sf_para_dict=sf_para_dict, gpu=gpu, device=device)
+
+    class RankMSE(RankMSELoss, FusedScorerMixin, DeviceTrainLoop, DeviceEvaluator, base):
+        def __init__(self, sf_para_dict=None, gpu=False, device=None):
+            base.__init__(self, id='RankMSE', sf_para_dict=sf_para_dict, gpu=gpu, device=device)
+
     out = dict(RankNet=RankNet, LambdaRank=LambdaRank, LambdaLoss=LambdaLoss, ApproxNDCG=ApproxNDCG, ListNet=ListNet,
-               ListMLE=ListMLE)
+               ListMLE=ListMLE, STListNet=STListNet, RankCosine=RankCosine, RankMSE=RankMSE)
     for name, cls in out.items():
         cls.__name__ = cls.__qualname__ = name
         cls.__module__ = __name__
@@ -192,3 +228,4 @@ def make_ranker_classes(base=PointScorerRanker):
 _standalone = make_ranker_classes(PointScorerRanker)
 RankNet, LambdaRank, LambdaLoss = _standalone["RankNet"], _standalone["LambdaRank"], _standalone["LambdaLoss"]
 ApproxNDCG, ListNet, ListMLE = _standalone["ApproxNDCG"], _standalone["ListNet"], _standalone["ListMLE"]
+STListNet, RankCosine, RankMSE = _standalone["STListNet"], _standalone["RankCosine"], _standalone["RankMSE"]

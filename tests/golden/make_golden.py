@@ -48,6 +48,9 @@ from ptranking.ltr_adhoc.listwise.lambdaloss import LambdaLoss
 from ptranking.ltr_adhoc.listwise.approxNDCG import ApproxNDCG
 from ptranking.ltr_adhoc.listwise.listnet import ListNet
 from ptranking.ltr_adhoc.listwise.listmle import ListMLE
+from ptranking.ltr_adhoc.listwise.st_listnet import STListNet
+from ptranking.ltr_adhoc.listwise.rank_cosine import RankCosine
+from ptranking.ltr_adhoc.pointwise.rank_mse import RankMSE
 import ptranking.ltr_adhoc.listwise.listmle as ref_listmle_mod
 from ptranking.metric.adhoc.adhoc_metric import (
     torch_ndcg_at_k, torch_ndcg_at_ks, torch_ap_at_k, torch_ap_at_ks,
@@ -211,6 +214,40 @@ def gen_losses():
     print(f"losses.npz: {len(store)} arrays, {len(set(k.rsplit('/', 1)[0] for k in store))} cases")
 
 
+def gen_siblings():
+    """STListNet (st_listnet.py:33-55), RankCosine (rank_cosine.py:24-38), RankMSE (rank_mse.py:13-40)."""
+    store = {}
+    rng = np.random.default_rng(SEED + 7)
+    for ci, (B, L) in enumerate([(3, 8), (4, 32), (2, 128), (2, 300)]):
+        preds, labels = synth(rng, B, L)
+        loss, grad = run_loss(RankMSE(sf_para_dict=SF, device="cpu"), preds, labels)
+        add(store, f"rankmse/c{ci}", preds=preds, labels=labels, loss=loss, grad=grad)
+        loss, grad = run_loss(RankCosine(sf_para_dict=SF, device="cpu"), preds, labels)
+        add(store, f"rankcosine/c{ci}", preds=preds, labels=labels, loss=loss, grad=grad)
+        for T in (1.0, 2.5):
+            captured = {}
+            orig_rand = torch.rand
+
+            def spy(*a, **k):
+                out = orig_rand(*a, **k)
+                captured["unif"] = out.numpy().astype(np.float32).copy()
+                return out
+
+            torch.rand = spy
+            try:
+                loss, grad = run_loss(STListNet(sf_para_dict=SF, model_para_dict={"temperature": T}, device="cpu"), preds, labels)
+            finally:
+                torch.rand = orig_rand
+            add(store, f"stlistnet/c{ci}_t{T:g}", preds=preds, labels=labels, unif=captured["unif"], temperature=np.float32(T),
+                loss=loss, grad=grad)
+    zp = np.zeros((2, 5), np.float32)                                  # zero score vector: CosineSimilarity's eps path
+    zl = np.array([[2, 1, 1, 0, 0], [1, 0, 0, 0, 0]], np.float32)
+    loss, grad = run_loss(RankCosine(sf_para_dict=SF, device="cpu"), zp, zl)
+    add(store, "rankcosine/zero", preds=zp, labels=zl, loss=loss, grad=grad)
+    np.savez_compressed(os.path.join(HERE, "siblings.npz"), **store)
+    print(f"siblings.npz: {len(store)} arrays")
+
+
 def gen_metrics():
     store = {}
     # --- the reference's own known-answer vectors, testing/metric/testing_metric.py:17-61 ---
@@ -265,6 +302,8 @@ def gen_metrics():
 
 
 if __name__ == "__main__":
-    gen_losses()
-    gen_metrics()
+    if "--only-siblings" not in sys.argv:
+        gen_losses()
+        gen_metrics()
+    gen_siblings()
     print("torch", torch.__version__, "numpy", np.__version__)

@@ -52,6 +52,12 @@ def metrics():
     return _CACHE["m"]
 
 
+def siblings():
+    if "s" not in _CACHE:
+        _CACHE["s"] = _load("siblings.npz")
+    return _CACHE["s"]
+
+
 def case_ids(fam, which="losses"):
-    d = losses() if which == "losses" else metrics()
+    d = {"losses": losses, "metrics": metrics, "siblings": siblings}[which]()
     return sorted(d[fam].keys())

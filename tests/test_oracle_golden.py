@@ -193,3 +193,31 @@ def test_c_oracle_padding_equals_unpadded():
             assert np.allclose(lq[b], lq1[0], rtol=1e-6, atol=1e-6)
             assert np.allclose(g[b, :n], g1[0], rtol=1e-6, atol=1e-6)
             assert np.all(g[b, n:] == 0)
+
+
+# =================================================================== sibling losses
+@pytest.mark.parametrize("name", G.case_ids("rankmse", "siblings"))
+def test_rankmse_oracles(name):
+    c = G.siblings()["rankmse"][name]
+    loss, grad = T.loss_and_grad(T.rankmse_loss, _t(c["preds"]), _t(c["labels"]))
+    G.assert_close(loss.numpy(), c["loss"], "torch loss"); G.assert_close(grad.numpy(), c["grad"], "torch grad")
+    lq, g = CO.rankmse(c["preds"], c["labels"])
+    G.assert_close(lq.astype(np.float64).mean(), c["loss"], "C loss"); G.assert_close(g, c["grad"], "C grad")
+
+
+@pytest.mark.parametrize("name", G.case_ids("rankcosine", "siblings"))
+def test_rankcosine_oracles(name):
+    c = G.siblings()["rankcosine"][name]
+    loss, grad = T.loss_and_grad(T.rankcosine_loss, _t(c["preds"]), _t(c["labels"]))
+    G.assert_close(loss.numpy(), c["loss"], "torch loss"); G.assert_close(grad.numpy(), c["grad"], "torch grad")
+    lq, g = CO.rankcosine(c["preds"], c["labels"])
+    G.assert_close(lq.astype(np.float64).sum(), c["loss"], "C loss"); G.assert_close(g, c["grad"], "C grad")
+
+
+@pytest.mark.parametrize("name", G.case_ids("stlistnet", "siblings"))
+def test_stlistnet_oracles(name):
+    c = G.siblings()["stlistnet"][name]
+    loss, grad = T.loss_and_grad(T.stlistnet_loss, _t(c["preds"]), _t(c["labels"]), _t(c["unif"]), temperature=float(c["temperature"]))
+    G.assert_close(loss.numpy(), c["loss"], "torch loss"); G.assert_close(grad.numpy(), c["grad"], "torch grad")
+    lq, g = CO.stlistnet(c["preds"], c["labels"], c["unif"], float(c["temperature"]))
+    G.assert_close(lq.astype(np.float64).sum(), c["loss"], "C loss"); G.assert_close(g, c["grad"], "C grad")

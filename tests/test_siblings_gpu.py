@@ -1,0 +1,72 @@
+"""GPU: STListNet / RankCosine / RankMSE — HIP vs the reference's golden outputs and vs the oracle."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as G
+from test_parity_gpu import dev, loss_and_grad, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def F():
+    from ptranking_amd import functional
+    return functional
+
+
+@pytest.mark.parametrize("name", G.case_ids("rankmse", "siblings"))
+def test_golden_rankmse(F, name):
+    c = G.siblings()["rankmse"][name]
+    loss, grad = loss_and_grad(F.rankmse_loss, c["preds"], dev(c["labels"]))
+    G.assert_close(loss, c["loss"], "loss"); G.assert_close(grad, c["grad"], "grad")
+
+
+@pytest.mark.parametrize("name", G.case_ids("rankcosine", "siblings"))
+def test_golden_rankcosine(F, name):
+    c = G.siblings()["rankcosine"][name]
+    loss, grad = loss_and_grad(F.rankcosine_loss, c["preds"], dev(c["labels"]))
+    G.assert_close(loss, c["loss"], "loss"); G.assert_close(grad, c["grad"], "grad")
+
+
+@pytest.mark.parametrize("name", G.case_ids("stlistnet", "siblings"))
+def test_golden_stlistnet(F, name):
+    c = G.siblings()["stlistnet"][name]
+    loss, grad = loss_and_grad(F.stlistnet_loss, c["preds"], dev(c["labels"]), temperature=float(c["temperature"]), unif=dev(c["unif"]))
+    G.assert_close(loss, c["loss"], "loss"); G.assert_close(grad, c["grad"], "grad")
+
+
+@pytest.mark.parametrize("B,L", [(7, 5), (33, 128), (9, 700), (2, 4096)])
+@pytest.mark.parametrize("use_lens", [False, True])
+def test_oracle_siblings(F, B, L, use_lens):
+    from oracle import c_oracle as CO
+    preds, labels, ln = synth(5000 + L, B, L, lens=use_lens)
+    lens_t = None if ln is None else dev(ln)
+    unif = np.random.default_rng(L).random((B, L)).astype(np.float32)
+    loss, grad = loss_and_grad(F.rankmse_loss, preds, dev(labels), lens=lens_t)
+    lq, g = CO.rankmse(preds, labels, lens=ln)
+    G.assert_close(loss, lq.astype(np.float64).mean(), "rankmse loss"); G.assert_close(grad, g, "rankmse grad")
+    loss, grad = loss_and_grad(F.rankcosine_loss, preds, dev(labels), lens=lens_t)
+    lq, g = CO.rankcosine(preds, labels, lens=ln)
+    G.assert_close(loss, lq.astype(np.float64).sum(), "rankcosine loss"); G.assert_close(grad, g, "rankcosine grad")
+    loss, grad = loss_and_grad(F.stlistnet_loss, preds, dev(labels), temperature=2.0, unif=dev(unif), lens=lens_t)
+    lq, g = CO.stlistnet(preds, labels, unif, 2.0, lens=ln)
+    G.assert_close(loss, lq.astype(np.float64).sum(), "stlistnet loss"); G.assert_close(grad, g, "stlistnet grad")
+
+
+def test_sibling_rankers_train():
+    import ptranking_amd as pa
+    sf = {"sf_id": "pointsf", "opt": "Adam", "lr": 1e-3,
+          "pointsf": dict(num_features=24, num_layers=3, AF="R", TL_AF="S", apply_tl_af=False, BN=False, bn_type=None, bn_affine=False)}
+    X = torch.randn(6, 40, 24, device="cuda")
+    Y = torch.sort(torch.randint(0, 5, (6, 40), device="cuda").float(), dim=1, descending=True)[0].contiguous()
+    for name in ("STListNet", "RankCosine", "RankMSE"):
+        cls = getattr(pa, name)
+        r = cls(sf_para_dict=copy.deepcopy(sf), model_para_dict=dict(pa.DEFAULT_PARAS[name]), gpu=True, device="cuda:0") \
+            if name == "STListNet" else cls(sf_para_dict=copy.deepcopy(sf), gpu=True, device="cuda:0")
+        r.init(); r.train_mode()
+        before = r.point_sf.flat.detach().clone()
+        loss, stop = r.train_op(X, Y, epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
+        assert torch.isfinite(loss) and not stop and not torch.equal(before, r.point_sf.flat), name
