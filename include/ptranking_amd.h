@@ -147,6 +147,19 @@ int ptr_adam_step(float *param, const float *grad, float *exp_avg, float *exp_av
 /* Test helper: the dropout keep-mask (1.0 / 0.0) of dropout site `site` for an [R][n_feat] activation. */
 int ptr_mlp_dropout_mask(int R, int n_feat, int site, float p_drop, uint64_t seed, float *out, void *stream);
 
+/* ---- LETOR / libsvm text input (HOST buffers; the data format feeding the path) ---------------------------------------
+ * Replaces the pure-Python tokenizer ptranking/data/data_utils.py:276-387 (iter_lines / parse_letor):
+ *   "<label> qid:<id> <fid>:<val> ... [# comment]", feature ids one-indexed unless one_indexed == 0 (Yahoo! sets,
+ *   data_utils.py:495-496), absent features = `missing`, width = largest feature id in the file, values rounded
+ *   text -> double -> float (the reference's float() + FloatTensor cast, data_utils.py:610).
+ * Stateless two-call protocol: ptr_letor_scan sizes the file, the caller allocates, ptr_letor_load fills
+ *   X [n_docs][n_features] (float, or double when x_is_f64 — parse_letor's own precision, wanted before feature scaling),
+ *   y [n_docs], qids [n_queries], qoff [n_queries+1] (row range of every run of equal qids, in file
+ *   order; a non-numeric qid token is reported as a 63-bit FNV-1a hash).  Multi-threaded on the host; no GPU involved. */
+int ptr_letor_scan(const char *path, int one_indexed, int64_t *n_docs, int32_t *n_features, int64_t *n_queries);
+int ptr_letor_load(const char *path, int one_indexed, float missing, int64_t n_docs, int32_t n_features, int64_t n_queries,
+                   void *X, int x_is_f64, float *y, int64_t *qids, int64_t *qoff);
+
 #ifdef __cplusplus
 }
 #endif

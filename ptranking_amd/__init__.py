@@ -13,6 +13,7 @@ there is no CPU fallback.  Build it with `python -m ptranking_amd.build`.
 """
 from . import _lib, batching, dp, functional, host, rankers, scorer   # noqa: F401
 from .batching import PaddedQueryBatches            # noqa: F401
+from . import letor                                   # noqa: F401
 from .host import LABEL_TYPE, DeviceEvaluator       # noqa: F401
 from .install import install, uninstall             # noqa: F401
 from .rankers import (ApproxNDCG, LambdaLoss, LambdaRank, ListMLE, ListNet, RankNet, STListNet, RankCosine, RankMSE,  # noqa: F401

@@ -65,6 +65,17 @@ class PaddedQueryBatches:
                 hi = min(nq, lo + per)
                 self._batches.append((ids[lo:hi], Xd[lo:hi], Yd[lo:hi], Ld[lo:hi]))
 
+    @classmethod
+    def from_letor_file(cls, path, device, rough_batch_size=4096, pad_to=16, presort=True, shuffle=False, seed=137,
+                        **query_kwargs):
+        """LETOR text file -> padded device batches.  The file is tokenised by the native parser (csrc/letor.cpp) and
+        grouped / scaled / filtered by letor.load_letor_queries (**query_kwargs: min_docs, min_rele, binary_rele,
+        unknown_as_zero, scaler_id, one_indexed, ...) — the job of LTRDataset.__init__ + iter_queries
+        (ptranking/data/data_utils.py:420-549, :553-660)."""
+        from .letor import load_letor_queries
+        return cls(load_letor_queries(path, **query_kwargs), device, rough_batch_size=rough_batch_size, pad_to=pad_to,
+                   presort=presort, shuffle=shuffle, seed=seed)
+
     def __len__(self):
         return len(self._batches)
 

@@ -15,7 +15,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 OBJ_DIR = os.path.join(PKG_DIR, "csrc", "build")
 LIB_PATH = os.path.join(PKG_DIR, "libptranking_amd.so")
 ARCH = "gfx950"
-SOURCES = ["abi.hip", "pairwise.hip", "lambdaloss.hip", "approxndcg.hip", "listwise.hip", "metrics.hip", "scorer.hip"]
+SOURCES = ["abi.hip", "pairwise.hip", "lambdaloss.hip", "approxndcg.hip", "listwise.hip", "metrics.hip", "scorer.hip", "letor.cpp"]
 HEADERS = ["ptr_device.h", os.path.join("..", "..", "include", "ptranking_amd.h")]
 CXXFLAGS = ["-O3", "-std=c++20", "-fPIC", "-fno-gpu-rdc", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
             "-ffp-contract=off"]
@@ -45,10 +45,12 @@ def build(force=False, verbose=False):
     objs = []
     for s in srcs:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(OBJ_DIR, s.replace(".hip", ".o"))
+        obj = os.path.join(OBJ_DIR, os.path.splitext(s)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([hipcc] + CXXFLAGS + ["-c", src, "-o", obj])
+            flags = CXXFLAGS if s.endswith(".hip") else [f for f in CXXFLAGS if not f.startswith("--offload-arch")
+                                                              and f != "-fno-gpu-rdc"] + ["-pthread"]
+            jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
