@@ -37,6 +37,8 @@ extern "C" {
 #define PTR_ERR_INVALID_ARG 1001   /* NULL pointer, negative size, bad enum value               */
 #define PTR_ERR_UNSUPPORTED 1002   /* L > PTR_MAX_LIST_LEN, nk > PTR_MAX_CUTOFFS, ...            */
 
+#define PTR_LAMBDALOSS_NDCG_LOSS1 0    /* 'NDCG_Loss1'   (lambdaloss.py:33-34; the reference only runs it at batch size 1: its
+                                         [B,L] weights broadcast against [B,L,L]; here every query uses its own w_j)  */
 #define PTR_LAMBDALOSS_NDCG_LOSS2 1    /* 'NDCG_Loss2'   (ptranking/ltr_adhoc/listwise/lambdaloss.py:36-45) */
 #define PTR_LAMBDALOSS_NDCG_LOSS2PP 2  /* 'NDCG_Loss2++' (ptranking/ltr_adhoc/listwise/lambdaloss.py:47-58) */
 
@@ -63,6 +65,12 @@ int ptr_lambdarank_fwd_bwd(const float *preds, const float *labels, const int32_
 int ptr_lambdaloss_fwd_bwd(const float *preds, const float *labels, const int32_t *lens, int B, int L, int k,
                            float sigma, float mu, int loss_type, int presort, float *loss_out, float *loss_q,
                            float *grad, void *stream);
+
+/* SoftRank — replaces ptranking/ltr_adhoc/listwise/softrank.py:47-69 and its backward: expected ranks from
+ * 0.5*erfc((s_i-s_j)/sqrt(4*delta^2)), loss = -sum_q sum_{i<top_k} (2^l_i-1)/(log2(E[rank_i]+1)*IDCG_q).  Labels must be
+ * in ideal order (the reference asserts presort).  top_k <= 0: no truncation (top_k=None).  delta > 0. */
+int ptr_softrank_fwd_bwd(const float *preds, const float *labels, const int32_t *lens, int B, int L, float delta, int top_k,
+                         float *loss_out, float *loss_q, float *grad, void *stream);
 
 /* ApproxNDCG — replaces ptranking/ltr_adhoc/listwise/approxNDCG.py:19-27,45-62 (+ Robust_Sigmoid,
  * ptranking/base/utils.py:57-95) and its backward.  alpha must be > 0.

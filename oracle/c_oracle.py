@@ -87,6 +87,10 @@ def approxndcg(preds, labels, alpha=10.0, presort=True, couple_batch=True, lens=
     return loss[0], dcg, inv, grad
 
 
+def softrank(preds, labels, delta=2.0, top_k=None, lens=None):
+    return _pair_loss(lib().orc_softrank, preds, labels, lens, C.c_float(delta), C.c_int(int(top_k) if top_k else 0))
+
+
 def listnet(preds, labels, lens=None):
     return _pair_loss(lib().orc_listnet, preds, labels, lens)
 

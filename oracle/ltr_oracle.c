@@ -160,7 +160,7 @@ int orc_lambdarank(const float *preds, const float *labels, const int32_t *lens,
  * The reference's discount table is inverted twice (SURVEY.md §7 iii): inv[r] = (1/log2(r+2))^-1. */
 int orc_lambdaloss(const float *preds, const float *labels, const int32_t *lens, int B, int L, int k, float sigma,
                    float mu, int loss_type, int presort, float *loss_q, float *grad) {
-    if (loss_type != 1 && loss_type != 2) return ORC_EINVAL;
+    if (loss_type != 0 && loss_type != 1 && loss_type != 2) return ORC_EINVAL;
     size_t Ls = (size_t)(L > 0 ? L : 1);
     kv_t *tmp = (kv_t *)malloc(sizeof(kv_t) * Ls);
     int32_t *il = (int32_t *)malloc(sizeof(int32_t) * Ls), *ip = (int32_t *)malloc(sizeof(int32_t) * Ls);
@@ -188,12 +188,19 @@ int orc_lambdaloss(const float *preds, const float *labels, const int32_t *lens,
         double loss = 0.0;
         for (int i = 0; i < kk; ++i)
             for (int j = 0; j < kk; ++j) {
-                if (i == j) continue;
-                if (!(ideal[ip[i]] - ideal[ip[j]] > 0.0f)) continue;   /* lambdaloss.py:127-128 */
-                int d = i > j ? i - j : j - i;
-                float delta = fabsf(inv[d - 1] - inv[d]);
-                float w = delta * fabsf(G[i] - G[j]);
-                if (loss_type == 2) w = (fabsf(inv[i] - inv[j]) + mu * delta) * fabsf(G[i] - G[j]);
+                float w;
+                if (loss_type == 0) {
+                    /* NDCG_Loss1 (lambdaloss.py:33-34,108-109,130): every entry of the k x k block, diagonal included, weight
+                     * of the column: G_j / discount_j (the reference's [B,L] weights broadcast onto the last axis at B = 1) */
+                    w = G[j] / (1.0f / log2f((float)j + 2.0f));
+                } else {
+                    if (i == j) continue;
+                    if (!(ideal[ip[i]] - ideal[ip[j]] > 0.0f)) continue;   /* lambdaloss.py:127-128 */
+                    int d = i > j ? i - j : j - i;
+                    float delta = fabsf(inv[d - 1] - inv[d]);
+                    w = delta * fabsf(G[i] - G[j]);
+                    if (loss_type == 2) w = (fabsf(inv[i] - inv[j]) + mu * delta) * fabsf(G[i] - G[j]);
+                }
                 float df = ss[i] - ss[j];
                 if (df > 1e8f) df = 1e8f; if (df < -1e8f) df = -1e8f; if (df != df) df = 0.0f;
                 float p0 = sigmoidf_(sigma * df);
@@ -201,7 +208,7 @@ int orc_lambdaloss(const float *preds, const float *labels, const int32_t *lens,
                 float wp0 = powf(p, w);
                 float wp = wp0 > eps ? wp0 : eps;
                 loss += -log2f(wp);
-                if (p0 >= eps && wp0 >= eps) {                       /* clamp(min) passes gradient at equality */
+                if (i != j && p0 >= eps && wp0 >= eps) {             /* clamp(min) passes gradient at equality */
                     float dls = -(1.0f / (wp * ln2)) * (w * powf(p, w - 1.0f)) * ((1.0f - p0) * p0) * sigma;
                     gs[i] += dls; gs[j] -= dls;
                 }
@@ -210,6 +217,53 @@ int orc_lambdaloss(const float *preds, const float *labels, const int32_t *lens,
         loss_q[q] = (float)loss;
     }
     free(tmp); free(il); free(ip); free(buf);
+    return ORC_OK;
+}
+
+/* SoftRank — ptranking/ltr_adhoc/listwise/softrank.py:47-69 (labels in ideal order, the reference asserts presort).
+ * E[rank_i] = 1 + sum_{j != i} 0.5*erfc((s_i - s_j)/sqrt(2*2*delta^2)); loss_q = -sum_{i<k} g_i/(log2(E_i + 1)*IDCG_q).
+ * Closed-form gradient: c_i = g_i/(IDCG*ln2*(1+E_i)*log2(1+E_i)^2) (i < k, else 0), phi_ij = exp(-x_ij^2)/(sqrt(pi)*den),
+ * dL/ds_m = sum_{i != m} phi_im*(c_i - c_m). */
+int orc_softrank(const float *preds, const float *labels, const int32_t *lens, int B, int L, float delta, int top_k,
+                 float *loss_q, float *grad) {
+    size_t Ls = (size_t)(L > 0 ? L : 1);
+    float *E = (float *)malloc(sizeof(float) * Ls * 2);
+    if (!E) return ORC_ENOMEM;
+    float *c = E + Ls;
+    const float var = 2.0f * (delta * delta);
+    const float den = sqrtf(2.0f * var);
+    const float ln2 = 0.6931471805599453f, inv_sqrt_pi = 0.5641895835477563f;
+    for (int q = 0; q < B; ++q) {
+        const float *s = preds + (size_t)q * L, *y = labels + (size_t)q * L;
+        float *g = grad + (size_t)q * L;
+        int n = qlen(lens, q, L);
+        memset(g, 0, sizeof(float) * (size_t)L);
+        int k = (top_k > 0 && top_k < n) ? top_k : n;
+        float idcg = dcg_all(y, n);
+        double loss = 0.0;
+        for (int i = 0; i < n; ++i) {
+            double acc = 0.0;
+            for (int j = 0; j < n; ++j) if (j != i) acc += 0.5f * erfcf((s[i] - s[j]) / den);
+            E[i] = (float)acc + 1.0f;
+            c[i] = 0.0f;
+            if (i < k) {
+                float lg = log2f(E[i] + 1.0f);
+                loss -= (double)((1.0f / lg) * gain(y[i]) / idcg);
+                c[i] = gain(y[i]) / (idcg * ln2 * (1.0f + E[i]) * lg * lg);
+            }
+        }
+        for (int m = 0; m < n; ++m) {
+            double acc = 0.0;
+            for (int i = 0; i < n; ++i) {
+                if (i == m) continue;
+                float x = (s[i] - s[m]) / den;
+                acc += (double)(inv_sqrt_pi / den * expf(-x * x)) * (double)(c[i] - c[m]);
+            }
+            g[m] = (float)acc;
+        }
+        loss_q[q] = (float)loss;
+    }
+    free(E);
     return ORC_OK;
 }
 

@@ -70,7 +70,8 @@ def lambdarank_loss(preds, labels, sigma=1.0):
 
 
 def lambdaloss_loss(preds, labels, k=5, sigma=1.0, mu=5.0, loss_type=1, presort=True):
-    """ptranking/ltr_adhoc/listwise/lambdaloss.py:83-132.  loss_type 1 = NDCG_Loss2 (:36-45), 2 = NDCG_Loss2++ (:47-58).
+    """ptranking/ltr_adhoc/listwise/lambdaloss.py:83-132.  loss_type 0 = NDCG_Loss1 (:33-34), 1 = NDCG_Loss2 (:36-45),
+    2 = NDCG_Loss2++ (:47-58).
     The inverted discount table (`pow(1/log2(r+2), -1)`) is reproduced as the reference computes it (SURVEY §7 iii)."""
     if presort:
         tp, ideal = preds, labels
@@ -88,19 +89,25 @@ def lambdaloss_loss(preds, labels, k=5, sigma=1.0, mu=5.0, loss_type=1, presort=
     delta = torch.abs(inv[dist - 1] - inv[dist])       # index -1 wraps on the diagonal, then zeroed (:41-42)
     delta.diagonal().zero_()
     absG = torch.abs(G[:, :, None] - G[:, None, :])
-    if loss_type == 1:
+    if loss_type == 0:
+        # NDCG_Loss1 (:33-34): weights [B, L] = G / discounts.  The reference broadcasts them against [B, L, L] (only legal at
+        # B == 1, where they index the COLUMN j); restated per query, w[b, i, j] = G[b, j] / disc[j].
+        w = (G / disc[None])[:, None, :].expand(-1, L, -1)
+    elif loss_type == 1:
         w = delta[None] * absG
     elif loss_type == 2:
         rho = torch.abs(inv[:, None] - inv[None, :])
         w = (rho + mu * delta)[None] * absG
     else:
-        raise NotImplementedError("NDCG_Loss1 only broadcasts for B == 1 in the reference; not part of the path")
+        raise NotImplementedError(loss_type)
     d = (sp.unsqueeze(2) - sp.unsqueeze(1)).clamp(min=-1e8, max=1e8)
     d = torch.where(torch.isnan(d), torch.zeros_like(d), d)
     wp = (torch.sigmoid(sigma * d).clamp(min=EPS_LAMBDALOSS) ** w).clamp(min=EPS_LAMBDALOSS)
     lw = torch.log2(wp)
     trunc = torch.zeros(L, L, dtype=torch.bool)
     trunc[:k, :k] = True
+    if loss_type == 0:
+        return -torch.sum(lw[trunc[None].expand_as(lw)])      # :130, no label mask
     mask = ((ranked.unsqueeze(2) - ranked.unsqueeze(1)) > 0) & trunc
     return -torch.sum(lw[mask])
 
@@ -156,6 +163,21 @@ def listnet_loss(preds, labels):
 def gumbel_from_uniform(unif):
     """ptranking/ltr_adhoc/listwise/st_listnet.py:18,43 (EPS = 1e-20)."""
     return -torch.log(-torch.log(unif + 1e-20) + 1e-20)
+
+
+def softrank_loss(preds, labels, delta=2.0, top_k=None):
+    """ptranking/ltr_adhoc/listwise/softrank.py:47-69 (labels in ideal order; the reference asserts presort)."""
+    dlt = torch.tensor([delta], dtype=torch.float32)
+    sub = preds.unsqueeze(2) - preds.unsqueeze(1)
+    var = 2 * dlt ** 2
+    phi0 = 0.5 * torch.erfc(sub / torch.sqrt(2 * var))
+    phi0 = torch.triu(phi0, diagonal=1) + torch.tril(phi0, diagonal=-1)
+    ranks = torch.sum(phi0, dim=2) + 1.0
+    dists = 1.0 / torch.log2(ranks + 1.0)
+    gains = _gain(labels)
+    idcg = dcg_full(labels)
+    k = labels.size(1) if top_k is None else min(top_k, labels.size(1))
+    return -torch.sum(torch.sum(dists[:, :k] * gains[:, :k] / idcg, dim=1))
 
 
 def stlistnet_loss(preds, labels, unif, temperature=1.0):

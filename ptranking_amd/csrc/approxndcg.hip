@@ -35,10 +35,23 @@ __device__ __forceinline__ void robust_pair(float delta, float alpha, float &ya,
     yb = pos ? sm : (neg ? r : 0.5f);
 }
 
-template <int G, int DPT>
+// SoftRank (ptranking/ltr_adhoc/listwise/softrank.py:47-69) is the same two-pass scheme with a Gaussian rank indicator:
+//   E[rank_i] = 1 + sum_{j != i} 0.5*erfc((s_i - s_j)/den),  den = sqrt(2*(2*delta^2))               (:50-56)
+//   loss      = -sum_q sum_{i < top_k} (2^l_i - 1) / (log2(E[rank_i] + 1) * IDCG_q)                  (:58-69; no batch coupling)
+// Both indicators of an unordered pair from one erfc: the small one directly, the other as its complement.
+// `alpha` carries 1/den.  delta = s_b - s_a; ya = 0.5*erfc((s_a - s_b)/den) is b's contribution to E[rank_a].
+__device__ __forceinline__ void soft_pair(float delta, float inv_den, float &ya, float &yb) {
+    const float sm = 0.5f * erfcf(fabsf(delta) * inv_den);
+    const float lg = 1.0f - sm;
+    const bool pos = delta > 0.0f;
+    ya = pos ? lg : sm;
+    yb = pos ? sm : lg;
+}
+
+template <int G, int DPT, bool SOFT>
 __global__ void __launch_bounds__(kBlock)
 approxndcg_kernel(const float *__restrict__ preds, const float *__restrict__ labels, const int32_t *__restrict__ lens, int B,
-                  int L, int Lp, float alpha, int presort, int couple_batch, float *__restrict__ dcg_q,
+                  int L, int Lp, float alpha, int presort, int couple_batch, int top_k, float *__restrict__ dcg_q,
                   float *__restrict__ inv_idcg_q, float *__restrict__ grad) {
     constexpr int QPB = kBlock / G, NW = G / kWave;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -88,7 +101,7 @@ approxndcg_kernel(const float *__restrict__ preds, const float *__restrict__ lab
             if (a < n) {
                 int b = a + d; if (b >= n) b -= n;
                 float ya, yb;
-                robust_pair(S_id[b] - sa[m], alpha, ya, yb);
+                if constexpr (SOFT) soft_pair(S_id[b] - sa[m], alpha, ya, yb); else robust_pair(S_id[b] - sa[m], alpha, ya, yb);
                 pia[m] += ya;
                 aw[b] += yb;                                  // per-wave row, distinct b per lane (no atomics needed)
             }
@@ -101,7 +114,7 @@ approxndcg_kernel(const float *__restrict__ preds, const float *__restrict__ lab
             const int a = t + m * G;
             if (a < d) {
                 float ya, yb;
-                robust_pair(S_id[a + d] - sa[m], alpha, ya, yb);
+                if constexpr (SOFT) soft_pair(S_id[a + d] - sa[m], alpha, ya, yb); else robust_pair(S_id[a + d] - sa[m], alpha, ya, yb);
                 pia[m] += ya;
                 aw[a + d] += yb;
             }
@@ -117,11 +130,11 @@ approxndcg_kernel(const float *__restrict__ preds, const float *__restrict__ lab
     for (int m = 0; m < DPT; ++m) {
         const int a = t + m * G;
         ca[m] = 0.0f;
-        if (a < n) {
+        if (a < n && a < top_k) {                            // softrank.py:66-68 (top_k = n for ApproxNDCG)
             float pi = pia[m];
 #pragma unroll
             for (int w = 0; w < NW; ++w) pi += acc[(size_t)w * Lp + a];
-            pi += 1.0f;                                       // 0.5 (diagonal term) + 0.5 (approxNDCG.py:25)
+            pi += 1.0f;                                       // 0.5 (diagonal term) + 0.5 (approxNDCG.py:25); softrank.py:56
             const float lg = log2f(pi + 1.0f);
             dpart += gna[m] / lg;                             // approxNDCG.py:58
             ca[m] = gna[m] / (ln2 * (1.0f + pi) * lg * lg);   // d(-g/log2(1+pi))/d(pi)
@@ -145,10 +158,16 @@ approxndcg_kernel(const float *__restrict__ preds, const float *__restrict__ lab
 #pragma unroll
     for (int m = 0; m < DPT; ++m) ga[m] = 0.0f;
     auto gpair = [&](int m, int a, int b) {
-        float ya, yb;
-        robust_pair(S_id[b] - sa[m], alpha, ya, yb);
-        const float dab = (alpha * ya) * (1.0f - ya);         // base/utils.py:78
-        const float dba = (alpha * yb) * (1.0f - yb);
+        float dab, dba;
+        if constexpr (SOFT) {                                 // d(0.5*erfc(x/den))/dx = -exp(-(x/den)^2)/(sqrt(pi)*den), symmetric
+            const float x = (S_id[b] - sa[m]) * alpha;
+            dab = dba = 0.5641895835477563f * alpha * __expf(-x * x);
+        } else {
+            float ya, yb;
+            robust_pair(S_id[b] - sa[m], alpha, ya, yb);
+            dab = (alpha * ya) * (1.0f - ya);                 // base/utils.py:78
+            dba = (alpha * yb) * (1.0f - yb);
+        }
         const float cb = Y_id[b];
         const float flow = cb * dba - ca[m] * dab;            // d loss / d s_a from this pair
         ga[m] += flow;
@@ -190,7 +209,10 @@ approxndcg_kernel(const float *__restrict__ preds, const float *__restrict__ lab
             const int i = t + m * G;
             if (i < L) grad[(size_t)q * L + i] = i < n ? S_id[ipos[m]] : 0.0f;
         }
-        if (t == 0) { dcg_q[q] = dcg; inv_idcg_q[q] = inv_idcg; }
+        if (t == 0) {
+            if constexpr (SOFT) { dcg_q[q] = -(dcg * inv_idcg); }         // per-query loss
+            else { dcg_q[q] = dcg; inv_idcg_q[q] = inv_idcg; }
+        }
     }
 }
 
@@ -232,11 +254,11 @@ extern "C" int ptr_approxndcg_fwd_bwd(const float *preds, const float *labels, c
         const int Lp = round_up(L, 4);
         int rc = dispatch_tiling(L, [&]<int G, int DPT>() -> int {
             constexpr int QPB = kBlock / G, NW = G / kWave;
-            auto kern = approxndcg_kernel<G, DPT>;
+            auto kern = approxndcg_kernel<G, DPT, false>;
             const size_t lds = QPB * approx_group_floats(Lp, NW) * sizeof(float);
             if (int e = allow_lds(kern, lds)) return e;
             hipLaunchKernelGGL(kern, dim3((B + QPB - 1) / QPB), dim3(kBlock), lds, st, preds, labels, lens, B, L, Lp, alpha, presort,
-                               couple_batch, dcg_q, inv_idcg_q, grad);
+                               couple_batch, PTR_MAX_LIST_LEN, dcg_q, inv_idcg_q, grad);
             return check_hip(hipGetLastError(), who);
         });
         if (rc) return rc;
@@ -252,4 +274,30 @@ extern "C" int ptr_approxndcg_fwd_bwd(const float *preds, const float *labels, c
         if (int rc = check_hip(hipGetLastError(), who)) return rc;
     }
     return 0;
+}
+
+extern "C" int ptr_softrank_fwd_bwd(const float *preds, const float *labels, const int32_t *lens, int B, int L, float delta,
+                                    int top_k, float *loss_out, float *loss_q, float *grad, void *stream) {
+    using namespace ptr;
+    const char *who = "ptr_softrank_fwd_bwd";
+    if (int rc = check_batch(preds, labels, B, L, who)) return rc;
+    if (B > 0 && (!loss_q || !grad)) { set_error("%s: NULL output pointer", who); return PTR_ERR_INVALID_ARG; }
+    if (!(delta > 0.0f)) { set_error("%s: delta must be > 0 (got %g)", who, (double)delta); return PTR_ERR_INVALID_ARG; }
+    hipStream_t st = as_stream(stream);
+    if (B > 0) {
+        const float var = 2.0f * (delta * delta);             // softrank.py:52, in fp32 like the reference's tensor arithmetic
+        const float inv_den = 1.0f / sqrtf(2.0f * var);       // :54
+        const int Lp = round_up(L, 4);
+        int rc = dispatch_tiling(L, [&]<int G, int DPT>() -> int {
+            constexpr int QPB = kBlock / G, NW = G / kWave;
+            auto kern = approxndcg_kernel<G, DPT, true>;
+            const size_t lds = QPB * approx_group_floats(Lp, NW) * sizeof(float);
+            if (int e = allow_lds(kern, lds)) return e;
+            hipLaunchKernelGGL(kern, dim3((B + QPB - 1) / QPB), dim3(kBlock), lds, st, preds, labels, lens, B, L, Lp, inv_den, 1, 0,
+                               top_k > 0 ? top_k : PTR_MAX_LIST_LEN, loss_q, (float *)nullptr, grad);
+            return check_hip(hipGetLastError(), who);
+        });
+        if (rc) return rc;
+    }
+    return loss_out ? ptr_sum_f32(loss_q, B, 1.0f, loss_out, stream) : 0;
 }

@@ -1,4 +1,4 @@
-// Fused LambdaLoss kernel (NDCG_Loss2 / NDCG_Loss2++): ideal-order staging -> rank by score -> normalised gains ->
+// Fused LambdaLoss kernel (NDCG_Loss1 / NDCG_Loss2 / NDCG_Loss2++): ideal-order staging -> rank by score -> normalised gains ->
 // the k x k block of (winner, loser) pairs -> gradient scattered back through both permutations.
 //
 // Reference: ptranking/ltr_adhoc/listwise/lambdaloss.py:36-58 (power weights), :83-132 (loss), epsilon = 1e-8
@@ -103,6 +103,26 @@ lambdaloss_kernel(const float *__restrict__ preds, const float *__restrict__ lab
         const bool fwd = b < kk;
         if (!fwd) b -= kk;
         const float4 o = pk[b];
+        if (loss_type == PTR_LAMBDALOSS_NDCG_LOSS1) {
+            // NDCG_Loss1 (lambdaloss.py:33-34,108-109,130): no label mask; BOTH ordered entries (a,b) and (b,a) of the k x k
+            // block count, entry (i,j) carrying the column's weight w_j = G_j / D_j = G_j * inv[j].
+            float df = fminf(fmaxf(me[m].x - o.x, -1e8f), 1e8f);
+            if (df != df) df = 0.0f;
+            const float x = sigma * df;
+            const float wb = o.y * o.z, wa = me[m].y * me[m].z;
+            const float pab = 1.0f / (1.0f + expf(-x)), pba = 1.0f / (1.0f + expf(x));
+            const float lab = pab >= eps ? -log1pf(expf(-x)) * inv_ln2 : log2_eps;
+            const float lba = pba >= eps ? -log1pf(expf(x)) * inv_ln2 : log2_eps;
+            const float zab = wb * lab, zba = wa * lba;
+            const bool okab = zab >= log2_eps, okba = zba >= log2_eps;
+            lacc -= (okab ? zab : log2_eps) + (okba ? zba : log2_eps);
+            float g = 0.0f;                                               // d loss / d s_a; s_b gets -g
+            if (pab >= eps && okab) g -= (wb * sigma * (1.0f - pab)) * inv_ln2;
+            if (pba >= eps && okba) g += (wa * sigma * (1.0f - pba)) * inv_ln2;
+            ga[m] += g;
+            gw[b] -= g;
+            return;
+        }
         const bool a_wins = me[m].w > o.w, b_wins = o.w > me[m].w;        // lambdaloss.py:127-128
         if (!(a_wins || b_wins)) return;
         const float delta = fwd ? delta_fwd : delta_wrap;                  // |rank distance| = d or kk - d
@@ -128,6 +148,14 @@ lambdaloss_kernel(const float *__restrict__ preds, const float *__restrict__ lab
         gw[b] -= ga_;                                                      // per-wave row, distinct b per lane: race-free
     };
 
+    if (loss_type == PTR_LAMBDALOSS_NDCG_LOSS1) {
+        // diagonal entries: sigmoid(0)^w_j = 2^-w_j, constant in the scores
+#pragma unroll
+        for (int m = 0; m < DPT; ++m) {
+            const int a = t + m * G;
+            if (a < kk) lacc += fminf(me[m].y * me[m].z, -log2_eps);
+        }
+    }
     const int half = (kk - 1) >> 1;
     for (int d = 1; d <= half; ++d) {
         const float dfw = fabsf(reinterpret_cast<const float *>(pk + (d - 1))[2] - reinterpret_cast<const float *>(pk + d)[2]);
@@ -188,8 +216,8 @@ extern "C" int ptr_lambdaloss_fwd_bwd(const float *preds, const float *labels, c
     const char *who = "ptr_lambdaloss_fwd_bwd";
     if (int rc = check_batch(preds, labels, B, L, who)) return rc;
     if (B > 0 && (!loss_q || !grad)) { set_error("%s: NULL output pointer", who); return PTR_ERR_INVALID_ARG; }
-    if (loss_type != PTR_LAMBDALOSS_NDCG_LOSS2 && loss_type != PTR_LAMBDALOSS_NDCG_LOSS2PP) {
-        set_error("%s: loss_type %d not supported (1 = NDCG_Loss2, 2 = NDCG_Loss2++)", who, loss_type);
+    if (loss_type != PTR_LAMBDALOSS_NDCG_LOSS1 && loss_type != PTR_LAMBDALOSS_NDCG_LOSS2 && loss_type != PTR_LAMBDALOSS_NDCG_LOSS2PP) {
+        set_error("%s: loss_type %d not supported (0 = NDCG_Loss1, 1 = NDCG_Loss2, 2 = NDCG_Loss2++)", who, loss_type);
         return PTR_ERR_INVALID_ARG;
     }
     hipStream_t st = as_stream(stream);

@@ -14,9 +14,9 @@ from . import _lib
 
 __all__ = ["ranknet_loss", "lambdarank_loss", "lambdaloss_loss", "approxndcg_loss", "listnet_loss", "listmle_loss",
            "stlistnet_loss", "rankmse_loss", "rankcosine_loss",
-           "shuffle_ties_order", "sort_desc", "metrics_at_ks", "sum_f32", "LAMBDALOSS_TYPES"]
+           "softrank_loss", "shuffle_ties_order", "sort_desc", "metrics_at_ks", "sum_f32", "LAMBDALOSS_TYPES"]
 
-LAMBDALOSS_TYPES = {"NDCG_Loss2": 1, "NDCG_Loss2++": 2}   # ptranking/ltr_adhoc/listwise/lambdaloss.py:27
+LAMBDALOSS_TYPES = {"NDCG_Loss1": 0, "NDCG_Loss2": 1, "NDCG_Loss2++": 2}   # ptranking/ltr_adhoc/listwise/lambdaloss.py:27
 
 
 def _check(name, t, dtype=torch.float32, shape=None):
@@ -97,11 +97,18 @@ def lambdarank_loss(preds, labels, sigma=1.0, lens=None):
 
 
 def lambdaloss_loss(preds, labels, k=5, sigma=1.0, mu=5.0, loss_type="NDCG_Loss2", presort=True, lens=None):
-    """LambdaLoss NDCG_Loss2 / NDCG_Loss2++, ptranking/ltr_adhoc/listwise/lambdaloss.py:83-132."""
+    """LambdaLoss NDCG_Loss1 / NDCG_Loss2 / NDCG_Loss2++, ptranking/ltr_adhoc/listwise/lambdaloss.py:83-132.
+    NDCG_Loss1: the reference's [B,L] weights only broadcast against its [B,L,L] tensors at batch size 1; here every query
+    of a batch uses its own weights (identical to the reference at B = 1)."""
     if loss_type not in LAMBDALOSS_TYPES:
         raise NotImplementedError(f"LambdaLoss type {loss_type!r} (supported: {sorted(LAMBDALOSS_TYPES)})")
     return _simple("ptr_lambdaloss_fwd_bwd", preds, labels, lens, int(k), C.c_float(float(sigma)), C.c_float(float(mu)),
                    LAMBDALOSS_TYPES[loss_type], int(bool(presort)))
+
+
+def softrank_loss(preds, labels, delta=2.0, top_k=None, lens=None):
+    """SoftRank, ptranking/ltr_adhoc/listwise/softrank.py:47-69.  `labels` in ideal (descending) order per query."""
+    return _simple("ptr_softrank_fwd_bwd", preds, labels, lens, C.c_float(float(delta)), int(top_k) if top_k else 0)
 
 
 def listnet_loss(preds, labels, lens=None):

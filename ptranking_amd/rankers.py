@@ -16,7 +16,7 @@ from . import functional as F_
 from .host import DeviceEvaluator, DeviceTrainLoop, PointScorerRanker, is_multilabel
 from .scorer import FusedScorerMixin
 
-RANKER_NAMES = ("RankNet", "LambdaRank", "LambdaLoss", "ApproxNDCG", "ListNet", "ListMLE", "STListNet", "RankCosine", "RankMSE")
+RANKER_NAMES = ("RankNet", "LambdaRank", "LambdaLoss", "ApproxNDCG", "ListNet", "ListMLE", "STListNet", "RankCosine", "RankMSE", "SoftRank")
 
 # default hyper-parameters = the reference's `default_para_dict()`s
 DEFAULT_PARAS = {
@@ -29,6 +29,7 @@ DEFAULT_PARAS = {
     "STListNet": dict(model_id="STListNet", temperature=1.0),                          # listwise/st_listnet.py:70
     "RankCosine": dict(model_id="RankCosine"),
     "RankMSE": dict(model_id="RankMSE"),
+    "SoftRank": dict(model_id="SoftRank", delta=2.0, metric='nDCG', top_k=None),       # listwise/softrank.py:97
 }
 
 
@@ -113,6 +114,16 @@ class ApproxNDCGLoss(FusedStepMixin):
         bucket.flat[:bucket.numel].mul_(S)
         self.optimizer.step()
         return -(D * S)
+
+
+class SoftRankLoss(FusedStepMixin):
+    def custom_loss_function(self, batch_preds, batch_std_labels, **kwargs):
+        """ptranking/ltr_adhoc/listwise/softrank.py:33-78"""
+        assert 'presort' in kwargs and kwargs['presort'] is True  # aiming for direct usage of ideal ranking
+        assert 'nDCG' == self.metric
+        assert is_multilabel(kwargs['label_type'])
+        return self._fused_step(F_.softrank_loss(batch_preds, batch_std_labels, delta=self.delta_value, top_k=self.top_k,
+                                                 lens=kwargs.get('lens')))
 
 
 class ListNetLoss(FusedStepMixin):
@@ -217,8 +228,16 @@ def make_ranker_classes(base=PointScorerRanker):
         def __init__(self, sf_para_dict=None, gpu=False, device=None):
             base.__init__(self, id='RankMSE', sf_para_dict=sf_para_dict, gpu=gpu, device=device)
 
+    class SoftRank(SoftRankLoss, FusedScorerMixin, DeviceTrainLoop, DeviceEvaluator, base):
+        def __init__(self, sf_para_dict=None, model_para_dict=None, gpu=False, device=None):
+            base.__init__(self, id='SoftRank', sf_para_dict=sf_para_dict, gpu=gpu, device=device)
+            self.delta_value = float(model_para_dict['delta'])
+            self.delta = torch.tensor([self.delta_value], device=self.device)     # softrank.py:28-29
+            self.top_k = model_para_dict['top_k']
+            self.metric = model_para_dict['metric']
+
     out = dict(RankNet=RankNet, LambdaRank=LambdaRank, LambdaLoss=LambdaLoss, ApproxNDCG=ApproxNDCG, ListNet=ListNet,
-               ListMLE=ListMLE, STListNet=STListNet, RankCosine=RankCosine, RankMSE=RankMSE)
+               ListMLE=ListMLE, STListNet=STListNet, RankCosine=RankCosine, RankMSE=RankMSE, SoftRank=SoftRank)
     for name, cls in out.items():
         cls.__name__ = cls.__qualname__ = name
         cls.__module__ = __name__
@@ -229,3 +248,4 @@ _standalone = make_ranker_classes(PointScorerRanker)
 RankNet, LambdaRank, LambdaLoss = _standalone["RankNet"], _standalone["LambdaRank"], _standalone["LambdaLoss"]
 ApproxNDCG, ListNet, ListMLE = _standalone["ApproxNDCG"], _standalone["ListNet"], _standalone["ListMLE"]
 STListNet, RankCosine, RankMSE = _standalone["STListNet"], _standalone["RankCosine"], _standalone["RankMSE"]
+SoftRank = _standalone["SoftRank"]

@@ -240,6 +240,22 @@ def gen_siblings():
                 torch.rand = orig_rand
             add(store, f"stlistnet/c{ci}_t{T:g}", preds=preds, labels=labels, unif=captured["unif"], temperature=np.float32(T),
                 loss=loss, grad=grad)
+    # SoftRank (softrank.py:33-78) and LambdaLoss NDCG_Loss1 (lambdaloss.py:33-34; only runs at batch size 1 in the reference)
+    from ptranking.ltr_adhoc.listwise.softrank import SoftRank
+    for ci, (B, L) in enumerate([(3, 8), (4, 32), (2, 128), (2, 300)]):
+        preds, labels = synth(rng, B, L)
+        for delta, top_k in ((2.0, None), (1.0, None), (0.5, 5)):
+            mpd = dict(delta=delta, top_k=top_k, metric="nDCG")
+            loss, grad = run_loss(SoftRank(sf_para_dict=SF, model_para_dict=mpd, device="cpu"), preds, labels)
+            add(store, f"softrank/c{ci}_d{delta:g}_k{top_k or 0}", preds=preds, labels=labels, delta=np.float32(delta),
+                top_k=np.int32(top_k or 0), loss=loss, grad=grad)
+    for ci, L in enumerate([8, 32, 128, 300]):
+        preds, labels = synth(rng, 1, L)
+        for k in (5, L):
+            mpd = dict(k=k, sigma=1.0, loss_type="NDCG_Loss1", mu=5.0)
+            loss, grad = run_loss(LambdaLoss(sf_para_dict=SF, model_para_dict=mpd, device="cpu"), preds, labels)
+            add(store, f"lambdaloss1/c{ci}_k{k}", preds=preds, labels=labels, sigma=np.float32(1.0), k=np.int32(k), loss=loss,
+                grad=grad, sort_idx=pred_sort_idx(preds))
     zp = np.zeros((2, 5), np.float32)                                  # zero score vector: CosineSimilarity's eps path
     zl = np.array([[2, 1, 1, 0, 0], [1, 0, 0, 0, 0]], np.float32)
     loss, grad = run_loss(RankCosine(sf_para_dict=SF, device="cpu"), zp, zl)

@@ -221,3 +221,23 @@ def test_stlistnet_oracles(name):
     G.assert_close(loss.numpy(), c["loss"], "torch loss"); G.assert_close(grad.numpy(), c["grad"], "torch grad")
     lq, g = CO.stlistnet(c["preds"], c["labels"], c["unif"], float(c["temperature"]))
     G.assert_close(lq.astype(np.float64).sum(), c["loss"], "C loss"); G.assert_close(g, c["grad"], "C grad")
+
+
+@pytest.mark.parametrize("name", G.case_ids("softrank", "siblings"))
+def test_softrank_oracles(name):
+    c = G.siblings()["softrank"][name]
+    tk = int(c["top_k"]) or None
+    loss, grad = T.loss_and_grad(T.softrank_loss, _t(c["preds"]), _t(c["labels"]), delta=float(c["delta"]), top_k=tk)
+    G.assert_close(loss.numpy(), c["loss"], "torch loss"); G.assert_close(grad.numpy(), c["grad"], "torch grad")
+    lq, g = CO.softrank(c["preds"], c["labels"], float(c["delta"]), tk)
+    G.assert_close(lq.astype(np.float64).sum(), c["loss"], "C loss"); G.assert_close(g, c["grad"], "C grad")
+
+
+@pytest.mark.parametrize("name", G.case_ids("lambdaloss1", "siblings"))
+def test_lambdaloss1_oracles(name):
+    """NDCG_Loss1 — golden at B = 1 (the only batch size the reference's broadcast accepts)."""
+    c = G.siblings()["lambdaloss1"][name]
+    loss, grad = T.loss_and_grad(T.lambdaloss_loss, _t(c["preds"]), _t(c["labels"]), k=int(c["k"]), sigma=float(c["sigma"]), loss_type=0)
+    G.assert_close(loss.numpy(), c["loss"], "torch loss"); G.assert_close(grad.numpy(), c["grad"], "torch grad")
+    lq, g = CO.lambdaloss(c["preds"], c["labels"], k=int(c["k"]), sigma=float(c["sigma"]), loss_type=0)
+    G.assert_close(lq.astype(np.float64).sum(), c["loss"], "C loss"); G.assert_close(g, c["grad"], "C grad")

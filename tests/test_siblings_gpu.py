@@ -38,6 +38,37 @@ def test_golden_stlistnet(F, name):
     G.assert_close(loss, c["loss"], "loss"); G.assert_close(grad, c["grad"], "grad")
 
 
+@pytest.mark.parametrize("name", G.case_ids("softrank", "siblings"))
+def test_golden_softrank(F, name):
+    c = G.siblings()["softrank"][name]
+    loss, grad = loss_and_grad(F.softrank_loss, c["preds"], dev(c["labels"]), delta=float(c["delta"]), top_k=int(c["top_k"]) or None)
+    G.assert_close(loss, c["loss"], "loss"); G.assert_close(grad, c["grad"], "grad")
+
+
+@pytest.mark.parametrize("name", G.case_ids("lambdaloss1", "siblings"))
+def test_golden_lambdaloss1(F, name):
+    c = G.siblings()["lambdaloss1"][name]
+    loss, grad = loss_and_grad(F.lambdaloss_loss, c["preds"], dev(c["labels"]), k=int(c["k"]), sigma=float(c["sigma"]),
+                               loss_type="NDCG_Loss1")
+    G.assert_close(loss, c["loss"], "loss"); G.assert_close(grad, c["grad"], "grad")
+
+
+@pytest.mark.parametrize("B,L", [(7, 5), (33, 128), (9, 700), (3, 2048)])
+@pytest.mark.parametrize("use_lens", [False, True])
+def test_oracle_softrank_lambdaloss1(F, B, L, use_lens):
+    from oracle import c_oracle as CO
+    preds, labels, ln = synth(7000 + L, B, L, lens=use_lens)
+    lens_t = None if ln is None else dev(ln)
+    for delta, tk in ((2.0, None), (0.3, 10)):
+        loss, grad = loss_and_grad(F.softrank_loss, preds, dev(labels), delta=delta, top_k=tk, lens=lens_t)
+        lq, g = CO.softrank(preds, labels, delta, tk, lens=ln)
+        G.assert_close(loss, lq.astype(np.float64).sum(), "softrank loss"); G.assert_close(grad, g, "softrank grad")
+    for k in (5, 64, L):
+        loss, grad = loss_and_grad(F.lambdaloss_loss, preds, dev(labels), k=k, sigma=1.3, loss_type="NDCG_Loss1", lens=lens_t)
+        lq, g = CO.lambdaloss(preds, labels, k=k, sigma=1.3, loss_type=0, lens=ln)
+        G.assert_close(loss, lq.astype(np.float64).sum(), "loss1 loss"); G.assert_close(grad, g, "loss1 grad")
+
+
 @pytest.mark.parametrize("B,L", [(7, 5), (33, 128), (9, 700), (2, 4096)])
 @pytest.mark.parametrize("use_lens", [False, True])
 def test_oracle_siblings(F, B, L, use_lens):
@@ -62,10 +93,10 @@ def test_sibling_rankers_train():
           "pointsf": dict(num_features=24, num_layers=3, AF="R", TL_AF="S", apply_tl_af=False, BN=False, bn_type=None, bn_affine=False)}
     X = torch.randn(6, 40, 24, device="cuda")
     Y = torch.sort(torch.randint(0, 5, (6, 40), device="cuda").float(), dim=1, descending=True)[0].contiguous()
-    for name in ("STListNet", "RankCosine", "RankMSE"):
+    for name in ("STListNet", "RankCosine", "RankMSE", "SoftRank"):
         cls = getattr(pa, name)
         r = cls(sf_para_dict=copy.deepcopy(sf), model_para_dict=dict(pa.DEFAULT_PARAS[name]), gpu=True, device="cuda:0") \
-            if name == "STListNet" else cls(sf_para_dict=copy.deepcopy(sf), gpu=True, device="cuda:0")
+            if name in ("STListNet", "SoftRank") else cls(sf_para_dict=copy.deepcopy(sf), gpu=True, device="cuda:0")
         r.init(); r.train_mode()
         before = r.point_sf.flat.detach().clone()
         loss, stop = r.train_op(X, Y, epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
