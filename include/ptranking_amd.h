@@ -155,6 +155,32 @@ int ptr_adam_step(float *param, const float *grad, float *exp_avg, float *exp_av
 /* Test helper: the dropout keep-mask (1.0 / 0.0) of dropout site `site` for an [R][n_feat] activation. */
 int ptr_mlp_dropout_mask(int R, int n_feat, int site, float p_drop, uint64_t seed, float *out, void *stream);
 
+/* ---- listsf: the permutation-equivariant scorer's fused pieces (fp32 MFMA attention core, the reference's LayerNorm) ----
+ * ptr_mhsa_forward replaces ptranking/base/list_ranker.py:216-240 (Q K^T / sqrt(d_h) -> softmax -> Dropout -> . V, heads = column
+ * blocks of width F / n_heads of the [B][L][F] projections Q, K, V; the output O has the same layout, i.e. what
+ * `x.permute(0,2,1,3).contiguous().view(bsz,-1,F)` yields at :243-247).  Nothing of size L^2 is written: lse [B*H*L] (log-sum-exp
+ * of every score row) is the only side output and lets ptr_mhsa_backward recompute the probabilities.
+ * lens (nullable): keys >= lens[b] are excluded from the softmax (padded batches; the reference has no padding).
+ * p_drop > 0: dropout on the attention probabilities from the counter generator (seed, site, b, h, row, key); p_drop = 0: eval.
+ * ptr_mhsa_backward: dO [B][L][F] -> dQ, dK, dV [B][L][F] (every element written); dvec [B*H*L] is scratch; O, lse, p_drop,
+ * seed, site must be the forward call's.  Head dimension F / n_heads <= PTR_MHSA_MAX_HEAD_DIM. */
+#define PTR_MHSA_MAX_HEAD_DIM 128
+int ptr_mhsa_forward(const float *Q, const float *K, const float *V, const int32_t *lens, int B, int L, int F, int n_heads,
+                     float p_drop, uint64_t seed, int site, float *O, float *lse, void *stream);
+int ptr_mhsa_backward(const float *Q, const float *K, const float *V, const float *O, const float *dO, const float *lse,
+                      const int32_t *lens, int B, int L, int F, int n_heads, float p_drop, uint64_t seed, int site, float *dvec,
+                      float *dQ, float *dK, float *dV, void *stream);
+/* Test helper: the attention dropout keep-mask (1.0 / 0.0), out [B][n_heads][L][L]. */
+int ptr_mhsa_dropout_mask(int B, int L, int n_heads, float p_drop, uint64_t seed, int site, float *out, void *stream);
+/* LayerNorm of ptranking/base/list_ranker.py:152-174: y = a_2 * (x - mean) / (std + eps) + b_2 over the last axis of X [R][F],
+ * std UNBIASED (divides by F-1) and eps added to the std.  stats [R][3] = {mean, 1/(std+eps), std} feeds the backward.
+ * ptr_layernorm_backward: dY -> dX [R][F], da2 [F], db2 [F]; ws = ptr_layernorm_backward_ws_floats(F) floats of scratch. */
+int ptr_layernorm_forward(const float *X, const float *a2, const float *b2, int64_t R, int F, float eps, float *Y, float *stats,
+                          void *stream);
+size_t ptr_layernorm_backward_ws_floats(int F);
+int ptr_layernorm_backward(const float *X, const float *a2, const float *dY, const float *stats, int64_t R, int F, float *ws,
+                           float *dX, float *da2, float *db2, void *stream);
+
 /* ---- LETOR / libsvm text input (HOST buffers; the data format feeding the path) ---------------------------------------
  * Replaces the pure-Python tokenizer ptranking/data/data_utils.py:276-387 (iter_lines / parse_letor):
  *   "<label> qid:<id> <fid>:<val> ... [# comment]", feature ids one-indexed unless one_indexed == 0 (Yahoo! sets,

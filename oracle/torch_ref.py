@@ -337,3 +337,85 @@ def cpu_train_step(net, opt, X, Y, loss_fn, **loss_kw):
     loss.backward()
     opt.step()
     return loss.item()
+
+
+# ================================================================================ listwise scorer (listsf) restatement
+def layer_norm_ref(x, a_2, b_2, eps=1e-6):
+    """ptranking/base/list_ranker.py:170-174 — torch.std is the UNBIASED estimator, eps is added to the std."""
+    mean = x.mean(-1, keepdim=True)
+    std = x.std(-1, keepdim=True)
+    return a_2 * (x - mean) / (std + eps) + b_2
+
+
+def mhsa_core_ref(Q, K, V, n_heads, keep_mask=None, p_drop=0.0, lens=None):
+    """ptranking/base/list_ranker.py:213-247: split heads, Q K^T / sqrt(d_h), softmax, dropout (as an explicit keep mask
+    [B, H, L, L] scaled by 1/(1-p), what nn.Dropout does), times V, merge heads.  lens: padded keys are excluded (not in the
+    reference, which has no padding)."""
+    B, L, Fd = Q.shape
+    dh = Fd // n_heads
+    q = Q.view(B, L, n_heads, dh).permute(0, 2, 1, 3)
+    k = K.view(B, L, n_heads, dh).permute(0, 2, 1, 3)
+    v = V.view(B, L, n_heads, dh).permute(0, 2, 1, 3)
+    scale = torch.sqrt(torch.tensor([dh], dtype=torch.float32))
+    att = torch.matmul(q, k.permute(0, 1, 3, 2)) / scale
+    if lens is not None:
+        key_ok = torch.arange(L)[None, :] < torch.as_tensor(lens)[:, None].long()          # [B, L]
+        att = att.masked_fill(~key_ok[:, None, None, :], float("-inf"))
+    att = torch.softmax(att, dim=-1)
+    if keep_mask is not None and p_drop > 0.0:
+        att = att * keep_mask / (1.0 - p_drop)
+    x = torch.matmul(att, v)
+    return x.permute(0, 2, 1, 3).contiguous().view(B, L, Fd)
+
+
+def mhsa_ref(x, sd, n_heads, keep_mask=None, p_drop=0.0, lens=None, prefix=""):
+    """MultiheadAttention.forward (list_ranker.py:204-254) from a state_dict of tensors."""
+    lin = lambda name, t: F.linear(t, sd[f"{prefix}{name}.weight"], sd[f"{prefix}{name}.bias"])  # noqa: E731
+    core = mhsa_core_ref(lin("w_q", x), lin("w_k", x), lin("w_v", x), n_heads, keep_mask, p_drop, lens)
+    return lin("fc", core)
+
+
+def _ffnet_ref(x, sd, prefix, n_layers, act_last):
+    """get_stacked_FFNet in eval mode with AF='R', BN=False (ptranking/base/utils.py:288-356): Linear+ReLU per hidden layer,
+    last Linear followed by the activation only when apply_tl_af."""
+    for i in range(2, n_layers + 3):                       # n_layers hidden Linear+ReLU (ff_2 ..), then the last Linear
+        x = F.linear(x, sd[f"{prefix}ff_{i}.weight"], sd[f"{prefix}ff_{i}.bias"])
+        if i < n_layers + 2 or act_last:
+            x = F.relu(x)
+    return x
+
+
+def listsf_ref(x, sd, encoder_type, n_heads, encoder_layers, n_ff):
+    """ListNeuralRanker.forward in eval mode (list_ranker.py:352-378 with :46-150) from a flat state_dict whose keys are
+    '<part>/<module key>' for part in head_ffnns / encoder / tail_ffnns.  n_ff = len(ff_dims)."""
+    head = {k.split("/", 1)[1]: v for k, v in sd.items() if k.startswith("head_ffnns/")}
+    enc = {k.split("/", 1)[1]: v for k, v in sd.items() if k.startswith("encoder/")}
+    tail = {k.split("/", 1)[1]: v for k, v in sd.items() if k.startswith("tail_ffnns/")}
+    fc_map = _ffnet_ref(x, head, "", n_ff, True)            # head: apply_tl_af=True with TL_AF=AF (:312-313)
+
+    def encoder(t):
+        for l in range(encoder_layers):
+            pre = f"layers.{l}."
+            att = lambda u: mhsa_ref(u, enc, n_heads, prefix=pre + "mhsa.")  # noqa: E731
+            if encoder_type == "AllRank":
+                n0 = lambda u: layer_norm_ref(u, enc[pre + "sublayer_cont.0.norm.a_2"], enc[pre + "sublayer_cont.0.norm.b_2"])  # noqa: E731
+                n1 = lambda u: layer_norm_ref(u, enc[pre + "sublayer_cont.1.norm.a_2"], enc[pre + "sublayer_cont.1.norm.b_2"])  # noqa: E731
+                t = t + att(n0(t))
+                h = F.relu(F.linear(n1(t), enc[pre + "fc.w1.weight"], enc[pre + "fc.w1.bias"]))
+                t = t + F.linear(h, enc[pre + "fc.w2.weight"], enc[pre + "fc.w2.bias"])
+            else:
+                nrm = lambda u: layer_norm_ref(u, enc[pre + "sublayer_cont.norm.a_2"], enc[pre + "sublayer_cont.norm.b_2"])  # noqa: E731
+                t = nrm(att(t)) if encoder_type == "DASALC" else nrm(t + att(t))
+        if encoder_type == "AllRank":
+            t = layer_norm_ref(t, enc["norm.a_2"], enc["norm.b_2"])
+        return t
+
+    if encoder_type == "AllRank":
+        z = encoder(fc_map)
+    elif encoder_type == "DASALC":
+        z = (encoder(x) + 1.0) * fc_map
+    elif encoder_type == "AttnDIN":
+        z = encoder(fc_map) + x
+    else:
+        raise NotImplementedError(encoder_type)
+    return _ffnet_ref(z, tail, "", n_ff, False).squeeze(2)

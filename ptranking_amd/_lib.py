@@ -41,10 +41,17 @@ SIGNATURES = {
     "ptr_mlp_backward": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _vp, _vp, _vp, _vp],
     "ptr_adam_step": [_vp, _vp, _vp, _vp, C.c_int64, _f, _f, _f, _f, _f, _i, _vp],
     "ptr_mlp_dropout_mask": [_i, _i, _i, _f, _u64, _vp, _vp],
+    "ptr_mhsa_forward": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _i, _vp, _vp, _vp],
+    "ptr_mhsa_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _i, _vp, _vp, _vp, _vp, _vp],
+    "ptr_mhsa_dropout_mask": [_i, _i, _i, _f, _u64, _i, _vp, _vp],
+    "ptr_layernorm_forward": [_vp, _vp, _vp, C.c_int64, _i, _f, _vp, _vp, _vp],
+    "ptr_layernorm_backward_ws_floats": [_i],
+    "ptr_layernorm_backward": [_vp, _vp, _vp, _vp, C.c_int64, _i, _vp, _vp, _vp, _vp, _vp],
     "ptr_letor_scan": [C.c_char_p, _i, _vp, _vp, _vp],
     "ptr_letor_load": [C.c_char_p, _i, _f, C.c_int64, C.c_int32, C.c_int64, _vp, _i, _vp, _vp, _vp],
 }
-_RESTYPES = {"ptr_last_error": C.c_char_p, "ptr_mlp_num_params": C.c_size_t, "ptr_mlp_backward_ws_floats": C.c_size_t}
+_RESTYPES = {"ptr_last_error": C.c_char_p, "ptr_mlp_num_params": C.c_size_t, "ptr_mlp_backward_ws_floats": C.c_size_t,
+             "ptr_layernorm_backward_ws_floats": C.c_size_t}
 OPTIONAL = set()
 
 _lib = None

@@ -1,0 +1,601 @@
+// Fused kernels of the listwise (permutation-equivariant) scorer `listsf`: the multi-head self-attention core on fp32 MFMA
+// and the reference's own LayerNorm.
+//
+// Reference: ptranking/base/list_ranker.py:176-254 (MultiheadAttention.forward: Q K^T / sqrt(d_h) -> softmax -> Dropout -> . V,
+//            heads are column blocks of the [B, L, F] projections), :152-174 (LayerNorm: a_2*(x-mean)/(std+eps)+b_2 with the
+//            UNBIASED std and eps added to std, not to the variance).  Defaults parameter.py:152-166 (2 heads, 6 layers,
+//            dropout 0.1).  The Linear projections around the core stay library GEMMs.
+//
+// The reference materialises scores, softmax, dropout mask and dropped softmax as four [B, H, L, L] fp32 tensors per layer
+// (0.54 GB each at B = 1024, L = 256) and keeps them for backward.  Here nothing of size L^2 touches HBM:
+//   forward   one workgroup (8 waves) per (query, head, block of 128*RT rows): K/V stream through LDS in chunks of 64 keys,
+//             online softmax, dropout bits from a counter hash, O and the per-row log-sum-exp are the only outputs;
+//   backward  recomputes P = exp(S - lse) tile by tile: one kernel per row block for dQ, one per key block for dK / dV
+//             (two kernels instead of atomics on dQ: every output element has one owner, so results are bit-stable).
+// MFMA formulation (v_mfma_f32_16x16x4_f32, exact fp32), "transposed world" as in scorer.hip:
+//   S^T[key][row] = K[key][:] . Q[row][:]      -> lane (j = l&15, g = l>>4) holds row j, keys 16*kt + 4*g + {0..3}
+//   which IS the B-operand layout of   O^T[d][row] += V^T[d][key] * P^T[key][row]   (the k index may be visited in any
+//   order as long as A and B agree), so probabilities never leave registers.  Contractions over d read both operands from
+//   LDS as one ds_read_b128 per 4 k-steps (k-slot (c, g) <-> d = 16*blk + 4*g + c).
+#include "ptr_device.h"
+#include "ptr_dropout.h"
+
+namespace ptr {
+
+constexpr int kAW = 8;                 // waves per workgroup
+constexpr int kAT = kAW * 64;          // threads per workgroup
+constexpr int kKC = 64;                // keys per LDS chunk (forward, dQ)
+constexpr int kRC = 32;                // rows per LDS chunk (dK / dV)
+
+struct AttnArgs {
+    int B, L, H, dh, F;
+    float inv_scale;                   // 1 / sqrt(dh)
+    float p_drop;
+    uint32_t seed_lo, seed_hi;
+    int site;
+};
+
+// LDS leading dimension for a [rows][dh] tile: covers the 16*DT columns the d-tiles touch, ld/4 odd (conflict-free b128)
+__host__ __device__ constexpr int attn_ld(int DT) { return ((16 * DT / 4) & 1) ? 16 * DT : 16 * DT + 4; }
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// rows [row0, row0 + nrows) of the head's column block -> dst[nrows][ld]; rows >= row_lim and columns >= dh are zero
+__device__ __forceinline__ void stage_rows(float *dst, int ld, const float *src, int F, int dh, int row0, int nrows, int row_lim,
+                                           int tid, int nthr) {
+    const bool vec = ((dh & 3) == 0) && ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+    const int ld4 = ld >> 2;
+    for (int idx = tid; idx < nrows * ld4; idx += nthr) {
+        const int r = idx / ld4, c = (idx - r * ld4) << 2;
+        const int row = row0 + r;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < row_lim) {
+            const float *p = src + (size_t)row * F + c;
+            if (vec) { if (c < dh) v = *reinterpret_cast<const f32x4 *>(p); }
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (c + e < dh) v[e] = p[e];
+            }
+        }
+        *reinterpret_cast<f32x4 *>(dst + (size_t)r * ld + c) = v;
+    }
+}
+
+// acc[r] += sum_d A[a_row + j][d] * B[b_row + j][d] over the head dimension, both tiles in LDS with leading dimension ld.
+// Result lane (j, g), reg r: (A row 4*g + r) x (B row j).
+__device__ __forceinline__ f32x4 dot_tiles(const float *As, int a_row, const float *Bs, int b_row, int ld, int nb, int rem, int j, int g) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float *ap = As + (size_t)(a_row + j) * ld;
+    const float *bp = Bs + (size_t)(b_row + j) * ld;
+    for (int blk = 0; blk < nb; ++blk) {                    // k-slot (c, g) <-> d = 16*blk + 4*g + c
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(ap + 16 * blk + 4 * g);
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(bp + 16 * blk + 4 * g);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc = mfma4(a[c], b[c], acc);
+    }
+    for (int t = 0; t < rem; ++t) {                         // tail of dh % 16: k-slot g <-> d = 16*nb + 4*t + g
+        const int d = 16 * nb + 4 * t + g;
+        acc = mfma4(ap[d], bp[d], acc);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ float xor_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16));
+    return fmaxf(v, __shfl_xor(v, 32));
+}
+__device__ __forceinline__ float xor_sum(float v) {
+    v += __shfl_xor(v, 16);
+    return v + __shfl_xor(v, 32);
+}
+
+// ============================================================================================ forward
+template <int DT, int RT, int NW>
+__global__ void __launch_bounds__(NW * 64)
+mhsa_fwd_kernel(const float *__restrict__ Q, const float *__restrict__ K, const float *__restrict__ V,
+                const int32_t *__restrict__ lens, AttnArgs a, float *__restrict__ O, float *__restrict__ LSE) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int ld = attn_ld(DT), RPB = 16 * RT * NW, NT = NW * 64;
+    float *Qs = smem, *Ks = Qs + (size_t)RPB * ld, *Vs = Ks + (size_t)kKC * ld;
+    const int L = a.L, F = a.F, dh = a.dh;
+    const int nrb = (L + RPB - 1) / RPB;
+    const int rb = blockIdx.x % nrb, bh = blockIdx.x / nrb, b = bh / a.H, h = bh - b * a.H;
+    int n = lens ? lens[b] : L;
+    n = n < 0 ? 0 : (n > L ? L : n);
+    const size_t base = (size_t)b * L * F + (size_t)h * dh;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int row0 = rb * RPB;
+    const int dh4 = (dh + 3) & ~3, nb = dh4 >> 4, rem = (dh4 & 15) >> 2;
+    stage_rows(Qs, ld, Q + base, F, dh, row0, RPB, L, tid, NT);
+
+    const uint32_t thr = drop_thr(a.p_drop);
+    float m[RT], l[RT];
+    f32x4 acc[RT][DT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        m[rt] = -INFINITY; l[rt] = 0.0f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) acc[rt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int wrow = wave * 16 * RT;                       // first row of this wave inside the block
+
+    for (int kc = 0; kc < n; kc += kKC) {
+        __syncthreads();
+        stage_rows(Ks, ld, K + base, F, dh, kc, kKC, n, tid, NT);
+        stage_rows(Vs, ld, V + base, F, dh, kc, kKC, n, tid, NT);
+        __syncthreads();
+        f32x4 p[RT][4];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) p[rt][kt] = dot_tiles(Ks, 16 * kt, Qs, wrow + 16 * rt, ld, nb, rem, j, g);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kc + 16 * kt + 4 * g + r;
+                    const float v = key < n ? p[rt][kt][r] * a.inv_scale : -INFINITY;       // list_ranker.py:223
+                    p[rt][kt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+            mx = xor_max(mx);
+            const float m_new = fmaxf(m[rt], mx);
+            const float corr = __expf(m[rt] - m_new);
+            float rs = 0.0f;
+            const int grow = bh * L + row0 + wrow + 16 * rt + j;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                f32x4 e;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { e[r] = __expf(p[rt][kt][r] - m_new); rs += e[r]; }
+                if (thr != 0) {                                                             // list_ranker.py:229
+                    uint32_t w0, w1;
+                    drop_bits(a.seed_lo, a.seed_hi, a.site, grow, (kc + 16 * kt + 4 * g) >> 2, w0, w1);
+                    e = drop4(e, w0, w1, thr, 1.0f);
+                }
+                p[rt][kt] = e;
+            }
+            rs = xor_sum(rs);
+            l[rt] = l[rt] * corr + rs;
+            m[rt] = m_new;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) acc[rt][dt] *= corr;
+        }
+        // O^T[d][row] += V^T[d][key] * P^T[key][row]                                          (list_ranker.py:236)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float *vrow = Vs + (size_t)(16 * kt + 4 * g + r) * ld + j;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const float va = vrow[16 * dt];
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) acc[rt][dt] = mfma4(va, p[rt][kt][r], acc[rt][dt]);
+                }
+            }
+        }
+    }
+    const float keep_inv = thr != 0 ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+    const bool vec = ((dh & 3) == 0) && ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(O + base) & 15) == 0);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int row = row0 + wrow + 16 * rt + j;
+        if (row >= L) continue;
+        const float inv = l[rt] > 0.0f ? keep_inv / l[rt] : 0.0f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d = 16 * dt + 4 * g;
+            const f32x4 o = acc[rt][dt] * inv;
+            float *dst = O + base + (size_t)row * F + d;
+            if (vec) { if (d < dh) *reinterpret_cast<f32x4 *>(dst) = o; }
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (d + e < dh) dst[e] = o[e];
+            }
+        }
+        if (g == 0) LSE[(size_t)bh * L + row] = l[rt] > 0.0f ? m[rt] + __logf(l[rt]) : 0.0f;
+    }
+}
+
+// D[bh][row] = sum_d dO[row][d] * O[row][d]  (= sum_key P[row][key] * dP[row][key], also under dropout)
+__global__ void __launch_bounds__(256)
+attn_rowdot_kernel(const float *__restrict__ O, const float *__restrict__ dO, AttnArgs a, float *__restrict__ Dv) {
+    const int lane = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    const size_t nrows = (size_t)a.B * a.H * a.L;
+    for (size_t r = (size_t)blockIdx.x * 16 + slot; r < nrows; r += (size_t)gridDim.x * 16) {
+        const int bh = (int)(r / a.L), row = (int)(r - (size_t)bh * a.L), b = bh / a.H, h = bh - b * a.H;
+        const size_t off = ((size_t)b * a.L + row) * a.F + (size_t)h * a.dh;
+        float s = 0.0f;
+        for (int d = lane; d < a.dh; d += 16) s += O[off + d] * dO[off + d];
+        s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
+        if (lane == 0) Dv[r] = s;
+    }
+}
+
+// ============================================================================================ backward: dQ
+template <int DT, int NW>
+__global__ void __launch_bounds__(NW * 64)
+mhsa_bwd_dq_kernel(const float *__restrict__ Q, const float *__restrict__ K, const float *__restrict__ V,
+                   const float *__restrict__ dO, const float *__restrict__ LSE, const float *__restrict__ Dv,
+                   const int32_t *__restrict__ lens, AttnArgs a, float *__restrict__ dQ) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int ld = attn_ld(DT), RPB = 16 * NW, NT = NW * 64;
+    float *Qs = smem, *Gs = Qs + (size_t)RPB * ld, *Ks = Gs + (size_t)RPB * ld, *Vs = Ks + (size_t)kKC * ld;
+    const int L = a.L, F = a.F, dh = a.dh;
+    const int nrb = (L + RPB - 1) / RPB;
+    const int rb = blockIdx.x % nrb, bh = blockIdx.x / nrb, b = bh / a.H, h = bh - b * a.H;
+    int n = lens ? lens[b] : L;
+    n = n < 0 ? 0 : (n > L ? L : n);
+    const size_t base = (size_t)b * L * F + (size_t)h * dh;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int row0 = rb * RPB, wrow = wave * 16;
+    const int dh4 = (dh + 3) & ~3, nb = dh4 >> 4, rem = (dh4 & 15) >> 2;
+    stage_rows(Qs, ld, Q + base, F, dh, row0, RPB, L, tid, NT);
+    stage_rows(Gs, ld, dO + base, F, dh, row0, RPB, L, tid, NT);
+    const int row = row0 + wrow + j;
+    const bool rok = row < L;
+    const float lse = rok ? LSE[(size_t)bh * L + row] : 0.0f;
+    const float Dr = rok ? Dv[(size_t)bh * L + row] : 0.0f;
+    const uint32_t thr = drop_thr(a.p_drop);
+    const float keep_inv = thr != 0 ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+    f32x4 dq[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kc = 0; kc < n; kc += kKC) {
+        __syncthreads();
+        stage_rows(Ks, ld, K + base, F, dh, kc, kKC, n, tid, NT);
+        stage_rows(Vs, ld, V + base, F, dh, kc, kKC, n, tid, NT);
+        __syncthreads();
+        f32x4 ds[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const f32x4 s = dot_tiles(Ks, 16 * kt, Qs, wrow, ld, nb, rem, j, g);
+            const f32x4 dp = dot_tiles(Vs, 16 * kt, Gs, wrow, ld, nb, rem, j, g);
+            f32x4 keep = {keep_inv, keep_inv, keep_inv, keep_inv};
+            if (thr != 0) {
+                uint32_t w0, w1;
+                drop_bits(a.seed_lo, a.seed_hi, a.site, bh * L + row, (kc + 16 * kt + 4 * g) >> 2, w0, w1);
+                keep = drop4(keep, w0, w1, thr, 1.0f);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kc + 16 * kt + 4 * g + r;
+                const float pr = (key < n && rok) ? __expf(s[r] * a.inv_scale - lse) : 0.0f;
+                ds[kt][r] = pr * (dp[r] * keep[r] - Dr) * a.inv_scale;
+            }
+        }
+        // dQ^T[d][row] += K^T[d][key] * dS^T[key][row]
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float *krow = Ks + (size_t)(16 * kt + 4 * g + r) * ld + j;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) dq[dt] = mfma4(krow[16 * dt], ds[kt][r], dq[dt]);
+            }
+        }
+    }
+    if (!rok) return;
+    const bool vec = ((dh & 3) == 0) && ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(dQ + base) & 15) == 0);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        const int d = 16 * dt + 4 * g;
+        float *dst = dQ + base + (size_t)row * F + d;
+        if (vec) { if (d < dh) *reinterpret_cast<f32x4 *>(dst) = dq[dt]; }
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (d + e < dh) dst[e] = dq[dt][e];
+        }
+    }
+}
+
+// ============================================================================================ backward: dK, dV
+template <int DT, int NW>
+__global__ void __launch_bounds__(NW * 64)
+mhsa_bwd_dkv_kernel(const float *__restrict__ Q, const float *__restrict__ K, const float *__restrict__ V,
+                    const float *__restrict__ dO, const float *__restrict__ LSE, const float *__restrict__ Dv,
+                    const int32_t *__restrict__ lens, AttnArgs a, float *__restrict__ dK, float *__restrict__ dV) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int ld = attn_ld(DT), KPB = 16 * NW, NT = NW * 64;
+    float *Ks = smem, *Vs = Ks + (size_t)KPB * ld, *Qs = Vs + (size_t)KPB * ld, *Gs = Qs + (size_t)kRC * ld;
+    float *lse_s = Gs + (size_t)kRC * ld, *D_s = lse_s + kRC;
+    const int L = a.L, F = a.F, dh = a.dh;
+    const int nkb = (L + KPB - 1) / KPB;
+    const int kb = blockIdx.x % nkb, bh = blockIdx.x / nkb, b = bh / a.H, h = bh - b * a.H;
+    int n = lens ? lens[b] : L;
+    n = n < 0 ? 0 : (n > L ? L : n);
+    const size_t base = (size_t)b * L * F + (size_t)h * dh;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int key0 = kb * KPB, wkey = wave * 16;
+    const int key = key0 + wkey + j;
+    const int dh4 = (dh + 3) & ~3, nb = dh4 >> 4, rem = (dh4 & 15) >> 2;
+    stage_rows(Ks, ld, K + base, F, dh, key0, KPB, n, tid, NT);
+    stage_rows(Vs, ld, V + base, F, dh, key0, KPB, n, tid, NT);
+    const uint32_t thr = drop_thr(a.p_drop);
+    const float keep_inv = thr != 0 ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+    f32x4 dk[DT], dv[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const bool live = key0 < n;                            // a block of padded keys only writes zeros
+
+    for (int rc = 0; live && rc < L; rc += kRC) {
+        __syncthreads();
+        stage_rows(Qs, ld, Q + base, F, dh, rc, kRC, L, tid, NT);
+        stage_rows(Gs, ld, dO + base, F, dh, rc, kRC, L, tid, NT);
+        if (tid < kRC) {
+            const int row = rc + tid;
+            lse_s[tid] = row < L ? LSE[(size_t)bh * L + row] : 0.0f;
+            D_s[tid] = row < L ? Dv[(size_t)bh * L + row] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rt = 0; rt < kRC / 16; ++rt) {
+            // S[row][key]: lane (j, g), reg r = row 16*rt + 4*g + r, key j
+            const f32x4 s = dot_tiles(Qs, 16 * rt, Ks, wkey, ld, nb, rem, j, g);
+            const f32x4 dp = dot_tiles(Gs, 16 * rt, Vs, wkey, ld, nb, rem, j, g);
+            f32x4 pd, ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lr = 16 * rt + 4 * g + r, row = rc + lr;
+                const float pr = (key < n && row < L) ? __expf(s[r] * a.inv_scale - lse_s[lr]) : 0.0f;
+                float keep = keep_inv;
+                if (thr != 0) keep = drop_keep1(a.seed_lo, a.seed_hi, a.site, bh * L + row, key, thr) ? keep_inv : 0.0f;
+                pd[r] = pr * keep;
+                ds[r] = pr * (dp[r] * keep - D_s[lr]) * a.inv_scale;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float *grow = Gs + (size_t)(16 * rt + 4 * g + r) * ld + j;
+                const float *qrow = Qs + (size_t)(16 * rt + 4 * g + r) * ld + j;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    dv[dt] = mfma4(grow[16 * dt], pd[r], dv[dt]);        // dV^T[d][key] += dO^T[d][row] * Pdrop[row][key]
+                    dk[dt] = mfma4(qrow[16 * dt], ds[r], dk[dt]);        // dK^T[d][key] += Q^T[d][row]  * dS[row][key]
+                }
+            }
+        }
+    }
+    if (key >= L) return;
+    const bool vec = ((dh & 3) == 0) && ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(dK + base) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(dV + base) & 15) == 0);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        const int d = 16 * dt + 4 * g;
+        float *pk = dK + base + (size_t)key * F + d, *pv = dV + base + (size_t)key * F + d;
+        if (vec) { if (d < dh) { *reinterpret_cast<f32x4 *>(pk) = dk[dt]; *reinterpret_cast<f32x4 *>(pv) = dv[dt]; } }
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (d + e < dh) { pk[e] = dk[dt][e]; pv[e] = dv[dt][e]; }
+        }
+    }
+}
+
+// Test helper: the keep mask (1 / 0) of the attention dropout, [B][H][L][L].
+__global__ void __launch_bounds__(256) attn_mask_kernel(AttnArgs a, float *__restrict__ out) {
+    const size_t tot = (size_t)a.B * a.H * a.L * a.L;
+    const uint32_t thr = drop_thr(a.p_drop);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (size_t)gridDim.x * 256) {
+        const int key = (int)(i % a.L);
+        const size_t grow = i / a.L;
+        out[i] = (thr == 0 || drop_keep1(a.seed_lo, a.seed_hi, a.site, (int)grow, key, thr)) ? 1.0f : 0.0f;
+    }
+}
+
+// ============================================================================================ LayerNorm (list_ranker.py:152-174)
+// y = a_2 * (x - mean) / (std + eps) + b_2, std UNBIASED (torch.Tensor.std default).  One 16-lane slot per row.
+// stats[row] = {mean, 1/(std + eps), std}.
+__global__ void __launch_bounds__(256)
+layernorm_fwd_kernel(const float *__restrict__ X, const float *__restrict__ a2, const float *__restrict__ b2, size_t R, int F,
+                     float eps, float *__restrict__ Y, float *__restrict__ stats) {
+    const int lane = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    for (size_t r = (size_t)blockIdx.x * 16 + slot; r < R; r += (size_t)gridDim.x * 16) {
+        const float *x = X + r * F;
+        float s = 0.0f;
+        for (int d = lane; d < F; d += 16) s += x[d];
+        s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
+        const float mean = s / (float)F;
+        float v = 0.0f;
+        for (int d = lane; d < F; d += 16) { const float c = x[d] - mean; v += c * c; }
+        v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+        const float sd = sqrtf(v / (float)(F - 1));
+        const float rinv = 1.0f / (sd + eps);
+        for (int d = lane; d < F; d += 16) Y[r * F + d] = a2[d] * (x[d] - mean) * rinv + b2[d];
+        if (lane == 0) { stats[3 * r] = mean; stats[3 * r + 1] = rinv; stats[3 * r + 2] = sd; }
+    }
+}
+
+// dX, and per-block partial sums of da_2 / db_2 in part[gridDim.x][2*F] (reduced by layernorm_reduce_kernel).
+__global__ void __launch_bounds__(256)
+layernorm_bwd_kernel(const float *__restrict__ X, const float *__restrict__ a2, const float *__restrict__ dY,
+                     const float *__restrict__ stats, size_t R, int F, float *__restrict__ dX, float *__restrict__ part) {
+    extern __shared__ float red[];                         // [16][2*F]
+    const int lane = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    float *mine = red + (size_t)slot * 2 * F;
+    for (int d = lane; d < 2 * F; d += 16) mine[d] = 0.0f;
+    for (size_t r = (size_t)blockIdx.x * 16 + slot; r < R; r += (size_t)gridDim.x * 16) {
+        const float *x = X + r * F, *dy = dY + r * F;
+        const float mean = stats[3 * r], rinv = stats[3 * r + 1], sd = stats[3 * r + 2];
+        float sg = 0.0f, sgc = 0.0f;
+        for (int d = lane; d < F; d += 16) {
+            const float c = x[d] - mean, gy = dy[d], gg = gy * a2[d];
+            sg += gg; sgc += gg * c;
+            mine[d] += gy * c * rinv;                      // d a_2
+            mine[F + d] += gy;                             // d b_2
+        }
+        sg += __shfl_xor(sg, 8); sg += __shfl_xor(sg, 4); sg += __shfl_xor(sg, 2); sg += __shfl_xor(sg, 1);
+        sgc += __shfl_xor(sgc, 8); sgc += __shfl_xor(sgc, 4); sgc += __shfl_xor(sgc, 2); sgc += __shfl_xor(sgc, 1);
+        const float gbar = sg / (float)F;
+        // d(1/(std+eps))/dx_k = -rinv^2 * (x_k - mean) / (std * (F-1));  a constant row (std = 0) has no defined derivative
+        // (the reference's autograd returns NaN there): its second term is dropped
+        const float k2 = sd > 0.0f ? rinv * rinv * sgc / (sd * (float)(F - 1)) : 0.0f;
+        for (int d = lane; d < F; d += 16) dX[r * F + d] = rinv * (dy[d] * a2[d] - gbar) - (x[d] - mean) * k2;
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < 2 * F; d += 256) {
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[(size_t)k * 2 * F + d];
+        part[(size_t)blockIdx.x * 2 * F + d] = s;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+layernorm_reduce_kernel(const float *__restrict__ part, int nblk, int F, float *__restrict__ da2, float *__restrict__ db2) {
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= 2 * F) return;
+    float s = 0.0f;
+    for (int k = 0; k < nblk; ++k) s += part[(size_t)k * 2 * F + d];
+    if (d < F) da2[d] = s; else db2[d - F] = s;
+}
+
+constexpr int kLnBlocks = 1024;
+
+template <class Fn> inline int dispatch_dt(int DT, Fn &&f) {
+    switch (DT) {
+        case 1: return f.template operator()<1>();
+        case 2: return f.template operator()<2>();
+        case 3: return f.template operator()<3>();
+        case 4: return f.template operator()<4>();
+        case 5: return f.template operator()<5>();
+        case 6: return f.template operator()<6>();
+        case 7: return f.template operator()<7>();
+        default: return f.template operator()<8>();
+    }
+}
+
+static int attn_args(const char *who, int B, int L, int F, int H, float p_drop, uint64_t seed, int site, AttnArgs &a) {
+    if (B < 0 || L <= 0 || F <= 0 || H <= 0 || F % H != 0) { set_error("%s: bad shape B=%d L=%d F=%d heads=%d", who, B, L, F, H); return PTR_ERR_INVALID_ARG; }
+    if (!(p_drop >= 0.0f && p_drop < 1.0f)) { set_error("%s: p_drop must be in [0,1)", who); return PTR_ERR_INVALID_ARG; }
+    const int dh = F / H;
+    if (dh > PTR_MHSA_MAX_HEAD_DIM) { set_error("%s: head dimension %d exceeds PTR_MHSA_MAX_HEAD_DIM=%d", who, dh, PTR_MHSA_MAX_HEAD_DIM); return PTR_ERR_UNSUPPORTED; }
+    if ((size_t)B * H * L >= (1u << 31)) { set_error("%s: B*H*L too large", who); return PTR_ERR_UNSUPPORTED; }
+    a = AttnArgs{B, L, H, dh, F, 1.0f / sqrtf((float)dh), p_drop, (uint32_t)seed, (uint32_t)(seed >> 32), site};
+    return 0;
+}
+
+}  // namespace ptr
+
+constexpr size_t kAttnLdsCap = 160 * 1024;
+
+extern "C" int ptr_mhsa_forward(const float *Q, const float *K, const float *V, const int32_t *lens, int B, int L, int F, int n_heads,
+                                float p_drop, uint64_t seed, int site, float *O, float *lse, void *stream) {
+    using namespace ptr;
+    const char *who = "ptr_mhsa_forward";
+    AttnArgs a;
+    if (int rc = attn_args(who, B, L, F, n_heads, p_drop, seed, site, a)) return rc;
+    if (B == 0) return 0;
+    if (!Q || !K || !V || !O || !lse) { set_error("%s: NULL pointer", who); return PTR_ERR_INVALID_ARG; }
+    hipStream_t st = as_stream(stream);
+    const int DT = (a.dh + 15) / 16;
+    return dispatch_dt(DT, [&]<int D>() -> int {
+        auto launch = [&]<int RT, int NW>() -> int {
+            constexpr int RPB = 16 * RT * NW;
+            auto kern = mhsa_fwd_kernel<D, RT, NW>;
+            const size_t lds = ((size_t)RPB + 2 * kKC) * attn_ld(D) * sizeof(float);
+            if (int e = allow_lds(kern, lds)) return e;
+            const int nrb = (L + RPB - 1) / RPB;
+            hipLaunchKernelGGL(kern, dim3((unsigned)((size_t)B * n_heads * nrb)), dim3(NW * 64), lds, st, Q, K, V, lens, a, O, lse);
+            return check_hip(hipGetLastError(), who);
+        };
+        // two row tiles per wave when the rows exist and the Q tile fits next to the K / V chunks
+        constexpr size_t lds2 = ((size_t)32 * kAW + 2 * kKC) * attn_ld(D) * sizeof(float);
+        if constexpr (lds2 <= kAttnLdsCap) { if (L > 16 * kAW) return launch.template operator()<2, kAW>(); }
+        if (L > 64) return launch.template operator()<1, kAW>();
+        return launch.template operator()<1, 4>();
+    });
+}
+
+extern "C" int ptr_mhsa_backward(const float *Q, const float *K, const float *V, const float *O, const float *dO, const float *lse,
+                                 const int32_t *lens, int B, int L, int F, int n_heads, float p_drop, uint64_t seed, int site,
+                                 float *dvec, float *dQ, float *dK, float *dV, void *stream) {
+    using namespace ptr;
+    const char *who = "ptr_mhsa_backward";
+    AttnArgs a;
+    if (int rc = attn_args(who, B, L, F, n_heads, p_drop, seed, site, a)) return rc;
+    if (B == 0) return 0;
+    if (!Q || !K || !V || !O || !dO || !lse || !dvec || !dQ || !dK || !dV) { set_error("%s: NULL pointer", who); return PTR_ERR_INVALID_ARG; }
+    hipStream_t st = as_stream(stream);
+    const size_t nrows = (size_t)B * n_heads * L;
+    const int rblocks = (int)((nrows + 15) / 16 < 4096 ? (nrows + 15) / 16 : 4096);
+    hipLaunchKernelGGL(attn_rowdot_kernel, dim3(rblocks), dim3(256), 0, st, O, dO, a, dvec);
+    if (int rc = check_hip(hipGetLastError(), who)) return rc;
+    const int DT = (a.dh + 15) / 16;
+    return dispatch_dt(DT, [&]<int D>() -> int {
+        auto launch_dq = [&]<int NW>() -> int {
+            constexpr int RPB = 16 * NW;
+            auto kern = mhsa_bwd_dq_kernel<D, NW>;
+            const size_t lds = ((size_t)2 * RPB + 2 * kKC) * attn_ld(D) * sizeof(float);
+            if (int e = allow_lds(kern, lds)) return e;
+            const int nrb = (L + RPB - 1) / RPB;
+            hipLaunchKernelGGL(kern, dim3((unsigned)((size_t)B * n_heads * nrb)), dim3(NW * 64), lds, st, Q, K, V, dO, lse, dvec, lens, a, dQ);
+            return check_hip(hipGetLastError(), who);
+        };
+        auto launch_dkv = [&]<int NW>() -> int {
+            constexpr int KPB = 16 * NW;
+            auto kern = mhsa_bwd_dkv_kernel<D, NW>;
+            const size_t lds = (((size_t)2 * KPB + 2 * kRC) * attn_ld(D) + 2 * kRC) * sizeof(float);
+            if (int e = allow_lds(kern, lds)) return e;
+            const int nkb = (L + KPB - 1) / KPB;
+            hipLaunchKernelGGL(kern, dim3((unsigned)((size_t)B * n_heads * nkb)), dim3(NW * 64), lds, st, Q, K, V, dO, lse, dvec, lens, a, dK, dV);
+            return check_hip(hipGetLastError(), who);
+        };
+        constexpr size_t lds_dq8 = ((size_t)2 * 16 * kAW + 2 * kKC) * attn_ld(D) * sizeof(float);
+        constexpr size_t lds_dkv8 = (((size_t)2 * 16 * kAW + 2 * kRC) * attn_ld(D) + 2 * kRC) * sizeof(float);
+        int rc;
+        if (lds_dq8 <= kAttnLdsCap && L > 64) rc = launch_dq.template operator()<kAW>(); else rc = launch_dq.template operator()<4>();
+        if (rc) return rc;
+        if (lds_dkv8 <= kAttnLdsCap && L > 64) rc = launch_dkv.template operator()<kAW>(); else rc = launch_dkv.template operator()<4>();
+        return rc;
+    });
+}
+
+extern "C" int ptr_mhsa_dropout_mask(int B, int L, int n_heads, float p_drop, uint64_t seed, int site, float *out, void *stream) {
+    using namespace ptr;
+    const char *who = "ptr_mhsa_dropout_mask";
+    AttnArgs a;
+    if (int rc = attn_args(who, B, L, n_heads, n_heads, p_drop, seed, site, a)) return rc;
+    if (B == 0) return 0;
+    if (!out) { set_error("%s: NULL pointer", who); return PTR_ERR_INVALID_ARG; }
+    hipLaunchKernelGGL(attn_mask_kernel, dim3(2048), dim3(256), 0, as_stream(stream), a, out);
+    return check_hip(hipGetLastError(), who);
+}
+
+extern "C" int ptr_layernorm_forward(const float *X, const float *a2, const float *b2, int64_t R, int F, float eps, float *Y,
+                                     float *stats, void *stream) {
+    using namespace ptr;
+    const char *who = "ptr_layernorm_forward";
+    if (R < 0 || F < 2) { set_error("%s: bad shape R=%lld F=%d", who, (long long)R, F); return PTR_ERR_INVALID_ARG; }
+    if (R == 0) return 0;
+    if (!X || !a2 || !b2 || !Y || !stats) { set_error("%s: NULL pointer", who); return PTR_ERR_INVALID_ARG; }
+    const int blocks = (int)((R + 15) / 16 < 8192 ? (R + 15) / 16 : 8192);
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), X, a2, b2, (size_t)R, F, eps, Y, stats);
+    return check_hip(hipGetLastError(), who);
+}
+
+extern "C" size_t ptr_layernorm_backward_ws_floats(int F) { return (size_t)ptr::kLnBlocks * 2 * (size_t)(F > 0 ? F : 0); }
+
+extern "C" int ptr_layernorm_backward(const float *X, const float *a2, const float *dY, const float *stats, int64_t R, int F, float *ws,
+                                      float *dX, float *da2, float *db2, void *stream) {
+    using namespace ptr;
+    const char *who = "ptr_layernorm_backward";
+    if (R < 0 || F < 2) { set_error("%s: bad shape R=%lld F=%d", who, (long long)R, F); return PTR_ERR_INVALID_ARG; }
+    if (!a2 || !da2 || !db2 || !ws || (R > 0 && (!X || !dY || !stats || !dX))) { set_error("%s: NULL pointer", who); return PTR_ERR_INVALID_ARG; }
+    const size_t lds = (size_t)16 * 2 * F * sizeof(float);
+    if (lds > 160 * 1024) { set_error("%s: F=%d too wide", who, F); return PTR_ERR_UNSUPPORTED; }
+    if (int e = allow_lds(layernorm_bwd_kernel, lds)) return e;
+    hipStream_t st = as_stream(stream);
+    int blocks = (int)((R + 15) / 16 < kLnBlocks ? (R + 15) / 16 : kLnBlocks);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), lds, st, X, a2, dY, stats, (size_t)R, F,
+                       dX, ws);
+    if (int rc = check_hip(hipGetLastError(), who)) return rc;
+    hipLaunchKernelGGL(layernorm_reduce_kernel, dim3((2 * F + 255) / 256), dim3(256), 0, st, ws, blocks, F, da2, db2);
+    return check_hip(hipGetLastError(), who);
+}

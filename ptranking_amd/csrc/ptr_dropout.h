@@ -1,0 +1,39 @@
+// Counter-based dropout bits and the fp32 MFMA vector type, shared by the fused scorers (scorer.hip, listsf.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ptr {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+// 64 random bits for features [4*fg, 4*fg+3] of `row` at dropout site `site` (site l = the Dropout in front of hidden layer l)
+__device__ __forceinline__ void drop_bits(uint32_t seed_lo, uint32_t seed_hi, int site, int row, int fg, uint32_t &w0, uint32_t &w1) {
+    const uint32_t key = (uint32_t)row * 0x9E3779B1u + (uint32_t)fg * 0x85EBCA77u + (uint32_t)site * 0xC2B2AE3Du;
+    w0 = lowbias32(key ^ seed_lo);
+    w1 = lowbias32(w0 ^ seed_hi ^ 0x68E31DA4u);
+}
+__device__ __forceinline__ f32x4 drop4(f32x4 v, uint32_t w0, uint32_t w1, uint32_t thr, float scale) {
+    // multiplicative masks on purpose: with a select hipcc sinks the producing global load under the predicate and
+    // serialises it behind a vmcnt(0); x * 0.0f cannot be folded without fast-math, so the load stays unconditional
+    f32x4 o;
+    o[0] = v[0] * ((w0 & 0xFFFFu) >= thr ? scale : 0.0f);
+    o[1] = v[1] * ((w0 >> 16) >= thr ? scale : 0.0f);
+    o[2] = v[2] * ((w1 & 0xFFFFu) >= thr ? scale : 0.0f);
+    o[3] = v[3] * ((w1 >> 16) >= thr ? scale : 0.0f);
+    return o;
+}
+__device__ __forceinline__ bool drop_keep1(uint32_t seed_lo, uint32_t seed_hi, int site, int row, int k, uint32_t thr) {
+    uint32_t w0, w1;
+    drop_bits(seed_lo, seed_hi, site, row, k >> 2, w0, w1);
+    const uint32_t w = (k & 2) ? w1 : w0;
+    return ((k & 1) ? (w >> 16) : (w & 0xFFFFu)) >= thr;
+}
+
+__device__ __forceinline__ uint32_t drop_thr(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
+
+}  // namespace ptr

@@ -24,10 +24,9 @@
 #include <stdlib.h>
 
 #include "ptr_device.h"
+#include "ptr_dropout.h"
 
 namespace ptr {
-
-using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kH = 100;          // hidden width, hard-wired in the reference (point_ranker.py:30)
 constexpr int kHP = 112;         // padded to 7 MFMA tiles of 16
@@ -45,41 +44,12 @@ __host__ __device__ inline size_t off_wout(int NL, int F) { return off_W(NL, F);
 __host__ __device__ inline size_t n_params(int NL, int F) { return off_wout(NL, F) + kH + 1; }
 __host__ __device__ inline int ld_w1(int F) { return (F + 3) / 4 * 4 + 4; }   // LDS leading dimension of W1 (bank spread)
 
-// ---------------------------------------------------------------------------------------------- dropout bits
-__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
-    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
-    return x;
-}
-// 64 random bits for features [4*fg, 4*fg+3] of `row` at dropout site `site` (site l = the Dropout in front of hidden layer l)
-__device__ __forceinline__ void drop_bits(uint32_t seed_lo, uint32_t seed_hi, int site, int row, int fg, uint32_t &w0, uint32_t &w1) {
-    const uint32_t key = (uint32_t)row * 0x9E3779B1u + (uint32_t)fg * 0x85EBCA77u + (uint32_t)site * 0xC2B2AE3Du;
-    w0 = lowbias32(key ^ seed_lo);
-    w1 = lowbias32(w0 ^ seed_hi ^ 0x68E31DA4u);
-}
-__device__ __forceinline__ f32x4 drop4(f32x4 v, uint32_t w0, uint32_t w1, uint32_t thr, float scale) {
-    // multiplicative masks on purpose: with a select hipcc sinks the producing global load under the predicate and
-    // serialises it behind a vmcnt(0); x * 0.0f cannot be folded without fast-math, so the load stays unconditional
-    f32x4 o;
-    o[0] = v[0] * ((w0 & 0xFFFFu) >= thr ? scale : 0.0f);
-    o[1] = v[1] * ((w0 >> 16) >= thr ? scale : 0.0f);
-    o[2] = v[2] * ((w1 & 0xFFFFu) >= thr ? scale : 0.0f);
-    o[3] = v[3] * ((w1 >> 16) >= thr ? scale : 0.0f);
-    return o;
-}
-__device__ __forceinline__ bool drop_keep1(uint32_t seed_lo, uint32_t seed_hi, int site, int row, int k, uint32_t thr) {
-    uint32_t w0, w1;
-    drop_bits(seed_lo, seed_hi, site, row, k >> 2, w0, w1);
-    const uint32_t w = (k & 2) ? w1 : w0;
-    return ((k & 1) ? (w >> 16) : (w & 0xFFFFu)) >= thr;
-}
-
 struct MlpArgs {
     int R, F, NL;
     float p_drop;            // 0 => no dropout (eval mode)
     uint32_t seed_lo, seed_hi;
 };
 
-__device__ __forceinline__ uint32_t drop_thr(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
 
 // Stage a [rows_valid][cols_valid] row-major matrix into LDS as [kHP][ld], zero padded.  transpose: dst[c][r] = src[r][c].
 __device__ __forceinline__ void stage_matrix(float *dst, int ld, const float *src, int rows, int cols, bool transpose, int tid, int nthr) {

@@ -14,6 +14,7 @@ import torch
 from . import dp
 from . import functional as F_
 from .host import DeviceEvaluator, DeviceTrainLoop, PointScorerRanker, is_multilabel
+from .listsf import FusedListScorerMixin
 from .scorer import FusedScorerMixin
 
 RANKER_NAMES = ("RankNet", "LambdaRank", "LambdaLoss", "ApproxNDCG", "ListNet", "ListMLE", "STListNet", "RankCosine", "RankMSE", "SoftRank")
@@ -182,17 +183,17 @@ class ListMLELoss(FusedStepMixin):
 def make_ranker_classes(base=PointScorerRanker):
     """Return {name: class} built on `base` (anything with the reference's AdhocNeuralRanker interface)."""
 
-    class RankNet(RankNetLoss, FusedScorerMixin, DeviceTrainLoop, DeviceEvaluator, base):
+    class RankNet(RankNetLoss, FusedScorerMixin, FusedListScorerMixin, DeviceTrainLoop, DeviceEvaluator, base):
         def __init__(self, sf_para_dict=None, model_para_dict=None, gpu=False, device=None):
             base.__init__(self, id='RankNet', sf_para_dict=sf_para_dict, gpu=gpu, device=device)
             self.sigma = model_para_dict['sigma']
 
-    class LambdaRank(LambdaRankLoss, FusedScorerMixin, DeviceTrainLoop, DeviceEvaluator, base):
+    class LambdaRank(LambdaRankLoss, FusedScorerMixin, FusedListScorerMixin, DeviceTrainLoop, DeviceEvaluator, base):
         def __init__(self, sf_para_dict=None, model_para_dict=None, gpu=False, device=None):
             base.__init__(self, id='LambdaRank', sf_para_dict=sf_para_dict, gpu=gpu, device=device)
             self.sigma = model_para_dict['sigma']
 
-    class LambdaLoss(LambdaLossLoss, FusedScorerMixin, DeviceTrainLoop, DeviceEvaluator, base):
+    class LambdaLoss(LambdaLossLoss, FusedScorerMixin, FusedListScorerMixin, DeviceTrainLoop, DeviceEvaluator, base):
         def __init__(self, sf_para_dict=None, model_para_dict=None, gpu=False, device=None):
             base.__init__(self, id='LambdaLoss', sf_para_dict=sf_para_dict, gpu=gpu, device=device)
             self.lambdaloss_dict = model_para_dict
@@ -202,33 +203,33 @@ def make_ranker_classes(base=PointScorerRanker):
             if self.loss_type not in F_.LAMBDALOSS_TYPES:
                 raise NotImplementedError(f"loss_type {self.loss_type!r}")
 
-    class ApproxNDCG(ApproxNDCGLoss, FusedScorerMixin, DeviceTrainLoop, DeviceEvaluator, base):
+    class ApproxNDCG(ApproxNDCGLoss, FusedScorerMixin, FusedListScorerMixin, DeviceTrainLoop, DeviceEvaluator, base):
         def __init__(self, sf_para_dict=None, model_para_dict=None, gpu=False, device=None):
             base.__init__(self, id='ApproxNDCG', sf_para_dict=sf_para_dict, gpu=gpu, device=device)
             self.alpha = model_para_dict['alpha']
 
-    class ListNet(ListNetLoss, FusedScorerMixin, DeviceTrainLoop, DeviceEvaluator, base):
+    class ListNet(ListNetLoss, FusedScorerMixin, FusedListScorerMixin, DeviceTrainLoop, DeviceEvaluator, base):
         def __init__(self, sf_para_dict=None, gpu=False, device=None):
             base.__init__(self, id='ListNet', sf_para_dict=sf_para_dict, gpu=gpu, device=device)
 
-    class ListMLE(ListMLELoss, FusedScorerMixin, DeviceTrainLoop, DeviceEvaluator, base):
+    class ListMLE(ListMLELoss, FusedScorerMixin, FusedListScorerMixin, DeviceTrainLoop, DeviceEvaluator, base):
         def __init__(self, sf_para_dict=None, model_para_dict=None, gpu=False, device=None):
             base.__init__(self, id='ListMLE', sf_para_dict=sf_para_dict, gpu=gpu, device=device)
 
-    class STListNet(STListNetLoss, FusedScorerMixin, DeviceTrainLoop, DeviceEvaluator, base):
+    class STListNet(STListNetLoss, FusedScorerMixin, FusedListScorerMixin, DeviceTrainLoop, DeviceEvaluator, base):
         def __init__(self, sf_para_dict=None, model_para_dict=None, gpu=False, device=None):
             base.__init__(self, id='STListNet', sf_para_dict=sf_para_dict, gpu=gpu, device=device)
             self.temperature = model_para_dict['temperature']
 
-    class RankCosine(RankCosineLoss, FusedScorerMixin, DeviceTrainLoop, DeviceEvaluator, base):
+    class RankCosine(RankCosineLoss, FusedScorerMixin, FusedListScorerMixin, DeviceTrainLoop, DeviceEvaluator, base):
         def __init__(self, sf_para_dict=None, gpu=False, device=None):
             base.__init__(self, id='RankCosine', sf_para_dict=sf_para_dict, gpu=gpu, device=device)
 
-    class RankMSE(RankMSELoss, FusedScorerMixin, DeviceTrainLoop, DeviceEvaluator, base):
+    class RankMSE(RankMSELoss, FusedScorerMixin, FusedListScorerMixin, DeviceTrainLoop, DeviceEvaluator, base):
         def __init__(self, sf_para_dict=None, gpu=False, device=None):
             base.__init__(self, id='RankMSE', sf_para_dict=sf_para_dict, gpu=gpu, device=device)
 
-    class SoftRank(SoftRankLoss, FusedScorerMixin, DeviceTrainLoop, DeviceEvaluator, base):
+    class SoftRank(SoftRankLoss, FusedScorerMixin, FusedListScorerMixin, DeviceTrainLoop, DeviceEvaluator, base):
         def __init__(self, sf_para_dict=None, model_para_dict=None, gpu=False, device=None):
             base.__init__(self, id='SoftRank', sf_para_dict=sf_para_dict, gpu=gpu, device=device)
             self.delta_value = float(model_para_dict['delta'])

@@ -58,6 +58,23 @@ def siblings():
     return _CACHE["s"]
 
 
+def listsf():
+    """{family: {case: {field (may contain '/'): array}}} for listsf.npz (keys 'fam/case/field...')."""
+    if "ls" not in _CACHE:
+        z = np.load(os.path.join(GOLDEN_DIR, "listsf.npz"), allow_pickle=False)
+        fams = defaultdict(lambda: defaultdict(dict))
+        for key in z.files:
+            fam, case, field = key.split("/", 2)
+            fams[fam][case][field] = z[key]
+        _CACHE["ls"] = {f: dict(c) for f, c in fams.items()}
+    return _CACHE["ls"]
+
+
+def sub(case, prefix):
+    """Fields of a listsf case under 'prefix/' with the prefix stripped."""
+    return {k[len(prefix) + 1:]: v for k, v in case.items() if k.startswith(prefix + "/")}
+
+
 def case_ids(fam, which="losses"):
-    d = {"losses": losses, "metrics": metrics, "siblings": siblings}[which]()
+    d = {"losses": losses, "metrics": metrics, "siblings": siblings, "listsf": listsf}[which]()
     return sorted(d[fam].keys())

@@ -1,0 +1,160 @@
+"""GPU: the fused listsf pieces (fp32-MFMA attention core, LayerNorm) and the module mirror against the reference's golden
+outputs and against the oracle (torch-CPU restatement).  Tolerance |got-ref| <= 1e-5 + 1e-5*max|ref| (golden_util.assert_close)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as G
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+@pytest.fixture(scope="module")
+def LS():
+    from ptranking_amd import listsf
+    return listsf
+
+
+@pytest.mark.parametrize("name", G.case_ids("layernorm", "listsf"))
+def test_golden_layernorm(LS, name):
+    c = G.listsf()["layernorm"][name]
+    ln = LS.LayerNorm(c["x"].shape[-1]).to(DEV)
+    ln.load_state_dict({k: _t(v) for k, v in G.sub(c, "sd").items()})
+    x = _t(c["x"]).to(DEV).requires_grad_(True)
+    y = ln(x)
+    (y * _t(c["R"]).to(DEV)).sum().backward()
+    G.assert_close(y.detach().cpu().numpy(), c["y"], "y"); G.assert_close(x.grad.cpu().numpy(), c["dx"], "dx")
+    for k, p in ln.named_parameters():
+        G.assert_close(p.grad.cpu().numpy(), c[f"grad/{k}"], k)
+
+
+@pytest.mark.parametrize("name", G.case_ids("mhsa", "listsf"))
+def test_golden_mhsa(LS, name):
+    c = G.listsf()["mhsa"][name]
+    Fd = c["x"].shape[-1]
+    m = LS.MultiheadAttention(hid_dim=Fd, n_heads=int(c["n_heads"]), dropout=0.1).to(DEV)
+    m.load_state_dict({k: _t(v) for k, v in G.sub(c, "sd").items()})
+    m.eval()
+    x = _t(c["x"]).to(DEV).requires_grad_(True)
+    y = m(x)
+    (y * _t(c["R"]).to(DEV)).sum().backward()
+    G.assert_close(y.detach().cpu().numpy(), c["y"], "y"); G.assert_close(x.grad.cpu().numpy(), c["dx"], "dx")
+    for k, p in m.named_parameters():
+        G.assert_close(p.grad.cpu().numpy(), c[f"grad/{k}"], k)
+
+
+@pytest.mark.parametrize("enc", ["DASALC", "AllRank", "AttnDIN"])
+def test_golden_listsf_scorer(LS, enc):
+    c = G.listsf()["listsf"][enc]
+    mods = LS.build_listsf(num_features=24, ff_dims=[16, 32], AF='R', TL_AF='GE', apply_tl_af=False, BN=False, bn_type='BN2',
+                           bn_affine=False, n_heads=2, encoder_layers=2, encoder_type=enc)
+    for part, m in mods.items():
+        m.load_state_dict({k: _t(v) for k, v in G.sub(G.sub(c, "sd"), part).items()})
+        m.to(DEV).eval()
+    preds = LS.listsf_forward(mods, enc, _t(c["x"]).to(DEV))
+    (preds * _t(c["R"]).to(DEV)).sum().backward()
+    G.assert_close(preds.detach().cpu().numpy(), c["preds"], "preds")
+    for part, m in mods.items():
+        for k, p in m.named_parameters():
+            got = p.grad.cpu().numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+            G.assert_close(got, c[f"grad/{part}/{k}"], f"{part}/{k}")
+
+
+# (B, L, F, heads): head dims 68 (C5), 17 (scalar path), 128 (max), 4; L across chunk / tile boundaries
+CORE_SHAPES = [(3, 256, 136, 2), (2, 100, 68, 4), (2, 64, 256, 2), (5, 7, 8, 2), (2, 129, 136, 2), (1, 300, 40, 1), (2, 513, 64, 4)]
+
+
+@pytest.mark.parametrize("B,L,Fd,H", CORE_SHAPES)
+@pytest.mark.parametrize("mode", ["eval", "dropout", "lens", "dropout+lens"])
+def test_oracle_mhsa_core(LS, B, L, Fd, H, mode):
+    from oracle import torch_ref as T
+    rng = np.random.default_rng(1000 * L + Fd + H)
+    q, k, v, R = (torch.from_numpy(rng.standard_normal((B, L, Fd)).astype(np.float32)) for _ in range(4))
+    q = q * 2.0          # sharper softmax
+    p = 0.1 if "dropout" in mode else 0.0
+    lens = None
+    if "lens" in mode:
+        lens = torch.from_numpy(rng.integers(1, L + 1, size=B).astype(np.int32)); lens[0] = L
+    seed, site = 12345 + L, 3
+    mask = LS.mhsa_dropout_mask(B, L, H, p, seed, site, DEV).cpu() if p > 0 else None
+    if mask is not None:
+        keep = float(mask.mean())
+        assert abs(keep - 0.9) < 0.02, keep
+    qc, kc, vc = (t.clone().requires_grad_(True) for t in (q, k, v))
+    ref = T.mhsa_core_ref(qc, kc, vc, H, keep_mask=mask, p_drop=p, lens=lens)
+    (ref * R).sum().backward()
+    qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    out = LS.mhsa_core(qd, kd, vd, H, p_drop=p, seed=seed, site=site, lens=None if lens is None else lens.to(DEV))
+    (out * R.to(DEV)).sum().backward()
+    G.assert_close(out.detach().cpu().numpy(), ref.detach().numpy(), "O")
+    G.assert_close(qd.grad.cpu().numpy(), qc.grad.numpy(), "dQ")
+    G.assert_close(kd.grad.cpu().numpy(), kc.grad.numpy(), "dK")
+    G.assert_close(vd.grad.cpu().numpy(), vc.grad.numpy(), "dV")
+    # bit-stable: a second run gives identical bits (no atomics anywhere)
+    qd2, kd2, vd2 = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    out2 = LS.mhsa_core(qd2, kd2, vd2, H, p_drop=p, seed=seed, site=site, lens=None if lens is None else lens.to(DEV))
+    (out2 * R.to(DEV)).sum().backward()
+    assert torch.equal(out, out2) and torch.equal(qd.grad, qd2.grad) and torch.equal(kd.grad, kd2.grad) and torch.equal(vd.grad, vd2.grad)
+
+
+@pytest.mark.parametrize("R,Fd", [(1, 2), (17, 136), (4099, 24), (300, 700)])
+def test_oracle_layernorm(LS, R, Fd):
+    from oracle import torch_ref as T
+    rng = np.random.default_rng(R + Fd)
+    x = torch.from_numpy((rng.standard_normal((R, Fd)) * 2 + 0.5).astype(np.float32))
+    a2, b2, W = (torch.from_numpy(rng.standard_normal(s).astype(np.float32)) for s in ((Fd,), (Fd,), (R, Fd)))
+    xc, ac, bc = (t.clone().requires_grad_(True) for t in (x, a2, b2))
+    ref = T.layer_norm_ref(xc, ac, bc)
+    (ref * W).sum().backward()
+    xd, ad, bd = (t.to(DEV).requires_grad_(True) for t in (x, a2, b2))
+    out = LS.layer_norm(xd, ad, bd)
+    (out * W.to(DEV)).sum().backward()
+    G.assert_close(out.detach().cpu().numpy(), ref.detach().numpy(), "y")
+    G.assert_close(xd.grad.cpu().numpy(), xc.grad.numpy(), "dx")
+    G.assert_close(ad.grad.cpu().numpy(), ac.grad.numpy(), "da")
+    G.assert_close(bd.grad.cpu().numpy(), bc.grad.numpy(), "db")
+
+
+def test_padded_rows_do_not_leak(LS):
+    """Keys beyond lens must not influence the valid rows' outputs or gradients."""
+    torch.manual_seed(0)
+    B, L, Fd, H = 3, 96, 136, 2
+    lens = torch.tensor([96, 40, 1], dtype=torch.int32, device=DEV)
+    q, k, v = (torch.randn(B, L, Fd, device=DEV) for _ in range(3))
+    k2, v2 = k.clone(), v.clone()
+    for b in range(B):
+        k2[b, lens[b]:] = 1e3 * torch.randn_like(k2[b, lens[b]:]); v2[b, lens[b]:] = 1e3
+    o1 = LS.mhsa_core(q, k, v, H, lens=lens)
+    o2 = LS.mhsa_core(q, k2, v2, H, lens=lens)
+    assert torch.equal(o1, o2)
+
+
+def test_c5_ranker_trains(LS):
+    """BASELINE config 5: listsf (2 heads, 6 encoder layers, DASALC) + LambdaLoss NDCG_Loss2, L = 256, 136 features."""
+    import ptranking_amd as pa
+    listsf = dict(num_features=136, ff_dims=[128, 256, 512], AF='R', TL_AF='GE', apply_tl_af=False, BN=False, bn_type='BN2',
+                  bn_affine=False, n_heads=2, encoder_layers=6, encoder_type='DASALC')
+    sf = dict(sf_id='listsf', opt='Adagrad', lr=0.001, listsf=listsf)
+    r = pa.LambdaLoss(sf_para_dict=copy.deepcopy(sf), model_para_dict=dict(pa.DEFAULT_PARAS["LambdaLoss"]), gpu=True, device=DEV)
+    r.init(); r.train_mode()
+    torch.manual_seed(3)
+    X = torch.randn(8, 256, 136, device=DEV)
+    Y = torch.sort(torch.randint(0, 5, (8, 256), device=DEV).float(), dim=1, descending=True)[0].contiguous()
+    before = [p.detach().clone() for p in r.get_parameters()]
+    losses = []
+    for _ in range(3):
+        loss, stop = r.train_op(X, Y, epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
+        assert torch.isfinite(loss) and not stop
+        losses.append(float(loss))
+    changed = sum(int(not torch.equal(a, b)) for a, b in zip(before, r.get_parameters()))
+    assert changed >= len(before) - 2, (changed, len(before))
+    r.eval_mode()
+    ndcg = r.ndcg_at_ks(test_data=[(list(range(8)), X, Y)], ks=[1, 5, 10], label_type=pa.LABEL_TYPE.MultiLabel, presort=True)
+    assert ndcg.shape == (3,) and torch.isfinite(ndcg).all()
