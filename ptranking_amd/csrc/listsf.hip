@@ -61,23 +61,97 @@ __device__ __forceinline__ void stage_rows(float *dst, int ld, const float *src,
     }
 }
 
-// acc[r] += sum_d A[a_row + j][d] * B[b_row + j][d] over the head dimension, both tiles in LDS with leading dimension ld.
-// Result lane (j, g), reg r: (A row 4*g + r) x (B row j).
-__device__ __forceinline__ f32x4 dot_tiles(const float *As, int a_row, const float *Bs, int b_row, int ld, int nb, int rem, int j, int g) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const float *ap = As + (size_t)(a_row + j) * ld;
-    const float *bp = Bs + (size_t)(b_row + j) * ld;
-    for (int blk = 0; blk < nb; ++blk) {                    // k-slot (c, g) <-> d = 16*blk + 4*g + c
-        const f32x4 a = *reinterpret_cast<const f32x4 *>(ap + 16 * blk + 4 * g);
-        const f32x4 b = *reinterpret_cast<const f32x4 *>(bp + 16 * blk + 4 * g);
+// Software-pipelined variant of stage_rows: load() issues the global loads of the NEXT chunk into registers before the
+// current chunk is consumed, store() commits them to LDS afterwards, so the HBM/L2 latency hides behind the MFMA work.
+template <int NROWS, int LD, int NT>
+struct RowStage {
+    static constexpr int LD4 = LD / 4, TOT = NROWS * LD4, NIT = (TOT + NT - 1) / NT;
+    f32x4 v[NIT];
+    // Raw loads only (clamped, always-valid addresses): nothing here may consume the loaded values, or the s_waitcnt lands
+    // in front of the compute phase the loads are supposed to hide behind.  store() applies the zero padding.
+    __device__ __forceinline__ void load(const float *src, int F, int dh, int row0, int row_lim, int tid) {
+        const bool vec = ((dh & 3) == 0) && ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+        const int last = row_lim > 0 ? row_lim - 1 : 0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc = mfma4(a[c], b[c], acc);
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NT;
+            const int r = idx / LD4, c = (idx - r * LD4) << 2;
+            const int row = row0 + r < row_lim ? row0 + r : last;
+            if (vec) {
+                v[it] = *reinterpret_cast<const f32x4 *>(src + (size_t)row * F + (c < dh ? c : 0));
+            } else {
+                const float *p = src + (size_t)row * F;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[it][e] = p[c + e < dh ? c + e : 0];
+            }
+        }
     }
-    for (int t = 0; t < rem; ++t) {                         // tail of dh % 16: k-slot g <-> d = 16*nb + 4*t + g
-        const int d = 16 * nb + 4 * t + g;
-        acc = mfma4(ap[d], bp[d], acc);
+    __device__ __forceinline__ void store(float *dst, int dh, int row0, int row_lim, int tid) const {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NT;
+            if (idx < TOT) {
+                const int r = idx / LD4, c = (idx - r * LD4) << 2;
+                const bool rok = row0 + r < row_lim;
+                f32x4 t = v[it];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] *= (rok && c + e < dh) ? 1.0f : 0.0f;
+                *reinterpret_cast<f32x4 *>(dst + (size_t)r * LD + c) = t;
+            }
+        }
     }
-    return acc;
+};
+
+// One MFMA operand (16 rows x head dimension) held in registers in k-slot order: v[blk][c] <-> d = 16*blk + 4*g + c,
+// t[i] <-> d = 16*nb + 4*i + g (the dh % 16 tail).  Loaded once from an LDS tile row (row = tile row of lane j).
+template <int DT>
+struct OperandRegs {
+    f32x4 v[DT];
+    float t[3];
+    __device__ __forceinline__ void load(const float *row, int nb, int rem, int g) {
+#pragma unroll
+        for (int blk = 0; blk < DT; ++blk) v[blk] = blk < nb ? *reinterpret_cast<const f32x4 *>(row + 16 * blk + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) t[i] = i < rem ? row[16 * nb + 4 * i + g] : 0.0f;
+    }
+};
+
+// acc[ib][ia][r] = sum_d A[a_row0 + 16*ia + 4*g + r][d] * B_ib[j][d]:  NA A-tiles read from LDS (one ds_read_b128 per tile and
+// 4 k-steps), NB B-operands from registers.  NA*NB independent accumulators keep the MFMA pipe free of dependent chains.
+template <int DT, int NA, int NB>
+__device__ __forceinline__ void multi_dot(const float *As, int a_row0, int ld, int nb, int rem, int j, int g,
+                                          const OperandRegs<DT> (&b)[NB], f32x4 (&acc)[NB][NA]) {
+#pragma unroll
+    for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+        for (int ia = 0; ia < NA; ++ia) acc[ib][ia] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float *ap = As + (size_t)(a_row0 + j) * ld;
+#pragma unroll
+    for (int blk = 0; blk < DT; ++blk) {
+        if (blk < nb) {
+            f32x4 a[NA];
+#pragma unroll
+            for (int ia = 0; ia < NA; ++ia) a[ia] = *reinterpret_cast<const f32x4 *>(ap + (size_t)16 * ia * ld + 16 * blk + 4 * g);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int ia = 0; ia < NA; ++ia)
+#pragma unroll
+                    for (int ib = 0; ib < NB; ++ib) acc[ib][ia] = mfma4(a[ia][c], b[ib].v[blk][c], acc[ib][ia]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (i < rem) {
+            const int d = 16 * nb + 4 * i + g;
+#pragma unroll
+            for (int ia = 0; ia < NA; ++ia) {
+                const float av = ap[(size_t)16 * ia * ld + d];
+#pragma unroll
+                for (int ib = 0; ib < NB; ++ib) acc[ib][ia] = mfma4(av, b[ib].t[i], acc[ib][ia]);
+            }
+        }
+    }
 }
 
 __device__ __forceinline__ float xor_max(float v) {
@@ -118,18 +192,25 @@ mhsa_fwd_kernel(const float *__restrict__ Q, const float *__restrict__ K, const 
         for (int dt = 0; dt < DT; ++dt) acc[rt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int wrow = wave * 16 * RT;                       // first row of this wave inside the block
+    __syncthreads();
+    OperandRegs<DT> qr[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) qr[rt].load(Qs + (size_t)(wrow + 16 * rt + j) * ld, nb, rem, g);
 
+    RowStage<kKC, ld, NT> kst, vst;
+    kst.load(K + base, F, dh, 0, n, tid);
+    vst.load(V + base, F, dh, 0, n, tid);
     for (int kc = 0; kc < n; kc += kKC) {
+        __syncthreads();                                   // every wave is done with the previous chunk
+        kst.store(Ks, dh, kc, n, tid);
+        vst.store(Vs, dh, kc, n, tid);
         __syncthreads();
-        stage_rows(Ks, ld, K + base, F, dh, kc, kKC, n, tid, NT);
-        stage_rows(Vs, ld, V + base, F, dh, kc, kKC, n, tid, NT);
-        __syncthreads();
-        f32x4 p[RT][4];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) p[rt][kt] = dot_tiles(Ks, 16 * kt, Qs, wrow + 16 * rt, ld, nb, rem, j, g);
+        if (kc + kKC < n) {                                // prefetch the next chunk while this one is consumed
+            kst.load(K + base, F, dh, kc + kKC, n, tid);
+            vst.load(V + base, F, dh, kc + kKC, n, tid);
         }
+        f32x4 p[RT][4];
+        multi_dot<DT, 4, RT>(Ks, 0, ld, nb, rem, j, g, qr, p);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             float mx = -INFINITY;
@@ -247,17 +328,29 @@ mhsa_bwd_dq_kernel(const float *__restrict__ Q, const float *__restrict__ K, con
     f32x4 dq[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    OperandRegs<DT> qr[1], gr[1];
+    qr[0].load(Qs + (size_t)(wrow + j) * ld, nb, rem, g);
+    gr[0].load(Gs + (size_t)(wrow + j) * ld, nb, rem, g);
 
+    RowStage<kKC, ld, NT> kst, vst;
+    kst.load(K + base, F, dh, 0, n, tid);
+    vst.load(V + base, F, dh, 0, n, tid);
     for (int kc = 0; kc < n; kc += kKC) {
         __syncthreads();
-        stage_rows(Ks, ld, K + base, F, dh, kc, kKC, n, tid, NT);
-        stage_rows(Vs, ld, V + base, F, dh, kc, kKC, n, tid, NT);
+        kst.store(Ks, dh, kc, n, tid);
+        vst.store(Vs, dh, kc, n, tid);
         __syncthreads();
-        f32x4 ds[4];
+        if (kc + kKC < n) {
+            kst.load(K + base, F, dh, kc + kKC, n, tid);
+            vst.load(V + base, F, dh, kc + kKC, n, tid);
+        }
+        f32x4 ds[4], s4[1][4], dp4[1][4];
+        multi_dot<DT, 4, 1>(Ks, 0, ld, nb, rem, j, g, qr, s4);
+        multi_dot<DT, 4, 1>(Vs, 0, ld, nb, rem, j, g, gr, dp4);
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            const f32x4 s = dot_tiles(Ks, 16 * kt, Qs, wrow, ld, nb, rem, j, g);
-            const f32x4 dp = dot_tiles(Vs, 16 * kt, Gs, wrow, ld, nb, rem, j, g);
+            const f32x4 s = s4[0][kt], dp = dp4[0][kt];
             f32x4 keep = {keep_inv, keep_inv, keep_inv, keep_inv};
             if (thr != 0) {
                 uint32_t w0, w1;
@@ -325,21 +418,36 @@ mhsa_bwd_dkv_kernel(const float *__restrict__ Q, const float *__restrict__ K, co
     for (int dt = 0; dt < DT; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const bool live = key0 < n;                            // a block of padded keys only writes zeros
 
+    RowStage<kRC, ld, NT> qst, gst;
+    float lse_pf = 0.0f, d_pf = 0.0f;
+    auto prefetch = [&](int rc) {
+        qst.load(Q + base, F, dh, rc, L, tid);
+        gst.load(dO + base, F, dh, rc, L, tid);
+        if (tid < kRC) {
+            const int row = rc + tid, rcl = row < L ? row : L - 1;     // raw loads; rows >= L are masked where they are used
+            lse_pf = LSE[(size_t)bh * L + rcl];
+            d_pf = Dv[(size_t)bh * L + rcl];
+        }
+    };
+    if (live) prefetch(0);
+    __syncthreads();
+    OperandRegs<DT> kr[1], vr[1];                          // this wave's 16 keys as B operands, for the whole kernel
+    kr[0].load(Ks + (size_t)(wkey + j) * ld, nb, rem, g);
+    vr[0].load(Vs + (size_t)(wkey + j) * ld, nb, rem, g);
     for (int rc = 0; live && rc < L; rc += kRC) {
         __syncthreads();
-        stage_rows(Qs, ld, Q + base, F, dh, rc, kRC, L, tid, NT);
-        stage_rows(Gs, ld, dO + base, F, dh, rc, kRC, L, tid, NT);
-        if (tid < kRC) {
-            const int row = rc + tid;
-            lse_s[tid] = row < L ? LSE[(size_t)bh * L + row] : 0.0f;
-            D_s[tid] = row < L ? Dv[(size_t)bh * L + row] : 0.0f;
-        }
+        qst.store(Qs, dh, rc, L, tid);
+        gst.store(Gs, dh, rc, L, tid);
+        if (tid < kRC) { lse_s[tid] = lse_pf; D_s[tid] = d_pf; }
         __syncthreads();
+        if (rc + kRC < L) prefetch(rc + kRC);
+        // S[row][key], dP[row][key] for all row tiles of the chunk: lane (j, g), reg r = row 16*rt + 4*g + r, key j
+        f32x4 s4[1][kRC / 16], dp4[1][kRC / 16];
+        multi_dot<DT, kRC / 16, 1>(Qs, 0, ld, nb, rem, j, g, kr, s4);
+        multi_dot<DT, kRC / 16, 1>(Gs, 0, ld, nb, rem, j, g, vr, dp4);
 #pragma unroll
         for (int rt = 0; rt < kRC / 16; ++rt) {
-            // S[row][key]: lane (j, g), reg r = row 16*rt + 4*g + r, key j
-            const f32x4 s = dot_tiles(Qs, 16 * rt, Ks, wkey, ld, nb, rem, j, g);
-            const f32x4 dp = dot_tiles(Gs, 16 * rt, Vs, wkey, ld, nb, rem, j, g);
+            const f32x4 s = s4[0][rt], dp = dp4[0][rt];
             f32x4 pd, ds;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -389,70 +497,129 @@ __global__ void __launch_bounds__(256) attn_mask_kernel(AttnArgs a, float *__res
 }
 
 // ============================================================================================ LayerNorm (list_ranker.py:152-174)
-// y = a_2 * (x - mean) / (std + eps) + b_2, std UNBIASED (torch.Tensor.std default).  One 16-lane slot per row.
-// stats[row] = {mean, 1/(std + eps), std}.
+// y = a_2 * (x - mean) / (std + eps) + b_2, std UNBIASED (torch.Tensor.std default).  One wavefront per row, lanes along
+// the feature axis (coalesced 256-byte segments); HBM-bound streaming kernels.  stats[row] = {mean, 1/(std + eps), std}.
+// NI = ceil(F / 64) when the row fits in NI registers per lane (read once), 0 = generic re-reading loops.
+template <int NI>
 __global__ void __launch_bounds__(256)
 layernorm_fwd_kernel(const float *__restrict__ X, const float *__restrict__ a2, const float *__restrict__ b2, size_t R, int F,
                      float eps, float *__restrict__ Y, float *__restrict__ stats) {
-    const int lane = threadIdx.x & 15, slot = threadIdx.x >> 4;
-    for (size_t r = (size_t)blockIdx.x * 16 + slot; r < R; r += (size_t)gridDim.x * 16) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (size_t r = (size_t)blockIdx.x * 4 + wv; r < R; r += (size_t)gridDim.x * 4) {
         const float *x = X + r * F;
-        float s = 0.0f;
-        for (int d = lane; d < F; d += 16) s += x[d];
-        s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
-        const float mean = s / (float)F;
-        float v = 0.0f;
-        for (int d = lane; d < F; d += 16) { const float c = x[d] - mean; v += c * c; }
-        v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
-        const float sd = sqrtf(v / (float)(F - 1));
-        const float rinv = 1.0f / (sd + eps);
-        for (int d = lane; d < F; d += 16) Y[r * F + d] = a2[d] * (x[d] - mean) * rinv + b2[d];
-        if (lane == 0) { stats[3 * r] = mean; stats[3 * r + 1] = rinv; stats[3 * r + 2] = sd; }
+        if constexpr (NI > 0) {
+            float xv[NI];
+            float s = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int d = lane + 64 * i;
+                xv[i] = x[d < F ? d : F - 1] * (d < F ? 1.0f : 0.0f);
+                s += xv[i];
+            }
+            const float mean = wave_sum(s) / (float)F;
+            float v = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) { const float c = (lane + 64 * i < F) ? xv[i] - mean : 0.0f; v += c * c; }
+            const float sd = sqrtf(wave_sum(v) / (float)(F - 1));
+            const float rinv = 1.0f / (sd + eps);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int d = lane + 64 * i;
+                if (d < F) Y[r * F + d] = a2[d] * (xv[i] - mean) * rinv + b2[d];
+            }
+            if (lane == 0) { stats[3 * r] = mean; stats[3 * r + 1] = rinv; stats[3 * r + 2] = sd; }
+        } else {
+            float s = 0.0f;
+            for (int d = lane; d < F; d += 64) s += x[d];
+            const float mean = wave_sum(s) / (float)F;
+            float v = 0.0f;
+            for (int d = lane; d < F; d += 64) { const float c = x[d] - mean; v += c * c; }
+            const float sd = sqrtf(wave_sum(v) / (float)(F - 1));
+            const float rinv = 1.0f / (sd + eps);
+            for (int d = lane; d < F; d += 64) Y[r * F + d] = a2[d] * (x[d] - mean) * rinv + b2[d];
+            if (lane == 0) { stats[3 * r] = mean; stats[3 * r + 1] = rinv; stats[3 * r + 2] = sd; }
+        }
     }
 }
 
 // dX, and per-block partial sums of da_2 / db_2 in part[gridDim.x][2*F] (reduced by layernorm_reduce_kernel).
+template <int NI>
 __global__ void __launch_bounds__(256)
 layernorm_bwd_kernel(const float *__restrict__ X, const float *__restrict__ a2, const float *__restrict__ dY,
                      const float *__restrict__ stats, size_t R, int F, float *__restrict__ dX, float *__restrict__ part) {
-    extern __shared__ float red[];                         // [16][2*F]
-    const int lane = threadIdx.x & 15, slot = threadIdx.x >> 4;
-    float *mine = red + (size_t)slot * 2 * F;
-    for (int d = lane; d < 2 * F; d += 16) mine[d] = 0.0f;
-    for (size_t r = (size_t)blockIdx.x * 16 + slot; r < R; r += (size_t)gridDim.x * 16) {
+    extern __shared__ float red[];                         // [4 waves][2*F]: every lane only touches its own columns
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float *mine = red + (size_t)wv * 2 * F;
+    for (int d = lane; d < 2 * F; d += 64) mine[d] = 0.0f;
+    float pa[NI > 0 ? NI : 1], pb[NI > 0 ? NI : 1], av[NI > 0 ? NI : 1];
+    if constexpr (NI > 0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) { const int d = lane + 64 * i; pa[i] = 0.0f; pb[i] = 0.0f; av[i] = d < F ? a2[d] : 0.0f; }
+    }
+    for (size_t r = (size_t)blockIdx.x * 4 + wv; r < R; r += (size_t)gridDim.x * 4) {
         const float *x = X + r * F, *dy = dY + r * F;
         const float mean = stats[3 * r], rinv = stats[3 * r + 1], sd = stats[3 * r + 2];
         float sg = 0.0f, sgc = 0.0f;
-        for (int d = lane; d < F; d += 16) {
-            const float c = x[d] - mean, gy = dy[d], gg = gy * a2[d];
-            sg += gg; sgc += gg * c;
-            mine[d] += gy * c * rinv;                      // d a_2
-            mine[F + d] += gy;                             // d b_2
+        if constexpr (NI > 0) {
+            float cv[NI], gv[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int d = lane + 64 * i, dc = d < F ? d : F - 1;
+                const float ok = d < F ? 1.0f : 0.0f;
+                cv[i] = (x[dc] - mean) * ok;
+                gv[i] = dy[dc] * ok;
+                const float gg = gv[i] * av[i];
+                sg += gg; sgc += gg * cv[i];
+                pa[i] += gv[i] * cv[i] * rinv;
+                pb[i] += gv[i];
+            }
+            sg = wave_sum(sg); sgc = wave_sum(sgc);
+            const float gbar = sg / (float)F;
+            const float k2 = sd > 0.0f ? rinv * rinv * sgc / (sd * (float)(F - 1)) : 0.0f;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int d = lane + 64 * i;
+                if (d < F) dX[r * F + d] = rinv * (gv[i] * av[i] - gbar) - cv[i] * k2;
+            }
+        } else {
+            for (int d = lane; d < F; d += 64) {
+                const float c = x[d] - mean, gy = dy[d], gg = gy * a2[d];
+                sg += gg; sgc += gg * c;
+                mine[d] += gy * c * rinv;                      // d a_2
+                mine[F + d] += gy;                             // d b_2
+            }
+            sg = wave_sum(sg); sgc = wave_sum(sgc);
+            const float gbar = sg / (float)F;
+            // d(1/(std+eps))/dx_k = -rinv^2 * (x_k - mean) / (std * (F-1));  a constant row (std = 0) has no defined
+            // derivative (the reference's autograd returns NaN there): its second term is dropped
+            const float k2 = sd > 0.0f ? rinv * rinv * sgc / (sd * (float)(F - 1)) : 0.0f;
+            for (int d = lane; d < F; d += 64) dX[r * F + d] = rinv * (dy[d] * a2[d] - gbar) - (x[d] - mean) * k2;
         }
-        sg += __shfl_xor(sg, 8); sg += __shfl_xor(sg, 4); sg += __shfl_xor(sg, 2); sg += __shfl_xor(sg, 1);
-        sgc += __shfl_xor(sgc, 8); sgc += __shfl_xor(sgc, 4); sgc += __shfl_xor(sgc, 2); sgc += __shfl_xor(sgc, 1);
-        const float gbar = sg / (float)F;
-        // d(1/(std+eps))/dx_k = -rinv^2 * (x_k - mean) / (std * (F-1));  a constant row (std = 0) has no defined derivative
-        // (the reference's autograd returns NaN there): its second term is dropped
-        const float k2 = sd > 0.0f ? rinv * rinv * sgc / (sd * (float)(F - 1)) : 0.0f;
-        for (int d = lane; d < F; d += 16) dX[r * F + d] = rinv * (dy[d] * a2[d] - gbar) - (x[d] - mean) * k2;
+    }
+    if constexpr (NI > 0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) { const int d = lane + 64 * i; if (d < F) { mine[d] = pa[i]; mine[F + d] = pb[i]; } }
     }
     __syncthreads();
-    for (int d = threadIdx.x; d < 2 * F; d += 256) {
-        float s = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) s += red[(size_t)k * 2 * F + d];
-        part[(size_t)blockIdx.x * 2 * F + d] = s;
-    }
+    for (int d = threadIdx.x; d < 2 * F; d += 256)
+        part[(size_t)blockIdx.x * 2 * F + d] = (red[d] + red[(size_t)2 * F + d]) + (red[(size_t)4 * F + d] + red[(size_t)6 * F + d]);
 }
 
+// Fixed-order reduction of the per-block partials: 64 columns x 4 row slices per block.
 __global__ void __launch_bounds__(256)
 layernorm_reduce_kernel(const float *__restrict__ part, int nblk, int F, float *__restrict__ da2, float *__restrict__ db2) {
-    const int d = blockIdx.x * 256 + threadIdx.x;
-    if (d >= 2 * F) return;
+    __shared__ float sl[4][64];
+    const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int d = blockIdx.x * 64 + col;
     float s = 0.0f;
-    for (int k = 0; k < nblk; ++k) s += part[(size_t)k * 2 * F + d];
-    if (d < F) da2[d] = s; else db2[d - F] = s;
+    if (d < 2 * F)
+        for (int k = slice; k < nblk; k += 4) s += part[(size_t)k * 2 * F + d];
+    sl[slice][col] = s;
+    __syncthreads();
+    if (slice == 0 && d < 2 * F) {
+        const float t = (sl[0][col] + sl[1][col]) + (sl[2][col] + sl[3][col]);
+        if (d < F) da2[d] = t; else db2[d - F] = t;
+    }
 }
 
 constexpr int kLnBlocks = 1024;
@@ -574,8 +741,14 @@ extern "C" int ptr_layernorm_forward(const float *X, const float *a2, const floa
     if (R < 0 || F < 2) { set_error("%s: bad shape R=%lld F=%d", who, (long long)R, F); return PTR_ERR_INVALID_ARG; }
     if (R == 0) return 0;
     if (!X || !a2 || !b2 || !Y || !stats) { set_error("%s: NULL pointer", who); return PTR_ERR_INVALID_ARG; }
-    const int blocks = (int)((R + 15) / 16 < 8192 ? (R + 15) / 16 : 8192);
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), X, a2, b2, (size_t)R, F, eps, Y, stats);
+    const int blocks = (int)((R + 3) / 4 < 8192 ? (R + 3) / 4 : 8192);
+    const int ni = (F + 63) / 64;
+    auto launch = [&]<int NI>() {
+        hipLaunchKernelGGL(layernorm_fwd_kernel<NI>, dim3(blocks), dim3(256), 0, as_stream(stream), X, a2, b2, (size_t)R, F, eps, Y, stats);
+    };
+    if (ni == 1) launch.template operator()<1>(); else if (ni == 2) launch.template operator()<2>();
+    else if (ni == 3) launch.template operator()<3>(); else if (ni == 4) launch.template operator()<4>();
+    else launch.template operator()<0>();
     return check_hip(hipGetLastError(), who);
 }
 
@@ -587,15 +760,22 @@ extern "C" int ptr_layernorm_backward(const float *X, const float *a2, const flo
     const char *who = "ptr_layernorm_backward";
     if (R < 0 || F < 2) { set_error("%s: bad shape R=%lld F=%d", who, (long long)R, F); return PTR_ERR_INVALID_ARG; }
     if (!a2 || !da2 || !db2 || !ws || (R > 0 && (!X || !dY || !stats || !dX))) { set_error("%s: NULL pointer", who); return PTR_ERR_INVALID_ARG; }
-    const size_t lds = (size_t)16 * 2 * F * sizeof(float);
+    const size_t lds = (size_t)4 * 2 * F * sizeof(float);
     if (lds > 160 * 1024) { set_error("%s: F=%d too wide", who, F); return PTR_ERR_UNSUPPORTED; }
-    if (int e = allow_lds(layernorm_bwd_kernel, lds)) return e;
+    const int ni = (F + 63) / 64;
     hipStream_t st = as_stream(stream);
-    int blocks = (int)((R + 15) / 16 < kLnBlocks ? (R + 15) / 16 : kLnBlocks);
+    int blocks = (int)((R + 3) / 4 < kLnBlocks ? (R + 3) / 4 : kLnBlocks);
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), lds, st, X, a2, dY, stats, (size_t)R, F,
-                       dX, ws);
-    if (int rc = check_hip(hipGetLastError(), who)) return rc;
-    hipLaunchKernelGGL(layernorm_reduce_kernel, dim3((2 * F + 255) / 256), dim3(256), 0, st, ws, blocks, F, da2, db2);
+    auto launch = [&]<int NI>() -> int {
+        if (int e = allow_lds(layernorm_bwd_kernel<NI>, lds)) return e;
+        hipLaunchKernelGGL(layernorm_bwd_kernel<NI>, dim3(blocks), dim3(256), lds, st, X, a2, dY, stats, (size_t)R, F, dX, ws);
+        return check_hip(hipGetLastError(), who);
+    };
+    int rc0;
+    if (ni == 1) rc0 = launch.template operator()<1>(); else if (ni == 2) rc0 = launch.template operator()<2>();
+    else if (ni == 3) rc0 = launch.template operator()<3>(); else if (ni == 4) rc0 = launch.template operator()<4>();
+    else rc0 = launch.template operator()<0>();
+    if (rc0) return rc0;
+    hipLaunchKernelGGL(layernorm_reduce_kernel, dim3((2 * F + 63) / 64), dim3(256), 0, st, ws, blocks, F, da2, db2);
     return check_hip(hipGetLastError(), who);
 }

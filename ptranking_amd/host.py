@@ -228,6 +228,49 @@ class _BatchNormPerQuery(nn.Module):
         return Y * self.weight + self.bias if self.affine else Y
 
 
+class _SplitKLinearFn(torch.autograd.Function):
+    """y = x W^T + b with a weight gradient that fills the GPU.  dW = dY^T X is a [out, in] result contracted over ALL documents
+    of the batch (K = B*L ~ 10^5..10^6): the library GEMM picks one macro-tile per 32x32 outputs and no split-K, i.e. ~25
+    workgroups on 256 CUs for a 136x136 layer (measured 680 us where 30 us suffice).  Here the rows are cut into chunks of
+    `CHUNK` documents, one batched library GEMM produces [S, out, in] partial sums and a fixed-order sum reduces them —
+    deterministic, and every CU has work."""
+
+    CHUNK = 1024
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x2 = x.reshape(-1, x.shape[-1])
+        ctx.save_for_backward(x2, weight)
+        ctx.has_bias = bias is not None
+        y = torch.addmm(bias, x2, weight.t()) if bias is not None else x2 @ weight.t()
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        dx = (dy2 @ weight).view(*dy.shape[:-1], weight.shape[1]) if ctx.needs_input_grad[0] else None
+        R, ck = x2.shape[0], _SplitKLinearFn.CHUNK
+        S = R // ck
+        if S >= 8:
+            main = S * ck
+            part = torch.bmm(dy2[:main].view(S, ck, -1).transpose(1, 2), x2[:main].view(S, ck, -1))       # [S, out, in]
+            dw = part.sum(dim=0)
+            if main < R:
+                dw = dw + dy2[main:].t() @ x2[main:]
+        else:
+            dw = dy2.t() @ x2
+        db = dy2.sum(dim=0) if ctx.has_bias else None
+        return dx, dw, db
+
+
+class SplitKLinear(nn.Linear):
+    """nn.Linear (same parameters, initialisation and state_dict) whose backward computes dW with the split-K scheme above."""
+
+    def forward(self, x):
+        return _SplitKLinearFn.apply(x, self.weight, self.bias)
+
+
 def build_stacked_ffnet(ff_dims, AF=None, TL_AF=None, apply_tl_af=False, dropout=0.1, BN=True, bn_type=None, bn_affine=False,
                         device=None):
     """get_stacked_FFNet (ptranking/base/utils.py:288-356): (Dropout -> Linear[xavier_normal] -> [BN] -> AF) per hidden layer,
@@ -246,13 +289,13 @@ def build_stacked_ffnet(ff_dims, AF=None, TL_AF=None, apply_tl_af=False, dropout
     n = len(ff_dims)
     for i in range(1, n - 1):
         net.add_module(f'dr_{i}', nn.Dropout(dropout))
-        lin = nn.Linear(ff_dims[i - 1], ff_dims[i])
+        lin = SplitKLinear(ff_dims[i - 1], ff_dims[i])
         nn.init.xavier_normal_(lin.weight)
         net.add_module(f'ff_{i + 1}', lin)
         if BN:
             net.add_module(f'bn_{i + 1}', bn(ff_dims[i]))
         net.add_module(f'act_{i + 1}', get_AF(AF))
-    last = nn.Linear(ff_dims[-2], ff_dims[-1])
+    last = SplitKLinear(ff_dims[-2], ff_dims[-1])
     nn.init.xavier_normal_(last.weight)
     net.add_module(f'ff_{n}', last)
     if apply_tl_af:

@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .host import build_stacked_ffnet
+from .host import SplitKLinear, build_stacked_ffnet
 
 MAX_HEAD_DIM = 128        # PTR_MHSA_MAX_HEAD_DIM
 Encoder_Type = ['DASALC', 'AllRank', 'AttnDIN']   # list_ranker.py:13
@@ -145,10 +145,10 @@ class MultiheadAttention(nn.Module):
         if hid_dim // n_heads > MAX_HEAD_DIM:
             raise NotImplementedError(f"head dimension {hid_dim // n_heads} > {MAX_HEAD_DIM} is not covered by the fused kernels")
         self.hid_dim, self.n_heads = hid_dim, n_heads
-        self.w_q = nn.Linear(hid_dim, hid_dim)
-        self.w_k = nn.Linear(hid_dim, hid_dim)
-        self.w_v = nn.Linear(hid_dim, hid_dim)
-        self.fc = nn.Linear(hid_dim, hid_dim, bias=True)
+        self.w_q = SplitKLinear(hid_dim, hid_dim)
+        self.w_k = SplitKLinear(hid_dim, hid_dim)
+        self.w_v = SplitKLinear(hid_dim, hid_dim)
+        self.fc = SplitKLinear(hid_dim, hid_dim, bias=True)
         self.do_dropout = nn.Dropout(dropout)     # kept for its `p` and state_dict parity; the kernel applies the dropout
         self.site = 0                             # dropout stream id, set per encoder layer
 
@@ -164,8 +164,8 @@ class MultiheadAttention(nn.Module):
 class PositionwiseFeedForward(nn.Module):
     def __init__(self, num_features, hid_dim, dropout=0.1):
         super().__init__()
-        self.w1 = nn.Linear(num_features, hid_dim)
-        self.w2 = nn.Linear(hid_dim, num_features)
+        self.w1 = SplitKLinear(num_features, hid_dim)
+        self.w2 = SplitKLinear(hid_dim, num_features)
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, x):

@@ -76,3 +76,20 @@ def test_standalone_ranker_listsf_parameters_and_no_cpu_fallback():
     assert isinstance(r.optimizer, torch.optim.Adagrad)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         r.forward(torch.randn(2, 5, 24))
+
+
+@pytest.mark.parametrize("rows", [(3, 5), (9000,), (20, 500)])
+def test_splitk_linear_matches_nn_linear(rows):
+    """Same forward and gradients as nn.Linear (also through the chunked dW path: >= 8 chunks of 1024 rows + a tail)."""
+    from ptranking_amd.host import SplitKLinear
+    torch.manual_seed(1)
+    a = torch.nn.Linear(24, 17).double()
+    b = SplitKLinear(24, 17).double()
+    b.load_state_dict(a.state_dict())
+    x = torch.randn(*rows, 24, dtype=torch.float64)
+    R = torch.randn(*rows, 17, dtype=torch.float64)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    (a(xa) * R).sum().backward(); (b(xb) * R).sum().backward()
+    assert torch.allclose(a(xa), b(xb), atol=1e-12)
+    assert torch.allclose(xa.grad, xb.grad, atol=1e-12)
+    assert torch.allclose(a.weight.grad, b.weight.grad, atol=1e-10) and torch.allclose(a.bias.grad, b.bias.grad, atol=1e-10)
