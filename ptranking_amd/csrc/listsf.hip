@@ -17,6 +17,8 @@
 //   which IS the B-operand layout of   O^T[d][row] += V^T[d][key] * P^T[key][row]   (the k index may be visited in any
 //   order as long as A and B agree), so probabilities never leave registers.  Contractions over d read both operands from
 //   LDS as one ds_read_b128 per 4 k-steps (k-slot (c, g) <-> d = 16*blk + 4*g + c).
+#include <stdlib.h>
+
 #include "ptr_device.h"
 #include "ptr_dropout.h"
 
@@ -24,7 +26,6 @@ namespace ptr {
 
 constexpr int kAW = 8;                 // waves per workgroup
 constexpr int kAT = kAW * 64;          // threads per workgroup
-constexpr int kKC = 64;                // keys per LDS chunk (forward, dQ)
 constexpr int kRC = 32;                // rows per LDS chunk (dK / dV)
 
 struct AttnArgs {
@@ -114,6 +115,29 @@ struct OperandRegs {
 #pragma unroll
         for (int i = 0; i < 3; ++i) t[i] = i < rem ? row[16 * nb + 4 * i + g] : 0.0f;
     }
+    // Same operand straight from global memory (row = this lane's row of the head's column block; rows that do not exist
+    // are passed as a valid clamped pointer with ok = false).  Columns >= dh read as zero.
+    __device__ __forceinline__ void load_global(const float *row, bool ok, int dh, int nb, int rem, int g, bool vec) {
+        const float m = ok ? 1.0f : 0.0f;
+#pragma unroll
+        for (int blk = 0; blk < DT; ++blk) {
+            f32x4 x = {0.f, 0.f, 0.f, 0.f};
+            if (blk < nb) {
+                const int c = 16 * blk + 4 * g;
+                if (vec) x = *reinterpret_cast<const f32x4 *>(row + c);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = row[c + e < dh ? c + e : 0] * (c + e < dh ? 1.0f : 0.0f);
+                }
+            }
+            v[blk] = x * m;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int d = 16 * nb + 4 * i + g;
+            t[i] = i < rem ? row[d < dh ? d : 0] * ((d < dh) ? m : 0.0f) : 0.0f;
+        }
+    }
 };
 
 // acc[ib][ia][r] = sum_d A[a_row0 + 16*ia + 4*g + r][d] * B_ib[j][d]:  NA A-tiles read from LDS (one ds_read_b128 per tile and
@@ -165,12 +189,12 @@ __device__ __forceinline__ float xor_sum(float v) {
 
 // ============================================================================================ forward
 template <int DT, int RT, int NW>
-__global__ void __launch_bounds__(NW * 64)
+__global__ void __launch_bounds__(NW * 64, 2)
 mhsa_fwd_kernel(const float *__restrict__ Q, const float *__restrict__ K, const float *__restrict__ V,
                 const int32_t *__restrict__ lens, AttnArgs a, float *__restrict__ O, float *__restrict__ LSE) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int ld = attn_ld(DT), RPB = 16 * RT * NW, NT = NW * 64;
-    float *Qs = smem, *Ks = Qs + (size_t)RPB * ld, *Vs = Ks + (size_t)kKC * ld;
+    constexpr int ld = attn_ld(DT), RPB = 16 * RT * NW, NT = NW * 64, KC = 8 * NW, NKT = KC / 16;
+    float *Ks = smem, *Vs = Ks + (size_t)KC * ld;
     const int L = a.L, F = a.F, dh = a.dh;
     const int nrb = (L + RPB - 1) / RPB;
     const int rb = blockIdx.x % nrb, bh = blockIdx.x / nrb, b = bh / a.H, h = bh - b * a.H;
@@ -180,7 +204,7 @@ mhsa_fwd_kernel(const float *__restrict__ Q, const float *__restrict__ K, const 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
     const int row0 = rb * RPB;
     const int dh4 = (dh + 3) & ~3, nb = dh4 >> 4, rem = (dh4 & 15) >> 2;
-    stage_rows(Qs, ld, Q + base, F, dh, row0, RPB, L, tid, NT);
+    const bool vecq = ((dh & 3) == 0) && ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(Q + base) & 15) == 0);
 
     const uint32_t thr = drop_thr(a.p_drop);
     float m[RT], l[RT];
@@ -192,30 +216,32 @@ mhsa_fwd_kernel(const float *__restrict__ Q, const float *__restrict__ K, const 
         for (int dt = 0; dt < DT; ++dt) acc[rt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int wrow = wave * 16 * RT;                       // first row of this wave inside the block
-    __syncthreads();
     OperandRegs<DT> qr[RT];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) qr[rt].load(Qs + (size_t)(wrow + 16 * rt + j) * ld, nb, rem, g);
+    for (int rt = 0; rt < RT; ++rt) {
+        const int row = row0 + wrow + 16 * rt + j;
+        qr[rt].load_global(Q + base + (size_t)(row < L ? row : L - 1) * F, row < L, dh, nb, rem, g, vecq);
+    }
 
-    RowStage<kKC, ld, NT> kst, vst;
+    RowStage<KC, ld, NT> kst, vst;
     kst.load(K + base, F, dh, 0, n, tid);
     vst.load(V + base, F, dh, 0, n, tid);
-    for (int kc = 0; kc < n; kc += kKC) {
+    for (int kc = 0; kc < n; kc += KC) {
         __syncthreads();                                   // every wave is done with the previous chunk
         kst.store(Ks, dh, kc, n, tid);
         vst.store(Vs, dh, kc, n, tid);
         __syncthreads();
-        if (kc + kKC < n) {                                // prefetch the next chunk while this one is consumed
-            kst.load(K + base, F, dh, kc + kKC, n, tid);
-            vst.load(V + base, F, dh, kc + kKC, n, tid);
+        if (kc + KC < n) {                                // prefetch the next chunk while this one is consumed
+            kst.load(K + base, F, dh, kc + KC, n, tid);
+            vst.load(V + base, F, dh, kc + KC, n, tid);
         }
-        f32x4 p[RT][4];
-        multi_dot<DT, 4, RT>(Ks, 0, ld, nb, rem, j, g, qr, p);
+        f32x4 p[RT][NKT];
+        multi_dot<DT, NKT, RT>(Ks, 0, ld, nb, rem, j, g, qr, p);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             float mx = -INFINITY;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
+            for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kc + 16 * kt + 4 * g + r;
@@ -230,7 +256,7 @@ mhsa_fwd_kernel(const float *__restrict__ Q, const float *__restrict__ K, const 
             float rs = 0.0f;
             const int grow = bh * L + row0 + wrow + 16 * rt + j;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
+            for (int kt = 0; kt < NKT; ++kt) {
                 f32x4 e;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { e[r] = __expf(p[rt][kt][r] - m_new); rs += e[r]; }
@@ -249,7 +275,7 @@ mhsa_fwd_kernel(const float *__restrict__ Q, const float *__restrict__ K, const 
         }
         // O^T[d][row] += V^T[d][key] * P^T[key][row]                                          (list_ranker.py:236)
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
+        for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float *vrow = Vs + (size_t)(16 * kt + 4 * g + r) * ld + j;
@@ -301,13 +327,13 @@ attn_rowdot_kernel(const float *__restrict__ O, const float *__restrict__ dO, At
 
 // ============================================================================================ backward: dQ
 template <int DT, int NW>
-__global__ void __launch_bounds__(NW * 64)
+__global__ void __launch_bounds__(NW * 64, 2)
 mhsa_bwd_dq_kernel(const float *__restrict__ Q, const float *__restrict__ K, const float *__restrict__ V,
                    const float *__restrict__ dO, const float *__restrict__ LSE, const float *__restrict__ Dv,
                    const int32_t *__restrict__ lens, AttnArgs a, float *__restrict__ dQ) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int ld = attn_ld(DT), RPB = 16 * NW, NT = NW * 64;
-    float *Qs = smem, *Gs = Qs + (size_t)RPB * ld, *Ks = Gs + (size_t)RPB * ld, *Vs = Ks + (size_t)kKC * ld;
+    constexpr int ld = attn_ld(DT), RPB = 16 * NW, NT = NW * 64, KC = 8 * NW, NKT = KC / 16;
+    float *Ks = smem, *Vs = Ks + (size_t)KC * ld;
     const int L = a.L, F = a.F, dh = a.dh;
     const int nrb = (L + RPB - 1) / RPB;
     const int rb = blockIdx.x % nrb, bh = blockIdx.x / nrb, b = bh / a.H, h = bh - b * a.H;
@@ -317,8 +343,6 @@ mhsa_bwd_dq_kernel(const float *__restrict__ Q, const float *__restrict__ K, con
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
     const int row0 = rb * RPB, wrow = wave * 16;
     const int dh4 = (dh + 3) & ~3, nb = dh4 >> 4, rem = (dh4 & 15) >> 2;
-    stage_rows(Qs, ld, Q + base, F, dh, row0, RPB, L, tid, NT);
-    stage_rows(Gs, ld, dO + base, F, dh, row0, RPB, L, tid, NT);
     const int row = row0 + wrow + j;
     const bool rok = row < L;
     const float lse = rok ? LSE[(size_t)bh * L + row] : 0.0f;
@@ -328,28 +352,32 @@ mhsa_bwd_dq_kernel(const float *__restrict__ Q, const float *__restrict__ K, con
     f32x4 dq[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
     OperandRegs<DT> qr[1], gr[1];
-    qr[0].load(Qs + (size_t)(wrow + j) * ld, nb, rem, g);
-    gr[0].load(Gs + (size_t)(wrow + j) * ld, nb, rem, g);
+    {
+        const bool vq = ((dh & 3) == 0) && ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(Q + base) & 15) == 0) &&
+                        ((reinterpret_cast<uintptr_t>(dO + base) & 15) == 0);
+        const size_t ro = (size_t)(rok ? row : L - 1) * F;
+        qr[0].load_global(Q + base + ro, rok, dh, nb, rem, g, vq);
+        gr[0].load_global(dO + base + ro, rok, dh, nb, rem, g, vq);
+    }
 
-    RowStage<kKC, ld, NT> kst, vst;
+    RowStage<KC, ld, NT> kst, vst;
     kst.load(K + base, F, dh, 0, n, tid);
     vst.load(V + base, F, dh, 0, n, tid);
-    for (int kc = 0; kc < n; kc += kKC) {
+    for (int kc = 0; kc < n; kc += KC) {
         __syncthreads();
         kst.store(Ks, dh, kc, n, tid);
         vst.store(Vs, dh, kc, n, tid);
         __syncthreads();
-        if (kc + kKC < n) {
-            kst.load(K + base, F, dh, kc + kKC, n, tid);
-            vst.load(V + base, F, dh, kc + kKC, n, tid);
+        if (kc + KC < n) {
+            kst.load(K + base, F, dh, kc + KC, n, tid);
+            vst.load(V + base, F, dh, kc + KC, n, tid);
         }
-        f32x4 ds[4], s4[1][4], dp4[1][4];
-        multi_dot<DT, 4, 1>(Ks, 0, ld, nb, rem, j, g, qr, s4);
-        multi_dot<DT, 4, 1>(Vs, 0, ld, nb, rem, j, g, gr, dp4);
+        f32x4 ds[NKT], s4[1][NKT], dp4[1][NKT];
+        multi_dot<DT, NKT, 1>(Ks, 0, ld, nb, rem, j, g, qr, s4);
+        multi_dot<DT, NKT, 1>(Vs, 0, ld, nb, rem, j, g, gr, dp4);
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
+        for (int kt = 0; kt < NKT; ++kt) {
             const f32x4 s = s4[0][kt], dp = dp4[0][kt];
             f32x4 keep = {keep_inv, keep_inv, keep_inv, keep_inv};
             if (thr != 0) {
@@ -366,7 +394,7 @@ mhsa_bwd_dq_kernel(const float *__restrict__ Q, const float *__restrict__ K, con
         }
         // dQ^T[d][row] += K^T[d][key] * dS^T[key][row]
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
+        for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float *krow = Ks + (size_t)(16 * kt + 4 * g + r) * ld + j;
@@ -391,13 +419,13 @@ mhsa_bwd_dq_kernel(const float *__restrict__ Q, const float *__restrict__ K, con
 
 // ============================================================================================ backward: dK, dV
 template <int DT, int NW>
-__global__ void __launch_bounds__(NW * 64)
+__global__ void __launch_bounds__(NW * 64, 2)
 mhsa_bwd_dkv_kernel(const float *__restrict__ Q, const float *__restrict__ K, const float *__restrict__ V,
                     const float *__restrict__ dO, const float *__restrict__ LSE, const float *__restrict__ Dv,
                     const int32_t *__restrict__ lens, AttnArgs a, float *__restrict__ dK, float *__restrict__ dV) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int ld = attn_ld(DT), KPB = 16 * NW, NT = NW * 64;
-    float *Ks = smem, *Vs = Ks + (size_t)KPB * ld, *Qs = Vs + (size_t)KPB * ld, *Gs = Qs + (size_t)kRC * ld;
+    float *Qs = smem, *Gs = Qs + (size_t)kRC * ld;
     float *lse_s = Gs + (size_t)kRC * ld, *D_s = lse_s + kRC;
     const int L = a.L, F = a.F, dh = a.dh;
     const int nkb = (L + KPB - 1) / KPB;
@@ -409,8 +437,6 @@ mhsa_bwd_dkv_kernel(const float *__restrict__ Q, const float *__restrict__ K, co
     const int key0 = kb * KPB, wkey = wave * 16;
     const int key = key0 + wkey + j;
     const int dh4 = (dh + 3) & ~3, nb = dh4 >> 4, rem = (dh4 & 15) >> 2;
-    stage_rows(Ks, ld, K + base, F, dh, key0, KPB, n, tid, NT);
-    stage_rows(Vs, ld, V + base, F, dh, key0, KPB, n, tid, NT);
     const uint32_t thr = drop_thr(a.p_drop);
     const float keep_inv = thr != 0 ? 1.0f / (1.0f - a.p_drop) : 1.0f;
     f32x4 dk[DT], dv[DT];
@@ -430,10 +456,15 @@ mhsa_bwd_dkv_kernel(const float *__restrict__ Q, const float *__restrict__ K, co
         }
     };
     if (live) prefetch(0);
-    __syncthreads();
     OperandRegs<DT> kr[1], vr[1];                          // this wave's 16 keys as B operands, for the whole kernel
-    kr[0].load(Ks + (size_t)(wkey + j) * ld, nb, rem, g);
-    vr[0].load(Vs + (size_t)(wkey + j) * ld, nb, rem, g);
+    {
+        const bool vk = ((dh & 3) == 0) && ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(K + base) & 15) == 0) &&
+                        ((reinterpret_cast<uintptr_t>(V + base) & 15) == 0);
+        const bool kok = key < n;
+        const size_t ko = (size_t)(key < L ? key : L - 1) * F;
+        kr[0].load_global(K + base + ko, kok, dh, nb, rem, g, vk);
+        vr[0].load_global(V + base + ko, kok, dh, nb, rem, g, vk);
+    }
     for (int rc = 0; live && rc < L; rc += kRC) {
         __syncthreads();
         qst.store(Qs, dh, rc, L, tid);
@@ -649,7 +680,12 @@ static int attn_args(const char *who, int B, int L, int F, int H, float p_drop, 
 
 }  // namespace ptr
 
-constexpr size_t kAttnLdsCap = 160 * 1024;
+// Waves per workgroup: 4 (default) lets two independent workgroups share a CU, so one group's barrier / staging phases are
+// covered by the other's MFMA work; 8 halves the K/V re-staging traffic.  PTR_ATTN_WAVES=8 selects the latter.
+static int attn_waves() {
+    static int nw = [] { const char *e = getenv("PTR_ATTN_WAVES"); return (e && atoi(e) == 8) ? 8 : 4; }();
+    return nw;
+}
 
 extern "C" int ptr_mhsa_forward(const float *Q, const float *K, const float *V, const int32_t *lens, int B, int L, int F, int n_heads,
                                 float p_drop, uint64_t seed, int site, float *O, float *lse, void *stream) {
@@ -665,17 +701,17 @@ extern "C" int ptr_mhsa_forward(const float *Q, const float *K, const float *V, 
         auto launch = [&]<int RT, int NW>() -> int {
             constexpr int RPB = 16 * RT * NW;
             auto kern = mhsa_fwd_kernel<D, RT, NW>;
-            const size_t lds = ((size_t)RPB + 2 * kKC) * attn_ld(D) * sizeof(float);
+            const size_t lds = (size_t)2 * 8 * NW * attn_ld(D) * sizeof(float);
             if (int e = allow_lds(kern, lds)) return e;
             const int nrb = (L + RPB - 1) / RPB;
             hipLaunchKernelGGL(kern, dim3((unsigned)((size_t)B * n_heads * nrb)), dim3(NW * 64), lds, st, Q, K, V, lens, a, O, lse);
             return check_hip(hipGetLastError(), who);
         };
-        // two row tiles per wave when the rows exist and the Q tile fits next to the K / V chunks
-        constexpr size_t lds2 = ((size_t)32 * kAW + 2 * kKC) * attn_ld(D) * sizeof(float);
-        if constexpr (lds2 <= kAttnLdsCap) { if (L > 16 * kAW) return launch.template operator()<2, kAW>(); }
-        if (L > 64) return launch.template operator()<1, kAW>();
-        return launch.template operator()<1, 4>();
+        // two row tiles per wave (every K / V operand read feeds two MFMAs) when the rows exist and the registers allow it
+        if constexpr (D <= 5) {
+            if (L > 64) return attn_waves() == 8 && L > 128 ? launch.template operator()<2, 8>() : launch.template operator()<2, 4>();
+        }
+        return attn_waves() == 8 && L > 64 ? launch.template operator()<1, 8>() : launch.template operator()<1, 4>();
     });
 }
 
@@ -698,7 +734,7 @@ extern "C" int ptr_mhsa_backward(const float *Q, const float *K, const float *V,
         auto launch_dq = [&]<int NW>() -> int {
             constexpr int RPB = 16 * NW;
             auto kern = mhsa_bwd_dq_kernel<D, NW>;
-            const size_t lds = ((size_t)2 * RPB + 2 * kKC) * attn_ld(D) * sizeof(float);
+            const size_t lds = (size_t)2 * 8 * NW * attn_ld(D) * sizeof(float);
             if (int e = allow_lds(kern, lds)) return e;
             const int nrb = (L + RPB - 1) / RPB;
             hipLaunchKernelGGL(kern, dim3((unsigned)((size_t)B * n_heads * nrb)), dim3(NW * 64), lds, st, Q, K, V, dO, lse, dvec, lens, a, dQ);
@@ -707,19 +743,17 @@ extern "C" int ptr_mhsa_backward(const float *Q, const float *K, const float *V,
         auto launch_dkv = [&]<int NW>() -> int {
             constexpr int KPB = 16 * NW;
             auto kern = mhsa_bwd_dkv_kernel<D, NW>;
-            const size_t lds = (((size_t)2 * KPB + 2 * kRC) * attn_ld(D) + 2 * kRC) * sizeof(float);
+            const size_t lds = ((size_t)2 * kRC * attn_ld(D) + 2 * kRC) * sizeof(float);
             if (int e = allow_lds(kern, lds)) return e;
             const int nkb = (L + KPB - 1) / KPB;
             hipLaunchKernelGGL(kern, dim3((unsigned)((size_t)B * n_heads * nkb)), dim3(NW * 64), lds, st, Q, K, V, dO, lse, dvec, lens, a, dK, dV);
             return check_hip(hipGetLastError(), who);
         };
-        constexpr size_t lds_dq8 = ((size_t)2 * 16 * kAW + 2 * kKC) * attn_ld(D) * sizeof(float);
-        constexpr size_t lds_dkv8 = (((size_t)2 * 16 * kAW + 2 * kRC) * attn_ld(D) + 2 * kRC) * sizeof(float);
-        int rc;
-        if (lds_dq8 <= kAttnLdsCap && L > 64) rc = launch_dq.template operator()<kAW>(); else rc = launch_dq.template operator()<4>();
+        const bool w8 = attn_waves() == 8 && L > 64 && D <= 6;     // the 8-wave variants of the widest heads would spill
+        int rc = w8 ? launch_dq.template operator()<8>() : launch_dq.template operator()<4>();
         if (rc) return rc;
-        if (lds_dkv8 <= kAttnLdsCap && L > 64) rc = launch_dkv.template operator()<kAW>(); else rc = launch_dkv.template operator()<4>();
-        return rc;
+        const bool kv8 = L > 64 && (D >= 7 || attn_waves() == 8);   // 4-wave dK/dV variants of the widest heads spill more
+        return kv8 ? launch_dkv.template operator()<8>() : launch_dkv.template operator()<4>();
     });
 }
 

@@ -242,7 +242,10 @@ class _SplitKLinearFn(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1])
         ctx.save_for_backward(x2, weight)
         ctx.has_bias = bias is not None
-        y = torch.addmm(bias, x2, weight.t()) if bias is not None else x2 @ weight.t()
+        # x @ W^T on a transposed COPY of the small weight: for these tall-skinny shapes the library's kernel for a transposed
+        # B operand runs at less than half the speed of the plain one (311 vs 137 us at 262144 x 136 x 136, rocprofv3)
+        wt = weight.t().contiguous()
+        y = torch.addmm(bias, x2, wt) if bias is not None else x2 @ wt
         return y.view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
