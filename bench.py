@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--loss", default="LambdaRank", choices=["RankNet", "LambdaRank", "LambdaLoss", "ApproxNDCG", "ListNet", "ListMLE"],
                     help="ranker of the train step (the headline metric is LambdaRank; the others cover BASELINE.json configs 3-5)")
+    ap.add_argument("--scorer", default="pointsf", choices=["pointsf", "listsf"],
+                    help="listsf = BASELINE.json config 5: 2-head / 6-layer DASALC encoder (fused MFMA attention), use with --loss LambdaLoss "
+                         "--list-len 256 --batch 1024")
     args = ap.parse_args()
 
     import ptranking_amd as pa
@@ -108,10 +111,16 @@ def main():
 
     torch.manual_seed(SEED)                       # identical initial weights on every rank
     cls = getattr(pa, args.loss)
-    if args.loss == "ListNet":
-        ranker = cls(sf_para_dict=sf_para_dict(F), gpu=True, device=device)
+    if args.scorer == "listsf":      # ptranking/ltr_adhoc/eval/parameter.py:152-166 defaults
+        sfd = {"sf_id": "listsf", "opt": "Adagrad", "lr": 1e-3,
+               "listsf": dict(num_features=F, ff_dims=[128, 256, 512], AF="R", TL_AF="GE", apply_tl_af=False, BN=False, bn_type="BN2",
+                              bn_affine=False, n_heads=2, encoder_layers=6, encoder_type="DASALC")}
     else:
-        ranker = cls(sf_para_dict=sf_para_dict(F), model_para_dict=dict(pa.DEFAULT_PARAS[args.loss]), gpu=True, device=device)
+        sfd = sf_para_dict(F)
+    if args.loss == "ListNet":
+        ranker = cls(sf_para_dict=sfd, gpu=True, device=device)
+    else:
+        ranker = cls(sf_para_dict=sfd, model_para_dict=dict(pa.DEFAULT_PARAS[args.loss]), gpu=True, device=device)
     if args.loss == "ListMLE":
         ranker.tie_shuffle = "device"             # the reference's B host-side randperm calls per step would dominate
     ranker.init()
@@ -212,24 +221,40 @@ def main():
                         "traffic": pmc_bytes("ptr::mlp_fwd_kernel"), "avg_launch_ms": t_fwd, "algorithmic_flop_per_launch": fwd_flop,
                         "algorithmic_bytes_per_launch": R * (4 * F + 4) + NL * R * 448,
                         "note": "dominant kernel of the step by time; traffic = PMC FETCH_SIZE(x2 on gfx950)+WRITE_SIZE from profiles/r01_pmc_traffic.json"}
+        elif args.scorer == "listsf" and avg_ms("ptr_mhsa_forward"):
+            t_af, t_ab = avg_ms("ptr_mhsa_forward"), avg_ms("ptr_mhsa_backward")
+            att_flop = 4.0 * B * L * L * F                         # QK^T and PV, 2 flop per MAC, all heads (H * d_h = F)
+            tf = att_flop / (t_af * 1e-3) / 1e12
+            roofline = {"kernel": "mhsa_fwd_kernel (fused attention core: QK^T/sqrt(d) -> online softmax -> dropout -> PV, fp32 MFMA 16x16x4)",
+                        "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
+                        "traffic": None, "avg_launch_ms": t_af, "algorithmic_flop_per_launch": att_flop,
+                        "algorithmic_bytes_per_launch": 4 * B * L * F * 4 + B * 2 * L * 4,
+                        "note": "one launch per encoder layer; the linear / feed-forward GEMMs of listsf are library calls"}
+            kernels["attention_backward"] = {"kernels": "attn_rowdot + mhsa_bwd_dq + mhsa_bwd_dkv", "avg_call_ms": t_ab,
+                                             "achieved_TFLOPs": 2.5 * att_flop / (t_ab * 1e-3) / 1e12}
+            for nm in ("ptr_layernorm_forward", "ptr_layernorm_backward"):
+                if avg_ms(nm):
+                    kernels[nm] = {"avg_launch_ms": avg_ms(nm), "hbm_GBps": (2 if "forward" in nm else 3) * B * L * F * 4 / (avg_ms(nm) * 1e-3) / 1e9}
         else:   # scorer configuration not fusable: the north-star loss kernel is the only kernel of ours in the step
             roofline = dict(kernels.get("lambdarank_loss_grad", kernels.get("loss_grad", {})))
         qps = world * B * args.steps / elapsed
         out = {
-            "metric": ("queries/sec fwd+bwd LambdaRank, MSLR-WEB30K-shaped list_len=128" if (args.loss, L, F) == ("LambdaRank", 128, 136)
+            "metric": ("queries/sec fwd+bwd LambdaRank, MSLR-WEB30K-shaped list_len=128"
+                       if (args.loss, L, F, args.scorer) == ("LambdaRank", 128, 136, "pointsf")
                        else f"queries/sec fwd+bwd {args.loss}, synthetic list_len={L}, {F} feats"),
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.loss} train step (pointsf 3x100 ReLU scorer, dropout 0.1, Adam), "
-                                   f"MSLR-WEB30K-shaped synthetic, {F} feats, list_len={L}",
+            "config": {"workload": (f"{args.loss} train step (pointsf 3x100 ReLU scorer, dropout 0.1, Adam), " if args.scorer == "pointsf" else
+                                    f"{args.loss} train step (listsf: 2-head 6-layer DASALC encoder + 128/256/512 feed-forward stacks, "
+                                    f"dropout 0.1, Adagrad), ") + f"MSLR-WEB30K-shaped synthetic, {F} feats, list_len={L}",
                        "queries_per_gpu_per_step": B, "global_batch": world * B, "list_len": L, "features": F,
                        "parallelism": f"dp{world}", "resident_batches": len(batches)},
             "roofline": roofline,
             "kernels": kernels,
             "final_epoch_loss": final_loss,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.scorer == "pointsf":
             out["cpu_baseline"] = cpu_baseline(L, F, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -114,24 +114,27 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
             rok[rt] = row[rt] < R;
             xrow[rt] = X + (size_t)(rok[rt] ? row[rt] : R - 1) * F;
         }
-        auto load_x = [&](int S, f32x4 (&xb)[RT]) {
+        // load_raw only issues the loads; finish_x (zero padding + input dropout) runs AFTER the MFMAs of the super-step the
+        // loads are prefetched under — anything consuming the loaded value earlier would pull the s_waitcnt in front of them
+        auto load_raw = [&](int S, f32x4 (&xb)[RT]) {
             const int k0 = 16 * S + 4 * g;
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                f32x4 v;
                 if constexpr (VEC) {
-                    const bool kok = k0 < F;
-                    v = *reinterpret_cast<const f32x4 *>(xrow[rt] + (kok ? k0 : 0));
-                    const float okf = (kok && rok[rt]) ? 1.0f : 0.0f;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] *= okf;
+                    xb[rt] = *reinterpret_cast<const f32x4 *>(xrow[rt] + (k0 < F ? k0 : 0));
                 } else {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float okf = ((k0 + c < F) && rok[rt]) ? 1.0f : 0.0f;
-                        v[c] = xrow[rt][k0 + c < F ? k0 + c : 0] * okf;
-                    }
+                    for (int c = 0; c < 4; ++c) xb[rt][c] = xrow[rt][k0 + c < F ? k0 + c : 0];
                 }
+            }
+        };
+        auto finish_x = [&](int S, f32x4 (&xb)[RT]) {
+            const int k0 = 16 * S + 4 * g;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                f32x4 v = xb[rt];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] *= ((k0 + c < F) && rok[rt]) ? 1.0f : 0.0f;
                 if constexpr (TRAIN) {
                     uint32_t w0, w1;
                     drop_bits(a.seed_lo, a.seed_hi, 0, row[rt], k0 >> 2, w0, w1);
@@ -150,9 +153,10 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
             for (int rt = 0; rt < RT; ++rt) acc[mt][rt] = b4;
         }
         f32x4 xcur[RT], xnxt[RT];
-        load_x(0, xcur);
+        load_raw(0, xcur);
+        finish_x(0, xcur);
         for (int S = 0; S < nS1; ++S) {
-            if (S + 1 < nS1) load_x(S + 1, xnxt);
+            if (S + 1 < nS1) load_raw(S + 1, xnxt);
             const int k0 = 16 * S + 4 * g;
 #pragma unroll
             for (int mt = 0; mt < kMT; ++mt) {
@@ -172,6 +176,7 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
                     for (int rt = 0; rt < RT; ++rt)
                         acc[mt][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c], xcur[rt][c], acc[mt][rt], 0, 0, 0);
             }
+            if (S + 1 < nS1) finish_x(S + 1, xnxt);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) xcur[rt] = xnxt[rt];
         }

@@ -70,3 +70,53 @@ def test_two_ranks_on_one_gpu_match_the_full_batch(name, tmp_path):
     ref = r.point_sf.flat.grad.detach().cpu()
     scale = max(1.0, float(ref.abs().max()))
     assert float((r0["grads"] - ref).abs().max()) <= 2e-5 * scale
+
+
+# ------------------------------------------------------------------------------------------------ listsf under data parallelism
+LSF = {"sf_id": "listsf", "opt": "Adagrad", "lr": 1e-3,
+       "listsf": dict(num_features=24, ff_dims=[16, 32], AF="R", TL_AF="GE", apply_tl_af=False, BN=False, bn_type="BN2",
+                      bn_affine=False, n_heads=2, encoder_layers=2, dropout=0.0, encoder_type="DASALC")}
+
+
+def _make_list():
+    import ptranking_amd as pa
+    torch.manual_seed(33)
+    r = pa.LambdaLoss(sf_para_dict=copy.deepcopy(LSF), model_para_dict=dict(pa.DEFAULT_PARAS["LambdaLoss"]), gpu=True, device="cuda:0")
+    r.init()
+    r.eval_mode()      # the tail stack keeps its hard-wired Dropout(0.1) (list_ranker.py:340-341 passes no `dropout`): off for a
+    return r           # deterministic comparison; gradients flow in eval mode all the same
+
+
+def _flat_grads(r):
+    return torch.cat([p.grad.detach().reshape(-1).cpu() for p in r.get_parameters()])
+
+
+def _worker_list(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      PTR_DP_BACKEND="gloo")
+    import ptranking_amd as pa
+    from ptranking_amd import dp
+    dp.init_from_env()
+    X, Y = _data(B=8, L=48, F=24)
+    lo, hi = dp.shard_queries(X.size(0))
+    r = _make_list()
+    r.train_op(X[lo:hi].cuda(), Y[lo:hi].cuda(), epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
+    torch.save({"grads": _flat_grads(r), "params": torch.cat([p.detach().reshape(-1).cpu() for p in r.get_parameters()])},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_listsf_two_ranks_match_the_full_batch(tmp_path):
+    """The listwise scorer (fused attention / LayerNorm + library GEMMs) goes through the same single all-reduce."""
+    import ptranking_amd as pa
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker_list, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"rank{i}.pt") for i in range(2))
+    assert torch.equal(r0["params"], r1["params"]) and torch.equal(r0["grads"], r1["grads"])
+    X, Y = _data(B=8, L=48, F=24)
+    r = _make_list()
+    r.train_op(X.cuda(), Y.cuda(), epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
+    ref = _flat_grads(r)
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((r0["grads"] - ref).abs().max()) <= 2e-5 * scale
