@@ -163,11 +163,14 @@ int ptr_mlp_dropout_mask(int R, int n_feat, int site, float p_drop, uint64_t see
  * lens (nullable): keys >= lens[b] are excluded from the softmax (padded batches; the reference has no padding).
  * p_drop > 0: dropout on the attention probabilities from the counter generator (seed, site, b, h, row, key); p_drop = 0: eval.
  * ptr_mhsa_backward: dO [B][L][F] -> dQ, dK, dV [B][L][F] (every element written); dvec [B*H*L] is scratch; O, lse, p_drop,
- * seed, site must be the forward call's.  Head dimension F / n_heads <= PTR_MHSA_MAX_HEAD_DIM. */
+ * seed, site must be the forward call's.  Head dimension F / n_heads <= PTR_MHSA_MAX_HEAD_DIM.
+ * ld_qkv = row stride in floats of Q, K, V (and dQ, dK, dV): F for three separate tensors, 3F when they are the column blocks
+ * of ONE packed [B][L][3F] projection (pass base, base + F, base + 2F) — one GEMM then produces all three and dQ|dK|dV is
+ * directly the gradient of that projection.  O, dO are always [B][L][F]. */
 #define PTR_MHSA_MAX_HEAD_DIM 128
-int ptr_mhsa_forward(const float *Q, const float *K, const float *V, const int32_t *lens, int B, int L, int F, int n_heads,
-                     float p_drop, uint64_t seed, int site, float *O, float *lse, void *stream);
-int ptr_mhsa_backward(const float *Q, const float *K, const float *V, const float *O, const float *dO, const float *lse,
+int ptr_mhsa_forward(const float *Q, const float *K, const float *V, int ld_qkv, const int32_t *lens, int B, int L, int F,
+                     int n_heads, float p_drop, uint64_t seed, int site, float *O, float *lse, void *stream);
+int ptr_mhsa_backward(const float *Q, const float *K, const float *V, int ld_qkv, const float *O, const float *dO, const float *lse,
                       const int32_t *lens, int B, int L, int F, int n_heads, float p_drop, uint64_t seed, int site, float *dvec,
                       float *dQ, float *dK, float *dV, void *stream);
 /* Test helper: the attention dropout keep-mask (1.0 / 0.0), out [B][n_heads][L][L]. */

@@ -30,6 +30,7 @@ constexpr int kRC = 32;                // rows per LDS chunk (dK / dV)
 
 struct AttnArgs {
     int B, L, H, dh, F;
+    int ld;                            // row stride (floats) of Q / K / V and dQ / dK / dV: F, or 3F for a packed [B][L][3F] projection
     float inv_scale;                   // 1 / sqrt(dh)
     float p_drop;
     uint32_t seed_lo, seed_hi;
@@ -195,16 +196,16 @@ mhsa_fwd_kernel(const float *__restrict__ Q, const float *__restrict__ K, const 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int ld = attn_ld(DT), RPB = 16 * RT * NW, NT = NW * 64, KC = 8 * NW, NKT = KC / 16;
     float *Ks = smem, *Vs = Ks + (size_t)KC * ld;
-    const int L = a.L, F = a.F, dh = a.dh;
+    const int L = a.L, F = a.F, dh = a.dh, ldi = a.ld;
     const int nrb = (L + RPB - 1) / RPB;
     const int rb = blockIdx.x % nrb, bh = blockIdx.x / nrb, b = bh / a.H, h = bh - b * a.H;
     int n = lens ? lens[b] : L;
     n = n < 0 ? 0 : (n > L ? L : n);
-    const size_t base = (size_t)b * L * F + (size_t)h * dh;
+    const size_t base = (size_t)b * L * ldi + (size_t)h * dh, obase = (size_t)b * L * F + (size_t)h * dh;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
     const int row0 = rb * RPB;
     const int dh4 = (dh + 3) & ~3, nb = dh4 >> 4, rem = (dh4 & 15) >> 2;
-    const bool vecq = ((dh & 3) == 0) && ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(Q + base) & 15) == 0);
+    const bool vecq = ((dh & 3) == 0) && ((ldi & 3) == 0) && ((reinterpret_cast<uintptr_t>(Q + base) & 15) == 0);
 
     const uint32_t thr = drop_thr(a.p_drop);
     float m[RT], l[RT];
@@ -220,20 +221,20 @@ mhsa_fwd_kernel(const float *__restrict__ Q, const float *__restrict__ K, const 
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         const int row = row0 + wrow + 16 * rt + j;
-        qr[rt].load_global(Q + base + (size_t)(row < L ? row : L - 1) * F, row < L, dh, nb, rem, g, vecq);
+        qr[rt].load_global(Q + base + (size_t)(row < L ? row : L - 1) * ldi, row < L, dh, nb, rem, g, vecq);
     }
 
     RowStage<KC, ld, NT> kst, vst;
-    kst.load(K + base, F, dh, 0, n, tid);
-    vst.load(V + base, F, dh, 0, n, tid);
+    kst.load(K + base, ldi, dh, 0, n, tid);
+    vst.load(V + base, ldi, dh, 0, n, tid);
     for (int kc = 0; kc < n; kc += KC) {
         __syncthreads();                                   // every wave is done with the previous chunk
         kst.store(Ks, dh, kc, n, tid);
         vst.store(Vs, dh, kc, n, tid);
         __syncthreads();
         if (kc + KC < n) {                                // prefetch the next chunk while this one is consumed
-            kst.load(K + base, F, dh, kc + KC, n, tid);
-            vst.load(V + base, F, dh, kc + KC, n, tid);
+            kst.load(K + base, ldi, dh, kc + KC, n, tid);
+            vst.load(V + base, ldi, dh, kc + KC, n, tid);
         }
         f32x4 p[RT][NKT];
         multi_dot<DT, NKT, RT>(Ks, 0, ld, nb, rem, j, g, qr, p);
@@ -289,7 +290,7 @@ mhsa_fwd_kernel(const float *__restrict__ Q, const float *__restrict__ K, const 
         }
     }
     const float keep_inv = thr != 0 ? 1.0f / (1.0f - a.p_drop) : 1.0f;
-    const bool vec = ((dh & 3) == 0) && ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(O + base) & 15) == 0);
+    const bool vec = ((dh & 3) == 0) && ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(O + obase) & 15) == 0);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         const int row = row0 + wrow + 16 * rt + j;
@@ -299,7 +300,7 @@ mhsa_fwd_kernel(const float *__restrict__ Q, const float *__restrict__ K, const 
         for (int dt = 0; dt < DT; ++dt) {
             const int d = 16 * dt + 4 * g;
             const f32x4 o = acc[rt][dt] * inv;
-            float *dst = O + base + (size_t)row * F + d;
+            float *dst = O + obase + (size_t)row * F + d;
             if (vec) { if (d < dh) *reinterpret_cast<f32x4 *>(dst) = o; }
             else {
 #pragma unroll
@@ -334,12 +335,12 @@ mhsa_bwd_dq_kernel(const float *__restrict__ Q, const float *__restrict__ K, con
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int ld = attn_ld(DT), RPB = 16 * NW, NT = NW * 64, KC = 8 * NW, NKT = KC / 16;
     float *Ks = smem, *Vs = Ks + (size_t)KC * ld;
-    const int L = a.L, F = a.F, dh = a.dh;
+    const int L = a.L, F = a.F, dh = a.dh, ldi = a.ld;
     const int nrb = (L + RPB - 1) / RPB;
     const int rb = blockIdx.x % nrb, bh = blockIdx.x / nrb, b = bh / a.H, h = bh - b * a.H;
     int n = lens ? lens[b] : L;
     n = n < 0 ? 0 : (n > L ? L : n);
-    const size_t base = (size_t)b * L * F + (size_t)h * dh;
+    const size_t base = (size_t)b * L * ldi + (size_t)h * dh, obase = (size_t)b * L * F + (size_t)h * dh;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
     const int row0 = rb * RPB, wrow = wave * 16;
     const int dh4 = (dh + 3) & ~3, nb = dh4 >> 4, rem = (dh4 & 15) >> 2;
@@ -354,24 +355,24 @@ mhsa_bwd_dq_kernel(const float *__restrict__ Q, const float *__restrict__ K, con
     for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     OperandRegs<DT> qr[1], gr[1];
     {
-        const bool vq = ((dh & 3) == 0) && ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(Q + base) & 15) == 0) &&
-                        ((reinterpret_cast<uintptr_t>(dO + base) & 15) == 0);
-        const size_t ro = (size_t)(rok ? row : L - 1) * F;
-        qr[0].load_global(Q + base + ro, rok, dh, nb, rem, g, vq);
-        gr[0].load_global(dO + base + ro, rok, dh, nb, rem, g, vq);
+        const bool vq = ((dh & 3) == 0) && ((F & 3) == 0) && ((ldi & 3) == 0) && ((reinterpret_cast<uintptr_t>(Q + base) & 15) == 0) &&
+                        ((reinterpret_cast<uintptr_t>(dO + obase) & 15) == 0);
+        const size_t rr = (size_t)(rok ? row : L - 1);
+        qr[0].load_global(Q + base + rr * ldi, rok, dh, nb, rem, g, vq);
+        gr[0].load_global(dO + obase + rr * F, rok, dh, nb, rem, g, vq);
     }
 
     RowStage<KC, ld, NT> kst, vst;
-    kst.load(K + base, F, dh, 0, n, tid);
-    vst.load(V + base, F, dh, 0, n, tid);
+    kst.load(K + base, ldi, dh, 0, n, tid);
+    vst.load(V + base, ldi, dh, 0, n, tid);
     for (int kc = 0; kc < n; kc += KC) {
         __syncthreads();
         kst.store(Ks, dh, kc, n, tid);
         vst.store(Vs, dh, kc, n, tid);
         __syncthreads();
         if (kc + KC < n) {
-            kst.load(K + base, F, dh, kc + KC, n, tid);
-            vst.load(V + base, F, dh, kc + KC, n, tid);
+            kst.load(K + base, ldi, dh, kc + KC, n, tid);
+            vst.load(V + base, ldi, dh, kc + KC, n, tid);
         }
         f32x4 ds[NKT], s4[1][NKT], dp4[1][NKT];
         multi_dot<DT, NKT, 1>(Ks, 0, ld, nb, rem, j, g, qr, s4);
@@ -404,11 +405,11 @@ mhsa_bwd_dq_kernel(const float *__restrict__ Q, const float *__restrict__ K, con
         }
     }
     if (!rok) return;
-    const bool vec = ((dh & 3) == 0) && ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(dQ + base) & 15) == 0);
+    const bool vec = ((dh & 3) == 0) && ((ldi & 3) == 0) && ((reinterpret_cast<uintptr_t>(dQ + base) & 15) == 0);
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
         const int d = 16 * dt + 4 * g;
-        float *dst = dQ + base + (size_t)row * F + d;
+        float *dst = dQ + base + (size_t)row * ldi + d;
         if (vec) { if (d < dh) *reinterpret_cast<f32x4 *>(dst) = dq[dt]; }
         else {
 #pragma unroll
@@ -427,12 +428,12 @@ mhsa_bwd_dkv_kernel(const float *__restrict__ Q, const float *__restrict__ K, co
     constexpr int ld = attn_ld(DT), KPB = 16 * NW, NT = NW * 64;
     float *Qs = smem, *Gs = Qs + (size_t)kRC * ld;
     float *lse_s = Gs + (size_t)kRC * ld, *D_s = lse_s + kRC;
-    const int L = a.L, F = a.F, dh = a.dh;
+    const int L = a.L, F = a.F, dh = a.dh, ldi = a.ld;
     const int nkb = (L + KPB - 1) / KPB;
     const int kb = blockIdx.x % nkb, bh = blockIdx.x / nkb, b = bh / a.H, h = bh - b * a.H;
     int n = lens ? lens[b] : L;
     n = n < 0 ? 0 : (n > L ? L : n);
-    const size_t base = (size_t)b * L * F + (size_t)h * dh;
+    const size_t base = (size_t)b * L * ldi + (size_t)h * dh, obase = (size_t)b * L * F + (size_t)h * dh;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
     const int key0 = kb * KPB, wkey = wave * 16;
     const int key = key0 + wkey + j;
@@ -447,8 +448,8 @@ mhsa_bwd_dkv_kernel(const float *__restrict__ Q, const float *__restrict__ K, co
     RowStage<kRC, ld, NT> qst, gst;
     float lse_pf = 0.0f, d_pf = 0.0f;
     auto prefetch = [&](int rc) {
-        qst.load(Q + base, F, dh, rc, L, tid);
-        gst.load(dO + base, F, dh, rc, L, tid);
+        qst.load(Q + base, ldi, dh, rc, L, tid);
+        gst.load(dO + obase, F, dh, rc, L, tid);
         if (tid < kRC) {
             const int row = rc + tid, rcl = row < L ? row : L - 1;     // raw loads; rows >= L are masked where they are used
             lse_pf = LSE[(size_t)bh * L + rcl];
@@ -458,10 +459,10 @@ mhsa_bwd_dkv_kernel(const float *__restrict__ Q, const float *__restrict__ K, co
     if (live) prefetch(0);
     OperandRegs<DT> kr[1], vr[1];                          // this wave's 16 keys as B operands, for the whole kernel
     {
-        const bool vk = ((dh & 3) == 0) && ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(K + base) & 15) == 0) &&
+        const bool vk = ((dh & 3) == 0) && ((ldi & 3) == 0) && ((reinterpret_cast<uintptr_t>(K + base) & 15) == 0) &&
                         ((reinterpret_cast<uintptr_t>(V + base) & 15) == 0);
         const bool kok = key < n;
-        const size_t ko = (size_t)(key < L ? key : L - 1) * F;
+        const size_t ko = (size_t)(key < L ? key : L - 1) * ldi;
         kr[0].load_global(K + base + ko, kok, dh, nb, rem, g, vk);
         vr[0].load_global(V + base + ko, kok, dh, nb, rem, g, vk);
     }
@@ -502,12 +503,12 @@ mhsa_bwd_dkv_kernel(const float *__restrict__ Q, const float *__restrict__ K, co
         }
     }
     if (key >= L) return;
-    const bool vec = ((dh & 3) == 0) && ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(dK + base) & 15) == 0) &&
+    const bool vec = ((dh & 3) == 0) && ((ldi & 3) == 0) && ((reinterpret_cast<uintptr_t>(dK + base) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(dV + base) & 15) == 0);
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
         const int d = 16 * dt + 4 * g;
-        float *pk = dK + base + (size_t)key * F + d, *pv = dV + base + (size_t)key * F + d;
+        float *pk = dK + base + (size_t)key * ldi + d, *pv = dV + base + (size_t)key * ldi + d;
         if (vec) { if (d < dh) { *reinterpret_cast<f32x4 *>(pk) = dk[dt]; *reinterpret_cast<f32x4 *>(pv) = dv[dt]; } }
         else {
 #pragma unroll
@@ -668,13 +669,14 @@ template <class Fn> inline int dispatch_dt(int DT, Fn &&f) {
     }
 }
 
-static int attn_args(const char *who, int B, int L, int F, int H, float p_drop, uint64_t seed, int site, AttnArgs &a) {
+static int attn_args(const char *who, int B, int L, int F, int H, int ld, float p_drop, uint64_t seed, int site, AttnArgs &a) {
+    if (ld < F) { set_error("%s: row stride %d < F = %d", who, ld, F); return PTR_ERR_INVALID_ARG; }
     if (B < 0 || L <= 0 || F <= 0 || H <= 0 || F % H != 0) { set_error("%s: bad shape B=%d L=%d F=%d heads=%d", who, B, L, F, H); return PTR_ERR_INVALID_ARG; }
     if (!(p_drop >= 0.0f && p_drop < 1.0f)) { set_error("%s: p_drop must be in [0,1)", who); return PTR_ERR_INVALID_ARG; }
     const int dh = F / H;
     if (dh > PTR_MHSA_MAX_HEAD_DIM) { set_error("%s: head dimension %d exceeds PTR_MHSA_MAX_HEAD_DIM=%d", who, dh, PTR_MHSA_MAX_HEAD_DIM); return PTR_ERR_UNSUPPORTED; }
     if ((size_t)B * H * L >= (1u << 31)) { set_error("%s: B*H*L too large", who); return PTR_ERR_UNSUPPORTED; }
-    a = AttnArgs{B, L, H, dh, F, 1.0f / sqrtf((float)dh), p_drop, (uint32_t)seed, (uint32_t)(seed >> 32), site};
+    a = AttnArgs{B, L, H, dh, F, ld, 1.0f / sqrtf((float)dh), p_drop, (uint32_t)seed, (uint32_t)(seed >> 32), site};
     return 0;
 }
 
@@ -687,12 +689,12 @@ static int attn_waves() {
     return nw;
 }
 
-extern "C" int ptr_mhsa_forward(const float *Q, const float *K, const float *V, const int32_t *lens, int B, int L, int F, int n_heads,
-                                float p_drop, uint64_t seed, int site, float *O, float *lse, void *stream) {
+extern "C" int ptr_mhsa_forward(const float *Q, const float *K, const float *V, int ld_qkv, const int32_t *lens, int B, int L, int F,
+                                int n_heads, float p_drop, uint64_t seed, int site, float *O, float *lse, void *stream) {
     using namespace ptr;
     const char *who = "ptr_mhsa_forward";
     AttnArgs a;
-    if (int rc = attn_args(who, B, L, F, n_heads, p_drop, seed, site, a)) return rc;
+    if (int rc = attn_args(who, B, L, F, n_heads, ld_qkv, p_drop, seed, site, a)) return rc;
     if (B == 0) return 0;
     if (!Q || !K || !V || !O || !lse) { set_error("%s: NULL pointer", who); return PTR_ERR_INVALID_ARG; }
     hipStream_t st = as_stream(stream);
@@ -715,13 +717,13 @@ extern "C" int ptr_mhsa_forward(const float *Q, const float *K, const float *V, 
     });
 }
 
-extern "C" int ptr_mhsa_backward(const float *Q, const float *K, const float *V, const float *O, const float *dO, const float *lse,
-                                 const int32_t *lens, int B, int L, int F, int n_heads, float p_drop, uint64_t seed, int site,
-                                 float *dvec, float *dQ, float *dK, float *dV, void *stream) {
+extern "C" int ptr_mhsa_backward(const float *Q, const float *K, const float *V, int ld_qkv, const float *O, const float *dO,
+                                 const float *lse, const int32_t *lens, int B, int L, int F, int n_heads, float p_drop, uint64_t seed,
+                                 int site, float *dvec, float *dQ, float *dK, float *dV, void *stream) {
     using namespace ptr;
     const char *who = "ptr_mhsa_backward";
     AttnArgs a;
-    if (int rc = attn_args(who, B, L, F, n_heads, p_drop, seed, site, a)) return rc;
+    if (int rc = attn_args(who, B, L, F, n_heads, ld_qkv, p_drop, seed, site, a)) return rc;
     if (B == 0) return 0;
     if (!Q || !K || !V || !O || !dO || !lse || !dvec || !dQ || !dK || !dV) { set_error("%s: NULL pointer", who); return PTR_ERR_INVALID_ARG; }
     hipStream_t st = as_stream(stream);
@@ -761,7 +763,7 @@ extern "C" int ptr_mhsa_dropout_mask(int B, int L, int n_heads, float p_drop, ui
     using namespace ptr;
     const char *who = "ptr_mhsa_dropout_mask";
     AttnArgs a;
-    if (int rc = attn_args(who, B, L, n_heads, n_heads, p_drop, seed, site, a)) return rc;
+    if (int rc = attn_args(who, B, L, n_heads, n_heads, n_heads, p_drop, seed, site, a)) return rc;
     if (B == 0) return 0;
     if (!out) { set_error("%s: NULL pointer", who); return PTR_ERR_INVALID_ARG; }
     hipLaunchKernelGGL(attn_mask_kernel, dim3(2048), dim3(256), 0, as_stream(stream), a, out);

@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .host import SplitKLinear, build_stacked_ffnet
+from .host import SplitKLinear, _SplitKLinearFn, build_stacked_ffnet
 
 MAX_HEAD_DIM = 128        # PTR_MHSA_MAX_HEAD_DIM
 Encoder_Type = ['DASALC', 'AllRank', 'AttnDIN']   # list_ranker.py:13
@@ -33,7 +33,13 @@ def _need_gpu(t, who):
         raise _lib.NativeLibraryError(f"{who}: tensor on {t.device}; ptranking_amd has no CPU fallback — move it to the GPU")
 
 
+def _voff(t, floats):
+    return C.c_void_p(t.data_ptr() + 4 * floats)
+
+
 class _MhsaCoreFn(torch.autograd.Function):
+    """Three separate [B, L, F] tensors (row stride F)."""
+
     @staticmethod
     def forward(ctx, Q, K, V, lens, n_heads, p, seed, site):
         B, L, Fdim = Q.shape
@@ -42,7 +48,7 @@ class _MhsaCoreFn(torch.autograd.Function):
         O = torch.empty_like(Q)
         lse = torch.empty(B * n_heads * L, device=dev, dtype=torch.float32)
         with torch.cuda.device(dev):
-            _lib.call("ptr_mhsa_forward", _lib.ptr(Q), _lib.ptr(K), _lib.ptr(V), _lib.ptr(lens), B, L, Fdim, n_heads, C.c_float(p),
+            _lib.call("ptr_mhsa_forward", _lib.ptr(Q), _lib.ptr(K), _lib.ptr(V), Fdim, _lib.ptr(lens), B, L, Fdim, n_heads, C.c_float(p),
                       C.c_uint64(seed), site, _lib.ptr(O), _lib.ptr(lse), _lib.current_stream(dev))
         ctx.save_for_backward(Q, K, V, O, lse, lens)
         ctx.meta = (n_heads, p, seed, site)
@@ -58,10 +64,46 @@ class _MhsaCoreFn(torch.autograd.Function):
         dQ, dK, dV = torch.empty_like(Q), torch.empty_like(Q), torch.empty_like(Q)
         dvec = torch.empty_like(lse)
         with torch.cuda.device(dev):
-            _lib.call("ptr_mhsa_backward", _lib.ptr(Q), _lib.ptr(K), _lib.ptr(V), _lib.ptr(O), _lib.ptr(dO), _lib.ptr(lse),
+            _lib.call("ptr_mhsa_backward", _lib.ptr(Q), _lib.ptr(K), _lib.ptr(V), Fdim, _lib.ptr(O), _lib.ptr(dO), _lib.ptr(lse),
                       _lib.ptr(lens), B, L, Fdim, n_heads, C.c_float(p), C.c_uint64(seed), site, _lib.ptr(dvec), _lib.ptr(dQ),
                       _lib.ptr(dK), _lib.ptr(dV), _lib.current_stream(dev))
         return dQ, dK, dV, None, None, None, None, None
+
+
+class _MhsaPackedFn(torch.autograd.Function):
+    """One packed [B, L, 3F] projection Q | K | V (row stride 3F): the kernels read the three column blocks in place and write
+    dQ | dK | dV straight into the gradient of the projection."""
+
+    @staticmethod
+    def forward(ctx, qkv, lens, n_heads, p, seed, site):
+        B, L, F3 = qkv.shape
+        Fdim = F3 // 3
+        dev = qkv.device
+        qkv = qkv.contiguous()
+        O = torch.empty((B, L, Fdim), device=dev, dtype=torch.float32)
+        lse = torch.empty(B * n_heads * L, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.call("ptr_mhsa_forward", _voff(qkv, 0), _voff(qkv, Fdim), _voff(qkv, 2 * Fdim), F3, _lib.ptr(lens), B, L, Fdim, n_heads,
+                      C.c_float(p), C.c_uint64(seed), site, _lib.ptr(O), _lib.ptr(lse), _lib.current_stream(dev))
+        ctx.save_for_backward(qkv, O, lse, lens)
+        ctx.meta = (n_heads, p, seed, site)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        qkv, O, lse, lens = ctx.saved_tensors
+        n_heads, p, seed, site = ctx.meta
+        B, L, F3 = qkv.shape
+        Fdim = F3 // 3
+        dev = qkv.device
+        dO = dO.contiguous()
+        dqkv = torch.empty_like(qkv)
+        dvec = torch.empty_like(lse)
+        with torch.cuda.device(dev):
+            _lib.call("ptr_mhsa_backward", _voff(qkv, 0), _voff(qkv, Fdim), _voff(qkv, 2 * Fdim), F3, _lib.ptr(O), _lib.ptr(dO),
+                      _lib.ptr(lse), _lib.ptr(lens), B, L, Fdim, n_heads, C.c_float(p), C.c_uint64(seed), site, _lib.ptr(dvec),
+                      _voff(dqkv, 0), _voff(dqkv, Fdim), _voff(dqkv, 2 * Fdim), _lib.current_stream(dev))
+        return dqkv, None, None, None, None, None
 
 
 def mhsa_core(Q, K, V, n_heads, p_drop=0.0, seed=0, site=0, lens=None):
@@ -73,6 +115,16 @@ def mhsa_core(Q, K, V, n_heads, p_drop=0.0, seed=0, site=0, lens=None):
     if lens is not None:
         lens = lens.to(device=Q.device, dtype=torch.int32).contiguous()
     return _MhsaCoreFn.apply(Q, K, V, lens, int(n_heads), float(p_drop), int(seed), int(site))
+
+
+def mhsa_core_packed(qkv, n_heads, p_drop=0.0, seed=0, site=0, lens=None):
+    """Same, on the packed projection qkv = [Q | K | V] of shape [B, L, 3F]; returns O [B, L, F]."""
+    _need_gpu(qkv, "mhsa_core_packed")
+    if qkv.dtype != torch.float32 or qkv.dim() != 3 or qkv.shape[-1] % 3 != 0:
+        raise ValueError("mhsa_core_packed expects an fp32 [B, L, 3F] tensor")
+    if lens is not None:
+        lens = lens.to(device=qkv.device, dtype=torch.int32).contiguous()
+    return _MhsaPackedFn.apply(qkv, lens, int(n_heads), float(p_drop), int(seed), int(site))
 
 
 def mhsa_dropout_mask(B, L, n_heads, p_drop, seed, site, device):
@@ -153,10 +205,14 @@ class MultiheadAttention(nn.Module):
         self.site = 0                             # dropout stream id, set per encoder layer
 
     def forward(self, batch_rankings, lens=None):
-        Q, K, V = self.w_q(batch_rankings), self.w_k(batch_rankings), self.w_v(batch_rankings)
+        # the three projections (list_ranker.py:209-211) as ONE GEMM on the concatenated weights: a [B, L, 3F] tensor whose
+        # column blocks the attention kernels read in place (the concatenation of three F x F matrices is negligible)
+        w = torch.cat([self.w_q.weight, self.w_k.weight, self.w_v.weight], dim=0)
+        b = torch.cat([self.w_q.bias, self.w_k.bias, self.w_v.bias], dim=0)
+        qkv = _SplitKLinearFn.apply(batch_rankings, w, b)
         p = self.do_dropout.p if self.training else 0.0
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0      # CPU generator: no device sync
-        x = mhsa_core(Q, K, V, self.n_heads, p_drop=p, seed=seed, site=self.site, lens=lens)
+        x = mhsa_core_packed(qkv, self.n_heads, p_drop=p, seed=seed, site=self.site, lens=lens)
         self.last_seed = seed
         return self.fc(x)
 

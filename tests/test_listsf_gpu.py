@@ -158,3 +158,20 @@ def test_c5_ranker_trains(LS):
     r.eval_mode()
     ndcg = r.ndcg_at_ks(test_data=[(list(range(8)), X, Y)], ks=[1, 5, 10], label_type=pa.LABEL_TYPE.MultiLabel, presort=True)
     assert ndcg.shape == (3,) and torch.isfinite(ndcg).all()
+
+
+@pytest.mark.parametrize("B,L,Fd,H", [(3, 256, 136, 2), (2, 100, 68, 4), (2, 70, 24, 2)])
+def test_packed_projection_equals_separate_tensors(LS, B, L, Fd, H):
+    """The packed [B, L, 3F] entry (row stride 3F) must give the same bits as three contiguous tensors."""
+    torch.manual_seed(L)
+    qkv = torch.randn(B, L, 3 * Fd, device=DEV)
+    g = torch.randn(B, L, Fd, device=DEV)
+    lens = torch.randint(1, L + 1, (B,), device=DEV, dtype=torch.int32)
+    qp = qkv.clone().requires_grad_(True)
+    o1 = LS.mhsa_core_packed(qp, H, p_drop=0.1, seed=5, site=1, lens=lens)
+    o1.backward(g)
+    q, k, v = (qkv[..., i * Fd:(i + 1) * Fd].contiguous().requires_grad_(True) for i in range(3))
+    o2 = LS.mhsa_core(q, k, v, H, p_drop=0.1, seed=5, site=1, lens=lens)
+    o2.backward(g)
+    assert torch.equal(o1, o2)
+    assert torch.equal(qp.grad, torch.cat([q.grad, k.grad, v.grad], dim=-1))
