@@ -8,15 +8,17 @@
 //
 // The reference materialises scores, softmax, dropout mask and dropped softmax as four [B, H, L, L] fp32 tensors per layer
 // (0.54 GB each at B = 1024, L = 256) and keeps them for backward.  Here nothing of size L^2 touches HBM:
-//   forward   one workgroup (8 waves) per (query, head, block of 128*RT rows): K/V stream through LDS in chunks of 64 keys,
-//             online softmax, dropout bits from a counter hash, O and the per-row log-sum-exp are the only outputs;
+//   forward   one workgroup (4 or 8 waves) per (query, head, block of 16*RT rows per wave): K/V stream through LDS in chunks of
+//             8 keys per wave, software-pipelined (the next chunk's loads fly during the MFMAs); online softmax, dropout bits
+//             from a counter hash; O and the per-row log-sum-exp are the only outputs;
 //   backward  recomputes P = exp(S - lse) tile by tile: one kernel per row block for dQ, one per key block for dK / dV
 //             (two kernels instead of atomics on dQ: every output element has one owner, so results are bit-stable).
 // MFMA formulation (v_mfma_f32_16x16x4_f32, exact fp32), "transposed world" as in scorer.hip:
 //   S^T[key][row] = K[key][:] . Q[row][:]      -> lane (j = l&15, g = l>>4) holds row j, keys 16*kt + 4*g + {0..3}
 //   which IS the B-operand layout of   O^T[d][row] += V^T[d][key] * P^T[key][row]   (the k index may be visited in any
-//   order as long as A and B agree), so probabilities never leave registers.  Contractions over d read both operands from
-//   LDS as one ds_read_b128 per 4 k-steps (k-slot (c, g) <-> d = 16*blk + 4*g + c).
+//   order as long as A and B agree), so probabilities never leave registers.  Contractions over d keep the wave's own operand
+//   (its Q rows; its K / V rows in the dK/dV kernel) in registers for the whole kernel and read the streamed operand from
+//   LDS as one ds_read_b128 per 4 k-steps (k-slot (c, g) <-> d = 16*blk + 4*g + c), shared by all row tiles.
 #include <stdlib.h>
 
 #include "ptr_device.h"
@@ -24,8 +26,6 @@
 
 namespace ptr {
 
-constexpr int kAW = 8;                 // waves per workgroup
-constexpr int kAT = kAW * 64;          // threads per workgroup
 constexpr int kRC = 32;                // rows per LDS chunk (dK / dV)
 
 struct AttnArgs {
@@ -42,28 +42,8 @@ __host__ __device__ constexpr int attn_ld(int DT) { return ((16 * DT / 4) & 1) ?
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-// rows [row0, row0 + nrows) of the head's column block -> dst[nrows][ld]; rows >= row_lim and columns >= dh are zero
-__device__ __forceinline__ void stage_rows(float *dst, int ld, const float *src, int F, int dh, int row0, int nrows, int row_lim,
-                                           int tid, int nthr) {
-    const bool vec = ((dh & 3) == 0) && ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
-    const int ld4 = ld >> 2;
-    for (int idx = tid; idx < nrows * ld4; idx += nthr) {
-        const int r = idx / ld4, c = (idx - r * ld4) << 2;
-        const int row = row0 + r;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row < row_lim) {
-            const float *p = src + (size_t)row * F + c;
-            if (vec) { if (c < dh) v = *reinterpret_cast<const f32x4 *>(p); }
-            else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) if (c + e < dh) v[e] = p[e];
-            }
-        }
-        *reinterpret_cast<f32x4 *>(dst + (size_t)r * ld + c) = v;
-    }
-}
-
-// Software-pipelined variant of stage_rows: load() issues the global loads of the NEXT chunk into registers before the
+// Software-pipelined staging of rows [row0, row0 + NROWS) of a head's column block into an LDS tile dst[NROWS][LD] (rows >=
+// row_lim and columns >= dh zero): load() issues the global loads of the NEXT chunk into registers before the
 // current chunk is consumed, store() commits them to LDS afterwards, so the HBM/L2 latency hides behind the MFMA work.
 template <int NROWS, int LD, int NT>
 struct RowStage {

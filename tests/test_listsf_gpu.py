@@ -175,3 +175,38 @@ def test_packed_projection_equals_separate_tensors(LS, B, L, Fd, H):
     o2.backward(g)
     assert torch.equal(o1, o2)
     assert torch.equal(qp.grad, torch.cat([q.grad, k.grad, v.grad], dim=-1))
+
+
+@pytest.mark.parametrize("enc", ["DASALC", "AllRank", "AttnDIN"])
+def test_permutation_equivariance_at_baseline_size(LS, enc):
+    """Size-independent property at BASELINE config 5's shape (L = 256, 136 features, 2 heads, 6 layers): permuting the
+    documents of a query permutes the scores (what "permutation-equivariant scoring function" means, list_ranker.py:284-287);
+    and a query's scores do not depend on which other queries share the batch."""
+    torch.manual_seed(11)
+    mods = LS.build_listsf(num_features=136, ff_dims=[128, 256, 512], AF='R', TL_AF='GE', apply_tl_af=False, BN=False, bn_type='BN2',
+                           bn_affine=False, n_heads=2, encoder_layers=6, encoder_type=enc)
+    for m in mods.values():
+        m.to(DEV).eval()
+    X = torch.randn(6, 256, 136, device=DEV)
+    perm = torch.stack([torch.randperm(256, device=DEV) for _ in range(6)])
+    with torch.no_grad():
+        p = LS.listsf_forward(mods, enc, X)
+        pp = LS.listsf_forward(mods, enc, torch.gather(X, 1, perm[:, :, None].expand(-1, -1, 136)))
+        ps = LS.listsf_forward(mods, enc, X[2:4])
+    ref = torch.gather(p, 1, perm)
+    tol = 1e-4 * float(p.abs().max()) + 1e-5          # fp32 sums over 256 keys in a different order, 6 layers deep
+    assert float((pp - ref).abs().max()) <= tol
+    assert float((ps - p[2:4]).abs().max()) <= tol
+
+
+def test_layernorm_invariances_at_baseline_size(LS):
+    """Adding a constant to a row leaves the output unchanged; scaling a row by c > 0 scales (x - mean)/(std + eps) by
+    c*std/(c*std + eps) only — checked on the full C5 activation tensor [1024*256, 136]."""
+    torch.manual_seed(5)
+    x = torch.randn(1024 * 256, 136, device=DEV)
+    a, b = torch.ones(136, device=DEV), torch.zeros(136, device=DEV)
+    y = LS.layer_norm(x, a, b)
+    y_shift = LS.layer_norm(x + 3.0, a, b)
+    assert float((y - y_shift).abs().max()) < 5e-5
+    assert float(y.mean(dim=1).abs().max()) < 1e-5
+    assert float((y.std(dim=1) - 1.0).abs().max()) < 1e-4       # unbiased std of the output is std/(std+eps) ~ 1
