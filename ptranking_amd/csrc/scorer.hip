@@ -281,16 +281,37 @@ mlp_bwd_dz_kernel(const float *__restrict__ P, const float *__restrict__ acts, c
     for (int mt = 0; mt < kMT; ++mt) dwo[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float dbo = 0.0f;
 
-    for (int tile = blockIdx.x * wpb + wave; tile < ntiles; tile += gridDim.x * wpb) {
+    // The tile's first operands (last hidden activation, dpreds) are prefetched one tile ahead as RAW loads (clamped
+    // addresses, no consumer until the next iteration), so their HBM latency hides behind the previous tile's MFMA chain.
+    f32x4 hpf[kMT][RT];
+    float dspf[RT];
+    auto prefetch_top = [&](int tile) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int r = tile * rows_per_tile + 16 * rt + j;
+            const int rc = r < R ? r : R - 1;
+            dspf[rt] = dpreds[rc];
+#pragma unroll
+            for (int mt = 0; mt < kMT; ++mt)
+                hpf[mt][rt] = *reinterpret_cast<const f32x4 *>(acts + ((size_t)(NL - 1) * R + rc) * kAL + 16 * mt + 4 * g);
+        }
+    };
+    const int tile_first = blockIdx.x * wpb + wave, tile_step = gridDim.x * wpb;
+    if (tile_first < ntiles) prefetch_top(tile_first);
+    for (int tile = tile_first; tile < ntiles; tile += tile_step) {
         const int row0 = tile * rows_per_tile;
         int row[RT];
         float ds[RT];
+        f32x4 htop[kMT][RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             row[rt] = row0 + 16 * rt + j;
-            ds[rt] = row[rt] < R ? dpreds[row[rt]] : 0.0f;
+            ds[rt] = dspf[rt] * (row[rt] < R ? 1.0f : 0.0f);
             if (g == 0) dbo += ds[rt];
+#pragma unroll
+            for (int mt = 0; mt < kMT; ++mt) htop[mt][rt] = hpf[mt][rt];
         }
+        if (tile + tile_step < ntiles) prefetch_top(tile + tile_step);
         // top: dz_{NL-1} = ds * w_out * [h > 0];  d w_out += h * ds
         f32x4 cur[kMT][RT];
 #pragma unroll
@@ -300,7 +321,7 @@ mlp_bwd_dz_kernel(const float *__restrict__ P, const float *__restrict__ acts, c
             for (int rt = 0; rt < RT; ++rt) {
                 const bool ok = row[rt] < R;
                 const size_t o = ((size_t)(NL - 1) * R + row[rt]) * kAL + 16 * mt + 4 * g;
-                f32x4 h = *reinterpret_cast<const f32x4 *>(acts + (ok ? o : 0));      // clamped address, zeroed below
+                f32x4 h = htop[mt][rt];
                 const float okf = ok ? 1.0f : 0.0f;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) h[c] *= okf;
@@ -536,42 +557,49 @@ mlp_bwd_dw_lds_kernel(const float *__restrict__ A, int lda, const float *__restr
         z_col[s_] = z_ok[s_] ? 4 * (idx % (kAL / 4)) : 0;
     }
     f32x4 ra[SA], rz[SZ];
-    auto gload = [&](int r0) {                      // global -> registers (masks applied multiplicatively, loads stay unconditional)
+    // global -> registers: RAW loads from clamped (always valid) addresses.  Nothing here consumes the values — the zero
+    // padding and the recomputed input dropout are applied in lstore(), i.e. AFTER the MFMAs of the slab these loads are
+    // prefetched under; a consumer here would pull the s_waitcnt in front of them.
+    auto gload = [&](int r0) {
 #pragma unroll
         for (int s_ = 0; s_ < SA; ++s_) {
             const int r = r0 + a_row[s_];
-            const bool rok = r < r_end;
-            const int rc = rok ? r : r_end - 1;
-            f32x4 v = *reinterpret_cast<const f32x4 *>(A + (size_t)rc * lda + (a_ok[s_] ? a_col[s_] : 0));
-            const float okf = (rok & a_ok[s_]) ? 1.0f : 0.0f;
-            if constexpr (SITE0) {
-                uint32_t w0, w1;
-                drop_bits(a.seed_lo, a.seed_hi, 0, rc, a_col[s_] >> 2, w0, w1);
-                v = drop4(v, w0, w1, thr, scale);
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] *= okf;
-            ra[s_] = v;
+            const int rc = r < r_end ? r : r_end - 1;
+            ra[s_] = *reinterpret_cast<const f32x4 *>(A + (size_t)rc * lda + (a_ok[s_] ? a_col[s_] : 0));
         }
 #pragma unroll
         for (int s_ = 0; s_ < SZ; ++s_) {
             const int r = r0 + z_row[s_];
-            const bool rok = r < r_end;
-            const int rc = rok ? r : r_end - 1;
-            f32x4 v = *reinterpret_cast<const f32x4 *>(dZ + (size_t)rc * kAL + z_col[s_]);
-            const float okf = (rok & z_ok[s_]) ? 1.0f : 0.0f;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] *= okf;
-            rz[s_] = v;
+            const int rc = r < r_end ? r : r_end - 1;
+            rz[s_] = *reinterpret_cast<const f32x4 *>(dZ + (size_t)rc * kAL + z_col[s_]);
         }
     };
-    auto lstore = [&](int buf) {                    // registers -> LDS slab
+    auto lstore = [&](int buf, int r0) {            // registers -> LDS slab (rows r0 ..), masks applied here
 #pragma unroll
-        for (int s_ = 0; s_ < SA; ++s_)
-            *reinterpret_cast<f32x4 *>(ab(buf) + a_row[s_] * LDA + (a_col[s_] - col0)) = ra[s_];
+        for (int s_ = 0; s_ < SA; ++s_) {
+            const int r = r0 + a_row[s_];
+            const bool rok = r < r_end;
+            f32x4 v = ra[s_];
+            if constexpr (SITE0) {
+                uint32_t w0, w1;
+                drop_bits(a.seed_lo, a.seed_hi, 0, rok ? r : r_end - 1, a_col[s_] >> 2, w0, w1);
+                v = drop4(v, w0, w1, thr, scale);
+            }
+            const float okf = (rok & a_ok[s_]) ? 1.0f : 0.0f;
 #pragma unroll
-        for (int s_ = 0; s_ < SZ; ++s_)
-            if (z_ok[s_]) *reinterpret_cast<f32x4 *>(zb(buf) + z_row[s_] * LDZ + z_col[s_]) = rz[s_];
+            for (int c = 0; c < 4; ++c) v[c] *= okf;
+            *reinterpret_cast<f32x4 *>(ab(buf) + a_row[s_] * LDA + (a_col[s_] - col0)) = v;
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < SZ; ++s_) {
+            if (z_ok[s_]) {
+                const float okf = (r0 + z_row[s_] < r_end) ? 1.0f : 0.0f;
+                f32x4 v = rz[s_];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] *= okf;
+                *reinterpret_cast<f32x4 *>(zb(buf) + z_row[s_] * LDZ + z_col[s_]) = v;
+            }
+        }
     };
 
     f32x4 acc[NTW][kMT];
@@ -585,7 +613,7 @@ mlp_bwd_dw_lds_kernel(const float *__restrict__ A, int lda, const float *__restr
 
     if (r_begin < r_end) {
         gload(r_begin);
-        lstore(0);
+        lstore(0, r_begin);
     }
     __syncthreads();
     int buf = 0;
@@ -606,7 +634,7 @@ mlp_bwd_dw_lds_kernel(const float *__restrict__ A, int lda, const float *__restr
                 for (int mt = 0; mt < kMT; ++mt)
                     acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[t], acc[t][mt], 0, 0, 0);
         }
-        if (more) lstore(buf ^ 1);
+        if (more) lstore(buf ^ 1, r0 + RB);
         __syncthreads();
     }
     float *out = ws + (size_t)blockIdx.x * np_stride + w_off;
