@@ -743,7 +743,7 @@ static int env_flag(const char *name, int dflt) {
     const char *e = getenv(name);
     return e ? (atoi(e) != 0) : dflt;
 }
-static int fwd_wide() { static int v = -1; if (v < 0) v = env_flag("PTR_FWD_WIDE", 1); return v; }
+static int fwd_wide() { static int v = -1; if (v < 0) v = env_flag("PTR_FWD_WIDE", 0); return v; }
 static int dw_staged() { static int v = -1; if (v < 0) v = env_flag("PTR_DW_STAGED", 1); return v; }
 static int dw_rb() { static int v = -1; if (v < 0) { const char *e = getenv("PTR_DW_RB"); v = (e && atoi(e) == 32) ? 32 : 16; } return v; }   // 16 measured best (32: 1.09 vs 1.05 ms backward)
 static int dz_wide() { static int v = -1; if (v < 0) v = env_flag("PTR_DZ_WIDE", 0); return v; }
