@@ -225,9 +225,17 @@ def main():
             t_af, t_ab = avg_ms("ptr_mhsa_forward"), avg_ms("ptr_mhsa_backward")
             att_flop = 4.0 * B * L * L * F                         # QK^T and PV, 2 flop per MAC, all heads (H * d_h = F)
             tf = att_flop / (t_af * 1e-3) / 1e12
+            c5_traffic = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_c5.json")) as f:
+                    j5 = json.load(f)
+                if j5["config"] == {"queries_per_gpu_per_step": B, "list_len": L, "features": F}:
+                    c5_traffic = next((v["hbm_bytes_per_launch"] for k, v in j5["kernels"].items() if k.startswith("ptr::mhsa_fwd_kernel")), None)
+            except (OSError, KeyError, ValueError):
+                pass
             roofline = {"kernel": "mhsa_fwd_kernel (fused attention core: QK^T/sqrt(d) -> online softmax -> dropout -> PV, fp32 MFMA 16x16x4)",
                         "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
-                        "traffic": None, "avg_launch_ms": t_af, "algorithmic_flop_per_launch": att_flop,
+                        "traffic": c5_traffic, "avg_launch_ms": t_af, "algorithmic_flop_per_launch": att_flop,
                         "algorithmic_bytes_per_launch": 4 * B * L * F * 4 + B * 2 * L * 4,
                         "note": "one launch per encoder layer; the linear / feed-forward GEMMs of listsf are library calls"}
             kernels["attention_backward"] = {"kernels": "attn_rowdot + mhsa_bwd_dq + mhsa_bwd_dkv", "avg_call_ms": t_ab,

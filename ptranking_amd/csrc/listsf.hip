@@ -40,6 +40,13 @@ struct AttnArgs {
 // LDS leading dimension for a [rows][dh] tile: covers the 16*DT columns the d-tiles touch, ld/4 odd (conflict-free b128)
 __host__ __device__ constexpr int attn_ld(int DT) { return ((16 * DT / 4) & 1) ? 16 * DT : 16 * DT + 4; }
 
+// Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  The row (key) blocks of one (query, head) re-read the
+// same K / V (Q / dO) rows, so consecutive LOGICAL block ids are placed on the same XCD: logical = xcd * (n / 8) + slot.
+__device__ __forceinline__ int xcd_major_block_id() {
+    const int n = gridDim.x, b = blockIdx.x;
+    return (n & 7) == 0 ? (b & 7) * (n >> 3) + (b >> 3) : b;
+}
+
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 // Software-pipelined staging of rows [row0, row0 + NROWS) of a head's column block into an LDS tile dst[NROWS][LD] (rows >=
@@ -178,7 +185,8 @@ mhsa_fwd_kernel(const float *__restrict__ Q, const float *__restrict__ K, const 
     float *Ks = smem, *Vs = Ks + (size_t)KC * ld;
     const int L = a.L, F = a.F, dh = a.dh, ldi = a.ld;
     const int nrb = (L + RPB - 1) / RPB;
-    const int rb = blockIdx.x % nrb, bh = blockIdx.x / nrb, b = bh / a.H, h = bh - b * a.H;
+    const int lid = xcd_major_block_id();
+    const int rb = lid % nrb, bh = lid / nrb, b = bh / a.H, h = bh - b * a.H;
     int n = lens ? lens[b] : L;
     n = n < 0 ? 0 : (n > L ? L : n);
     const size_t base = (size_t)b * L * ldi + (size_t)h * dh, obase = (size_t)b * L * F + (size_t)h * dh;
@@ -317,7 +325,8 @@ mhsa_bwd_dq_kernel(const float *__restrict__ Q, const float *__restrict__ K, con
     float *Ks = smem, *Vs = Ks + (size_t)KC * ld;
     const int L = a.L, F = a.F, dh = a.dh, ldi = a.ld;
     const int nrb = (L + RPB - 1) / RPB;
-    const int rb = blockIdx.x % nrb, bh = blockIdx.x / nrb, b = bh / a.H, h = bh - b * a.H;
+    const int lid = xcd_major_block_id();
+    const int rb = lid % nrb, bh = lid / nrb, b = bh / a.H, h = bh - b * a.H;
     int n = lens ? lens[b] : L;
     n = n < 0 ? 0 : (n > L ? L : n);
     const size_t base = (size_t)b * L * ldi + (size_t)h * dh, obase = (size_t)b * L * F + (size_t)h * dh;
@@ -410,7 +419,8 @@ mhsa_bwd_dkv_kernel(const float *__restrict__ Q, const float *__restrict__ K, co
     float *lse_s = Gs + (size_t)kRC * ld, *D_s = lse_s + kRC;
     const int L = a.L, F = a.F, dh = a.dh, ldi = a.ld;
     const int nkb = (L + KPB - 1) / KPB;
-    const int kb = blockIdx.x % nkb, bh = blockIdx.x / nkb, b = bh / a.H, h = bh - b * a.H;
+    const int lid = xcd_major_block_id();
+    const int kb = lid % nkb, bh = lid / nkb, b = bh / a.H, h = bh - b * a.H;
     int n = lens ? lens[b] : L;
     n = n < 0 ? 0 : (n > L ? L : n);
     const size_t base = (size_t)b * L * ldi + (size_t)h * dh, obase = (size_t)b * L * F + (size_t)h * dh;
