@@ -52,13 +52,51 @@ struct MlpArgs {
 
 
 // Stage a [rows_valid][cols_valid] row-major matrix into LDS as [kHP][ld], zero padded.  transpose: dst[c][r] = src[r][c].
+// The source is walked linearly (coalesced) in batches of U INDEPENDENT loads — a plain `for (...) dst[i] = src[...]` loop issues
+// one load per iteration and waits for it (75 dependent L2 round trips per thread = 25 us of prologue at F = 136); the zero padding
+// of the [kHP][ld] tile is written separately (disjoint elements, no barrier needed in between).
 __device__ __forceinline__ void stage_matrix(float *dst, int ld, const float *src, int rows, int cols, bool transpose, int tid, int nthr) {
+    constexpr int U = 8;
+    const int n = rows * cols;
+    const bool vec = ((cols & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+    if (vec) {
+        const int n4 = n >> 2;
+        for (int base = tid; base < n4; base += U * nthr) {
+            f32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i4 = base + u * nthr;
+                v[u] = *reinterpret_cast<const f32x4 *>(src + 4 * (size_t)(i4 < n4 ? i4 : n4 - 1));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i4 = base + u * nthr;
+                if (i4 < n4) {
+                    const int idx = 4 * i4, r = idx / cols, c = idx - r * cols;
+                    if (!transpose) *reinterpret_cast<f32x4 *>(dst + (size_t)r * ld + c) = v[u];
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dst[(size_t)(c + e) * ld + r] = v[u][e];
+                    }
+                }
+            }
+        }
+    } else {
+        for (int base = tid; base < n; base += U * nthr) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int idx = base + u * nthr; v[u] = src[idx < n ? idx : n - 1]; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + u * nthr;
+                if (idx < n) { const int r = idx / cols, c = idx - r * cols; dst[transpose ? (size_t)c * ld + r : (size_t)r * ld + c] = v[u]; }
+            }
+        }
+    }
+    const int vr = transpose ? cols : rows, vc = transpose ? rows : cols;
     for (int idx = tid; idx < kHP * ld; idx += nthr) {
         const int r = idx / ld, c = idx - r * ld;
-        float v = 0.0f;
-        if (!transpose) { if (r < rows && c < cols) v = src[(size_t)r * cols + c]; }
-        else            { if (r < cols && c < rows) v = src[(size_t)c * cols + r]; }
-        dst[idx] = v;
+        if (r >= vr || c >= vc) dst[idx] = 0.0f;
     }
 }
 __device__ __forceinline__ void stage_vector(float *dst, const float *src, int n, int tid, int nthr) {
