@@ -94,6 +94,13 @@ class FlatGradBucket:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
 
 
+def all_reduce_sum(t):
+    """In-place SUM all-reduce of one contiguous tensor (no-op when not distributed)."""
+    if is_distributed():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
 def broadcast_parameters(params, src=0):
     """Make every replica start from rank `src`'s weights."""
     if is_distributed():

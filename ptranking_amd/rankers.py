@@ -40,6 +40,7 @@ class FusedStepMixin:
 
     data_parallel = True          # only takes effect when torch.distributed is initialised with world_size > 1
     _grad_bucket = None
+    _dp_single = None
 
     def _bucket(self, extra=0):
         if self._grad_bucket is None or self._grad_bucket.extra != extra:
@@ -48,10 +49,20 @@ class FusedStepMixin:
 
     def _fused_step(self, loss):
         if self.data_parallel and dp.is_distributed():
-            bucket = self._bucket()
-            bucket.zero()
-            loss.backward()
-            bucket.all_reduce()
+            if self._dp_single is None:
+                ps = [p for p in self.get_parameters() if p.requires_grad]
+                self._dp_single = ps[0] if len(ps) == 1 else False
+            if self._dp_single is not False:
+                # fused scorer: ONE flat parameter -> backward hands back one flat gradient, reduced in place
+                # (no bucket memset, no accumulate-into-view copy)
+                self.optimizer.zero_grad()
+                loss.backward()
+                dp.all_reduce_sum(self._dp_single.grad)
+            else:
+                bucket = self._bucket()
+                bucket.zero()
+                loss.backward()
+                bucket.all_reduce()
         else:
             self.optimizer.zero_grad()
             loss.backward()
