@@ -37,6 +37,10 @@ def uninstall(ltr_module="ptranking.ltr_adhoc.eval.ltr"):
     """Restore the reference's own classes."""
     mod = importlib.import_module(ltr_module)
     for (m, n), cls in list(_saved.items()):
-        if m == ltr_module and cls is not None:
+        if m != ltr_module:
+            continue
+        if cls is not None:
             setattr(mod, n, cls)
-            del _saved[(m, n)]
+        elif hasattr(mod, n):          # the name did not exist before install() (e.g. DASALC is never imported by ltr.py)
+            delattr(mod, n)
+        del _saved[(m, n)]

@@ -17,7 +17,7 @@ from .host import DeviceEvaluator, DeviceTrainLoop, PointScorerRanker, is_multil
 from .listsf import FusedListScorerMixin
 from .scorer import FusedScorerMixin
 
-RANKER_NAMES = ("RankNet", "LambdaRank", "LambdaLoss", "ApproxNDCG", "ListNet", "ListMLE", "STListNet", "RankCosine", "RankMSE", "SoftRank")
+RANKER_NAMES = ("RankNet", "LambdaRank", "LambdaLoss", "ApproxNDCG", "ListNet", "ListMLE", "STListNet", "RankCosine", "RankMSE", "SoftRank", "DASALC")
 
 # default hyper-parameters = the reference's `default_para_dict()`s
 DEFAULT_PARAS = {
@@ -31,6 +31,7 @@ DEFAULT_PARAS = {
     "RankCosine": dict(model_id="RankCosine"),
     "RankMSE": dict(model_id="RankMSE"),
     "SoftRank": dict(model_id="SoftRank", delta=2.0, metric='nDCG', top_k=None),       # listwise/softrank.py:97
+    "DASALC": dict(model_id="DASALC"),
 }
 
 
@@ -248,8 +249,15 @@ def make_ranker_classes(base=PointScorerRanker):
             self.top_k = model_para_dict['top_k']
             self.metric = model_para_dict['metric']
 
+    class DASALC(ListNetLoss, FusedScorerMixin, FusedListScorerMixin, DeviceTrainLoop, DeviceEvaluator, base):
+        """ptranking/ltr_adhoc/listwise/dasalc.py:7-41: the top-1 ListNet loss on the listwise (listsf) scorer."""
+
+        def __init__(self, sf_para_dict=None, gpu=False, device=None):
+            base.__init__(self, id='DASALC', sf_para_dict=sf_para_dict, gpu=gpu, device=device)
+            assert 'listsf' == sf_para_dict['sf_id']
+
     out = dict(RankNet=RankNet, LambdaRank=LambdaRank, LambdaLoss=LambdaLoss, ApproxNDCG=ApproxNDCG, ListNet=ListNet,
-               ListMLE=ListMLE, STListNet=STListNet, RankCosine=RankCosine, RankMSE=RankMSE, SoftRank=SoftRank)
+               ListMLE=ListMLE, STListNet=STListNet, RankCosine=RankCosine, RankMSE=RankMSE, SoftRank=SoftRank, DASALC=DASALC)
     for name, cls in out.items():
         cls.__name__ = cls.__qualname__ = name
         cls.__module__ = __name__
@@ -260,4 +268,4 @@ _standalone = make_ranker_classes(PointScorerRanker)
 RankNet, LambdaRank, LambdaLoss = _standalone["RankNet"], _standalone["LambdaRank"], _standalone["LambdaLoss"]
 ApproxNDCG, ListNet, ListMLE = _standalone["ApproxNDCG"], _standalone["ListNet"], _standalone["ListMLE"]
 STListNet, RankCosine, RankMSE = _standalone["STListNet"], _standalone["RankCosine"], _standalone["RankMSE"]
-SoftRank = _standalone["SoftRank"]
+SoftRank, DASALC = _standalone["SoftRank"], _standalone["DASALC"]

@@ -210,3 +210,20 @@ def test_layernorm_invariances_at_baseline_size(LS):
     assert float((y - y_shift).abs().max()) < 5e-5
     assert float(y.mean(dim=1).abs().max()) < 1e-5
     assert float((y.std(dim=1) - 1.0).abs().max()) < 1e-4       # unbiased std of the output is std/(std+eps) ~ 1
+
+
+def test_dasalc_ranker_trains(LS):
+    """ptranking/ltr_adhoc/listwise/dasalc.py: ListNet's top-1 loss on the listsf scorer."""
+    import ptranking_amd as pa
+    listsf = dict(num_features=24, ff_dims=[16, 32], AF='R', TL_AF='GE', apply_tl_af=False, BN=False, bn_type='BN2', bn_affine=False,
+                  n_heads=2, encoder_layers=2, encoder_type='DASALC')
+    sf = dict(sf_id='listsf', opt='Adagrad', lr=0.01, listsf=listsf)
+    r = pa.DASALC(sf_para_dict=copy.deepcopy(sf), gpu=True, device=DEV)
+    r.init(); r.train_mode()
+    torch.manual_seed(4)
+    X = torch.randn(16, 40, 24, device=DEV)
+    Y = torch.sort(torch.randint(0, 5, (16, 40), device=DEV).float(), dim=1, descending=True)[0].contiguous()
+    losses = [float(r.train_op(X, Y, epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)[0]) for _ in range(30)]
+    assert all(np.isfinite(losses)) and np.mean(losses[-5:]) < np.mean(losses[:5])
+    with pytest.raises(AssertionError):
+        pa.DASALC(sf_para_dict={"sf_id": "pointsf", "opt": "Adam", "lr": 1e-3, "pointsf": {}}, gpu=True, device=DEV)
