@@ -227,3 +227,17 @@ def test_dasalc_ranker_trains(LS):
     assert all(np.isfinite(losses)) and np.mean(losses[-5:]) < np.mean(losses[:5])
     with pytest.raises(AssertionError):
         pa.DASALC(sf_para_dict={"sf_id": "pointsf", "opt": "Adam", "lr": 1e-3, "pointsf": {}}, gpu=True, device=DEV)
+
+
+def test_empty_query_and_extreme_scores(LS):
+    """lens = 0 (a fully padded query) gives zero output and zero gradients, never NaN; scores of magnitude 1e4 stay finite."""
+    torch.manual_seed(9)
+    B, L, Fd, H = 3, 70, 24, 2
+    q, k, v = (torch.randn(B, L, Fd, device=DEV).requires_grad_(True) for _ in range(3))
+    lens = torch.tensor([70, 0, 5], dtype=torch.int32, device=DEV)
+    o = LS.mhsa_core(q * 100.0, k * 100.0, v, H, p_drop=0.1, seed=3, site=0, lens=lens)
+    o.sum().backward()
+    assert torch.isfinite(o).all() and all(torch.isfinite(t.grad).all() for t in (q, k, v))
+    assert float(o.detach()[1].abs().max()) == 0.0
+    assert float(k.grad[1].abs().max()) == 0.0 and float(v.grad[1].abs().max()) == 0.0 and float(q.grad[1].abs().max()) == 0.0
+    assert float(k.grad[2, 5:].abs().max()) == 0.0 and float(v.grad[2, 5:].abs().max()) == 0.0
