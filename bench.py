@@ -55,28 +55,48 @@ def sf_para_dict(F, lr=1e-3):
 
 
 def cpu_baseline(L, F, budget_s):
-    """Torch-CPU restatement of the reference's LambdaRank train step (oracle/torch_ref.py), all host cores."""
+    """Torch-CPU restatement of the reference's LambdaRank train step (oracle/torch_ref.py), all host cores.  Timed at the batch
+    sizes SURVEY.md 8(d) names: 1 (the reference's own default for lists of >= 100 documents, data_utils.py:713-716), 64 and 256;
+    `value` is the best of them.  Also a loss-only timing (leaf preds -> loss -> backward), kernel against kernel."""
     from oracle import torch_ref as T
     torch.manual_seed(SEED)
-    B = 256
     gen = torch.Generator().manual_seed(SEED)
-    X, Y = synth_batch(gen, B, L, F, "cpu")
+    Xf, Yf = synth_batch(gen, 256, L, F, "cpu")
     net = T.build_pointsf(F, seed=SEED)
     net.train()
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-3)
-    for _ in range(2):
-        T.cpu_train_step(net, opt, X, Y, T.lambdarank_loss, sigma=1.0)
-    t0 = time.perf_counter()
-    steps = 0
-    while True:
-        T.cpu_train_step(net, opt, X, Y, T.lambdarank_loss, sigma=1.0)
-        steps += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or steps >= 200:
-            break
-    return {"value": B * steps / el, "unit": "queries/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} train steps of {B} queries x {L} docs x {F} feats (torch-CPU restatement of the reference "
-                      f"train_op: pointsf scorer + LambdaRank + Adam), {el:.1f} s"}
+
+    def timed(fn, units, budget, max_iters):
+        for _ in range(2):
+            fn()
+        t0 = time.perf_counter()
+        it = 0
+        while True:
+            fn()
+            it += 1
+            el = time.perf_counter() - t0
+            if el >= budget or it >= max_iters:
+                return units * it / el, it, el
+
+    by_batch = {}
+    total = 0.0
+    for B, share, cap in ((1, 0.15, 2000), (64, 0.2, 400), (256, 0.5, 200)):
+        X, Y = Xf[:B].contiguous(), Yf[:B].contiguous()
+        qps, it, el = timed(lambda: T.cpu_train_step(net, opt, X, Y, T.lambdarank_loss, sigma=1.0), B, share * budget_s, cap)
+        by_batch[f"B{B}"] = {"queries_per_s": qps, "steps": it, "seconds": el}
+        total += el
+    preds = torch.randn(256, L, generator=gen)
+
+    def loss_only():
+        p = preds.clone().requires_grad_(True)
+        T.lambdarank_loss(p, Yf, sigma=1.0).backward()
+
+    lq, lit, lel = timed(loss_only, 256, 0.15 * budget_s, 400)
+    best = max(by_batch.values(), key=lambda d: d["queries_per_s"])
+    return {"value": best["queries_per_s"], "unit": "queries/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"torch-CPU restatement of the reference train_op (pointsf scorer + LambdaRank + Adam) on {L} docs x {F} feats: "
+                      f"batch sizes 1 / 64 / 256 for {total:.1f} s in total, value = best; plus {lel:.1f} s loss-only",
+            "by_batch": by_batch, "loss_only_queries_per_s": lq}
 
 
 def main():
