@@ -20,6 +20,7 @@ import torch.nn as nn
 import torch.optim as optim
 from torch.optim.lr_scheduler import StepLR
 
+from . import dp
 from . import functional as F_
 from .batching import unpack_batch
 
@@ -78,6 +79,20 @@ class DeviceEvaluator:
             if need_per_q:
                 for m in which:
                     per_q[m].append(out[m].cpu())
+        if getattr(self, 'distributed_eval', False) and dp.is_distributed():
+            # every rank evaluated ITS shard of the queries: one all_reduce(SUM) of [sum metric@ks ..., num_queries] per pass
+            # (SURVEY.md 8e); per-query lists stay local
+            dev = torch.device(self.device)
+            if sums is None:
+                sums = {m: torch.zeros(len(ks), device=dev) for m in which}
+            nq = num_queries if torch.is_tensor(num_queries) else torch.tensor(float(num_queries), device=dev)
+            pack = torch.cat([sums[m].float() for m in which] + [nq.reshape(1).float().to(dev)])
+            dp.all_reduce_sum(pack)
+            for i, m in enumerate(which):
+                sums[m] = pack[i * len(ks):(i + 1) * len(ks)]
+            num_queries = pack[-1]
+            if float(num_queries) == 0.0:
+                sums = None
         if sums is None:   # nothing evaluated: the reference divides 0 by 0 here
             avg = {m: torch.zeros(len(ks)) / 0.0 for m in which}
         else:

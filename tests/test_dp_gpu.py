@@ -120,3 +120,37 @@ def test_listsf_two_ranks_match_the_full_batch(tmp_path):
     ref = _flat_grads(r)
     scale = max(1.0, float(ref.abs().max()))
     assert float((r0["grads"] - ref).abs().max()) <= 2e-5 * scale
+
+
+# ------------------------------------------------------------------------------------------------ distributed evaluation
+def _worker_eval(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      PTR_DP_BACKEND="gloo")
+    import ptranking_amd as pa
+    from ptranking_amd import dp
+    dp.init_from_env()
+    X, Y = _data(B=11, L=64, F=136)
+    lo, hi = dp.shard_queries(X.size(0))
+    r = _make("LambdaRank")
+    r.distributed_eval = True
+    batches = [(list(range(lo, hi)), X[lo:hi].cuda(), Y[lo:hi].cuda())]
+    ndcg = r.ndcg_at_ks(test_data=batches, ks=[1, 5, 10], label_type=pa.LABEL_TYPE.MultiLabel, presort=True)
+    perf = r.adhoc_performance_at_ks(test_data=batches, ks=[1, 5, 10], label_type=pa.LABEL_TYPE.MultiLabel, max_label=4.0, presort=True)
+    torch.save({"ndcg": ndcg, "ap": perf[2]}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_distributed_evaluation_matches_single_process(tmp_path):
+    """Each rank evaluates its shard; one all_reduce(SUM) of [sum metric@ks, num_queries] gives every rank the global average."""
+    import ptranking_amd as pa
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker_eval, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"rank{i}.pt") for i in range(2))
+    assert torch.equal(r0["ndcg"], r1["ndcg"]) and torch.equal(r0["ap"], r1["ap"])
+    X, Y = _data(B=11, L=64, F=136)
+    r = _make("LambdaRank")
+    full = [(list(range(11)), X.cuda(), Y.cuda())]
+    ndcg = r.ndcg_at_ks(test_data=full, ks=[1, 5, 10], label_type=pa.LABEL_TYPE.MultiLabel, presort=True)
+    ap = r.adhoc_performance_at_ks(test_data=full, ks=[1, 5, 10], label_type=pa.LABEL_TYPE.MultiLabel, max_label=4.0, presort=True)[2]
+    assert torch.allclose(r0["ndcg"], ndcg, atol=1e-6) and torch.allclose(r0["ap"], ap, atol=1e-6)
