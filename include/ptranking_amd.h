@@ -122,11 +122,14 @@ int ptr_sort_desc(const float *preds, const int32_t *lens, int B, int L, float *
  * ptranking/metric/adhoc/adhoc_metric.py:36-62 (P@ks), :91-123 (AP@ks), :127-193 (nERR@ks), :219-260 (nDCG@ks).
  *   ks: HOST int32[nk] cut-offs (nk <= PTR_MAX_CUTOFFS); presort != 0 => labels already ideal-ordered;
  *   max_label: nERR's 2^max_label normaliser; < 0 => the batch maximum is computed on device into max_label_ws[1];
+ *   label_type: PTR_LABEL_* (nDCG's gain, adhoc_metric.py:207-212; nERR exists for MultiLabel only, as in the reference);
  *   ndcg/nerr/ap/prec: [B,nk] outputs, each nullable.  Cut-offs larger than the list are zero-filled at the END
  *   of the row exactly like the reference's padded_*_at_ks. */
+#define PTR_LABEL_MULTILABEL 0    /* LABEL_TYPE.MultiLabel: graded labels, DCG gain 2^l - 1 (data_utils.py:120-126)          */
+#define PTR_LABEL_PERMUTATION 1   /* LABEL_TYPE.Permutation: labels = n - rank position, DCG gain = the label itself        */
 int ptr_metrics_at_ks(const float *preds, const float *labels, const int32_t *lens, int B, int L, const int32_t *ks,
-                      int nk, int presort, float max_label, float *max_label_ws, float *ndcg, float *nerr, float *ap,
-                      float *prec, void *stream);
+                      int nk, int presort, int label_type, float max_label, float *max_label_ws, float *ndcg, float *nerr,
+                      float *ap, float *prec, void *stream);
 
 /* Deterministic sum of n floats (fixed reduction tree): out[0] = scale * sum(x).  Used for the per-query loss slots
  * and for Evaluator running sums. */

@@ -120,12 +120,12 @@ def listmle(preds, perm, lens=None):
     return loss_q, grad
 
 
-def metrics_at_ks(preds, labels, ks, presort, max_label=None, lens=None):
+def metrics_at_ks(preds, labels, ks, presort, max_label=None, lens=None, permutation_labels=False):
     """-> dict(ndcg, nerr, ap, p) of [B, len(ks)] float32."""
     preds, labels = _f(preds), _f(labels); B, L = preds.shape; lens = _lens(lens)
     ks = np.ascontiguousarray(ks, dtype=np.int32); nk = len(ks)
     out = {m: np.empty((B, nk), np.float32) for m in ("ndcg", "nerr", "ap", "p")}
     ml = -1.0 if max_label is None else float(max_label)
     _chk(lib().orc_metrics_at_ks(_p(preds), _p(labels), _p(lens, _i32p), B, L, _p(ks, _i32p), nk, C.c_int(int(presort)),
-                                 C.c_float(ml), _p(out["ndcg"]), _p(out["nerr"]), _p(out["ap"]), _p(out["p"])), "metrics")
+                                 C.c_int(int(permutation_labels)), C.c_float(ml), _p(out["ndcg"]), _p(out["nerr"]), _p(out["ap"]), _p(out["p"])), "metrics")
     return out

@@ -469,7 +469,7 @@ int orc_listmle(const float *preds, const int64_t *perm, const int32_t *lens, in
  * Outputs are [B, nk] each (any may be NULL); cut-offs > list length are zero-filled AT THE END of the row, exactly
  * like the reference's padded_*_at_ks.  max_label < 0 => use the batch maximum (adhoc_metric.py:174-175). */
 int orc_metrics_at_ks(const float *preds, const float *labels, const int32_t *lens, int B, int L, const int32_t *ks,
-                      int nk, int presort, float max_label, float *ndcg, float *nerr, float *ap, float *prec) {
+                      int nk, int presort, int linear_gain, float max_label, float *ndcg, float *nerr, float *ap, float *prec) {
     size_t Ls = (size_t)(L > 0 ? L : 1);
     kv_t *tmp = (kv_t *)malloc(sizeof(kv_t) * Ls);
     int32_t *ix = (int32_t *)malloc(sizeof(int32_t) * Ls);
@@ -500,7 +500,8 @@ int orc_metrics_at_ks(const float *preds, const float *labels, const int32_t *le
         float serr = 0.0f, ierr = 0.0f, sun = 1.0f, iun = 1.0f;
         for (int r = 0; r < n; ++r) {
             float disc = log2f((float)r + 2.0f);
-            sdcg += gain(sys[r]) / disc; idcg += gain(ideal[r]) / disc;
+            /* LABEL_TYPE.Permutation: the label is the gain (adhoc_metric.py:207-212) */
+            sdcg += (linear_gain ? sys[r] : gain(sys[r])) / disc; idcg += (linear_gain ? ideal[r] : gain(ideal[r])) / disc;
             float rel = sys[r] < 0.0f ? 0.0f : (sys[r] > 1.0f ? 1.0f : sys[r]);
             cumrel += rel;
             float pr = cumrel / ((float)r + 1.0f);

@@ -236,15 +236,17 @@ def _pad_ks(vals_at, ks, L, B):
     return out
 
 
-def ndcg_at_ks(sys_sorted, ideal_sorted, ks):
-    """ptranking/metric/adhoc/adhoc_metric.py:219-260 (cumsum DCG, zero-fill cut-offs > L at the END of the row)."""
+def ndcg_at_ks(sys_sorted, ideal_sorted, ks, permutation_labels=False):
+    """ptranking/metric/adhoc/adhoc_metric.py:219-260 (cumsum DCG, zero-fill cut-offs > L at the END of the row);
+    LABEL_TYPE.Permutation: the label is the gain (:225-230)."""
     B, L = sys_sorted.shape
+    gain = (lambda t: t) if permutation_labels else _gain
 
     def at(used):
         m = max(used)
         disc = torch.log2(torch.arange(m, dtype=torch.float32) + 2.0)
-        s = torch.cumsum(_gain(sys_sorted[:, :m]) / disc, dim=1)
-        i = torch.cumsum(_gain(ideal_sorted[:, :m]) / disc, dim=1)
+        s = torch.cumsum(gain(sys_sorted[:, :m]) / disc, dim=1)
+        i = torch.cumsum(gain(ideal_sorted[:, :m]) / disc, dim=1)
         ix = torch.tensor(used) - 1
         return s[:, ix] / i[:, ix]
     return _pad_ks(at, ks, L, B)

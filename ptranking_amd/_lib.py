@@ -33,7 +33,7 @@ SIGNATURES = {
     "ptr_rankcosine_fwd_bwd": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
     "ptr_shuffle_ties_order": [_vp, _vp, _i, _i, _u64, _vp, _vp],
     "ptr_sort_desc": [_vp, _vp, _i, _i, _vp, _vp, _vp],
-    "ptr_metrics_at_ks": [_vp, _vp, _vp, _i, _i, C.POINTER(C.c_int32), _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ptr_metrics_at_ks": [_vp, _vp, _vp, _i, _i, C.POINTER(C.c_int32), _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp],
     "ptr_sum_f32": [_vp, _i, _f, _vp, _vp],
     "ptr_mlp_num_params": [_i, _i],
     "ptr_mlp_backward_ws_floats": [_i, _i],

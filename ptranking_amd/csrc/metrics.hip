@@ -79,7 +79,7 @@ batch_max_kernel(const float *__restrict__ labels, const int32_t *__restrict__ l
 template <int G, int DPT>
 __global__ void __launch_bounds__(kBlock)
 metrics_kernel(const float *__restrict__ preds, const float *__restrict__ labels, const int32_t *__restrict__ lens, int B, int L,
-               int Lp, Cutoffs ck, int presort, float max_label_host, const float *__restrict__ max_label_dev,
+               int Lp, Cutoffs ck, int presort, int linear_gain, float max_label_host, const float *__restrict__ max_label_dev,
                float *__restrict__ o_ndcg, float *__restrict__ o_nerr, float *__restrict__ o_ap, float *__restrict__ o_p) {
     constexpr int QPB = kBlock / G;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -142,7 +142,8 @@ metrics_kernel(const float *__restrict__ preds, const float *__restrict__ labels
             const bool in = r < kmax;
             const float ys = in ? Y_sys[r] : 0.0f, yi = in ? Y_id[r] : 0.0f;
             const float disc = log2f((float)r + 2.0f);
-            const float gs = in ? gain_of(ys) : 0.0f, gi = in ? gain_of(yi) : 0.0f;
+            // DCG gain: 2^l - 1 for graded labels, the raw label for LABEL_TYPE.Permutation (adhoc_metric.py:207-212,225-230)
+            const float gs = in ? (linear_gain ? ys : gain_of(ys)) : 0.0f, gi = in ? (linear_gain ? yi : gain_of(yi)) : 0.0f;
             const float sdcg = wave_incl_sum(in ? gs / disc : 0.0f, lane) + c_sdcg;     // adhoc_metric.py:233-234
             const float idcg = wave_incl_sum(in ? gi / disc : 0.0f, lane) + c_idcg;
             const float rel = in ? fminf(fmaxf(ys, 0.0f), 1.0f) : 0.0f;                // binary relevance (:106)
@@ -199,13 +200,18 @@ extern "C" int ptr_sort_desc(const float *preds, const int32_t *lens, int B, int
 }
 
 extern "C" int ptr_metrics_at_ks(const float *preds, const float *labels, const int32_t *lens, int B, int L, const int32_t *ks,
-                                 int nk, int presort, float max_label, float *max_label_ws, float *ndcg, float *nerr, float *ap,
+                                 int nk, int presort, int label_type, float max_label, float *max_label_ws, float *ndcg, float *nerr, float *ap,
                                  float *prec, void *stream) {
     using namespace ptr;
     const char *who = "ptr_metrics_at_ks";
     if (int rc = check_batch(preds, labels, B, L, who)) return rc;
     if (nk < 0 || (nk > 0 && !ks)) { set_error("%s: bad cut-off list", who); return PTR_ERR_INVALID_ARG; }
     if (nk > PTR_MAX_CUTOFFS) { set_error("%s: %d cut-offs exceed PTR_MAX_CUTOFFS=%d", who, nk, PTR_MAX_CUTOFFS); return PTR_ERR_UNSUPPORTED; }
+    if (label_type != PTR_LABEL_MULTILABEL && label_type != PTR_LABEL_PERMUTATION) { set_error("%s: unknown label_type %d", who, label_type); return PTR_ERR_INVALID_ARG; }
+    if (nerr && label_type != PTR_LABEL_MULTILABEL) {   // adhoc_metric.py:157-164 raises NotImplementedError for anything else
+        set_error("%s: nERR is only defined for graded (MultiLabel) labels", who);
+        return PTR_ERR_UNSUPPORTED;
+    }
     if (nerr && max_label < 0.0f && !max_label_ws) {
         set_error("%s: nERR with max_label < 0 needs the max_label_ws device scalar", who);
         return PTR_ERR_INVALID_ARG;
@@ -229,7 +235,7 @@ extern "C" int ptr_metrics_at_ks(const float *preds, const float *labels, const 
         auto kern = metrics_kernel<G, DPT>;
         const size_t lds = (size_t)QPB * 3 * Lp * sizeof(float);
         if (int e = allow_lds(kern, lds)) return e;
-        hipLaunchKernelGGL(kern, dim3((B + QPB - 1) / QPB), dim3(kBlock), lds, st, preds, labels, lens, B, L, Lp, ck, presort, max_label,
+        hipLaunchKernelGGL(kern, dim3((B + QPB - 1) / QPB), dim3(kBlock), lds, st, preds, labels, lens, B, L, Lp, ck, presort, label_type == PTR_LABEL_PERMUTATION ? 1 : 0, max_label,
                            ml_dev, ndcg, nerr, ap, prec);
         return check_hip(hipGetLastError(), who);
     });

@@ -236,9 +236,13 @@ def sort_desc(preds, lens=None):
     return vals, idx
 
 
-def metrics_at_ks(preds, labels, ks, presort=False, max_label=None, lens=None, which=("ndcg", "nerr", "ap", "p")):
+def metrics_at_ks(preds, labels, ks, presort=False, max_label=None, lens=None, which=("ndcg", "nerr", "ap", "p"),
+                  permutation_labels=False):
     """Evaluator prologue + metrics at cut-offs `ks` for one batch -> dict name -> [B, len(ks)] float32 on device.
-    Replaces ptranking/base/ranker.py:220-243 + ptranking/metric/adhoc/adhoc_metric.py @ks functions."""
+    Replaces ptranking/base/ranker.py:220-243 + ptranking/metric/adhoc/adhoc_metric.py @ks functions.
+    permutation_labels: LABEL_TYPE.Permutation — nDCG's gain is the label itself; nERR is undefined (NotImplementedError)."""
+    if permutation_labels and "nerr" in which:
+        raise NotImplementedError("nERR is only defined for LABEL_TYPE.MultiLabel (adhoc_metric.py:157-164)")
     preds, labels, lens, B, L = _batch(preds.detach(), labels, lens)
     ks = [int(k) for k in ks]
     if len(ks) > _lib.MAX_CUTOFFS:
@@ -250,7 +254,7 @@ def metrics_at_ks(preds, labels, ks, presort=False, max_label=None, lens=None, w
     ml = -1.0 if max_label is None else float(max_label)
     with torch.cuda.device(dev):
         _lib.call("ptr_metrics_at_ks", _lib.ptr(preds), _lib.ptr(labels), _lib.ptr(lens), B, L, ks_arr, len(ks),
-                  int(bool(presort)), C.c_float(ml), _lib.ptr(ws), _lib.ptr(out.get("ndcg")), _lib.ptr(out.get("nerr")),
+                  int(bool(presort)), int(bool(permutation_labels)), C.c_float(ml), _lib.ptr(ws), _lib.ptr(out.get("ndcg")), _lib.ptr(out.get("nerr")),
                   _lib.ptr(out.get("ap")), _lib.ptr(out.get("p")), _lib.current_stream(dev))
     return out
 

@@ -32,6 +32,11 @@ class LABEL_TYPE(Enum):
     Permutation = auto()
 
 
+def is_permutation(label_type):
+    """True for LABEL_TYPE.Permutation (ours or the reference's enum member of the same name)."""
+    return getattr(label_type, "name", None) == "Permutation"
+
+
 def is_multilabel(label_type):
     """True for our LABEL_TYPE.MultiLabel and for the reference's enum member of the same name."""
     return getattr(label_type, "name", label_type) == "MultiLabel"
@@ -46,7 +51,7 @@ class DeviceEvaluator:
     def _to_dev(self, t):
         return t.to(self.device, non_blocking=True) if t.device != torch.device(self.device) else t
 
-    def _run_eval(self, test_data, ks, presort, which, max_label=None, min_len=None, need_per_q=False):
+    def _run_eval(self, test_data, ks, presort, which, max_label=None, min_len=None, need_per_q=False, permutation_labels=False):
         """Shared loop of every Evaluator method.  Accepts the reference's (ids, X, Y) batches (all lists of a batch have the
         same length) and PaddedQueryBatches' (ids, X, Y, lens).  min_len: the single-cut-off methods skip queries with
         fewer than k documents (ranker.py:41-42) — per batch for the reference's loaders, per query for padded batches."""
@@ -63,7 +68,7 @@ class DeviceEvaluator:
             batch_preds = self.predict(self._to_dev(batch_q_doc_vectors))
             self._batch_lens = None
             out = F_.metrics_at_ks(batch_preds.detach(), self._to_dev(batch_std_labels).float(), ks, presort=presort,
-                                   max_label=max_label, which=which, lens=lens_d)
+                                   max_label=max_label, which=which, lens=lens_d, permutation_labels=permutation_labels)
             if sums is None:
                 sums = {m: torch.zeros(len(ks), device=batch_preds.device) for m in which}
             if min_len is not None and lens_d is not None:
@@ -100,16 +105,16 @@ class DeviceEvaluator:
         return avg, per_q
 
     def ndcg_at_k(self, test_data=None, k=10, label_type=LABEL_TYPE.MultiLabel, presort=False, device='cpu'):
-        """ranker.py:31-65"""
-        if not is_multilabel(label_type):
+        """ranker.py:31-65; LABEL_TYPE.Permutation uses the label itself as gain (adhoc_metric.py:207-212)"""
+        if not (is_multilabel(label_type) or is_permutation(label_type)):
             raise NotImplementedError
-        return self._run_eval(test_data, [k], presort, ("ndcg",), min_len=k)[0]["ndcg"]
+        return self._run_eval(test_data, [k], presort, ("ndcg",), min_len=k, permutation_labels=is_permutation(label_type))[0]["ndcg"]
 
     def ndcg_at_ks(self, test_data=None, ks=[1, 5, 10], label_type=LABEL_TYPE.MultiLabel, presort=False, device='cpu'):
         """ranker.py:67-95"""
-        if not is_multilabel(label_type):
+        if not (is_multilabel(label_type) or is_permutation(label_type)):
             raise NotImplementedError
-        return self._run_eval(test_data, ks, presort, ("ndcg",))[0]["ndcg"]
+        return self._run_eval(test_data, ks, presort, ("ndcg",), permutation_labels=is_permutation(label_type))[0]["ndcg"]
 
     def nerr_at_k(self, test_data=None, k=10, label_type=LABEL_TYPE.MultiLabel, max_label=None, presort=False, device='cpu'):
         """ranker.py:97-128"""

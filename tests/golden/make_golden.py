@@ -256,6 +256,20 @@ def gen_siblings():
             loss, grad = run_loss(LambdaLoss(sf_para_dict=SF, model_para_dict=mpd, device="cpu"), preds, labels)
             add(store, f"lambdaloss1/c{ci}_k{k}", preds=preds, labels=labels, sigma=np.float32(1.0), k=np.int32(k), loss=loss,
                 grad=grad, sort_idx=pred_sort_idx(preds))
+    # nDCG with LABEL_TYPE.Permutation (labels = n - rank position, the MSLETOR "list" collections, data_utils.py:520-523):
+    # the label itself is the gain (adhoc_metric.py:207-212,225-230)
+    from ptranking.metric.adhoc.adhoc_metric import torch_ndcg_at_ks as _ndcg_ks, torch_ndcg_at_k as _ndcg_k
+    for ci, (B, L) in enumerate([(3, 8), (2, 40), (2, 130)]):
+        preds = rng.standard_normal((B, L)).astype(np.float32)
+        labels = np.stack([rng.permutation(L) + 1 for _ in range(B)]).astype(np.float32)
+        tp, tl = torch.from_numpy(preds), torch.from_numpy(labels)
+        _, idx = torch.sort(tp, dim=1, descending=True)
+        sys_sorted = torch.gather(tl, 1, idx)
+        ideal = torch.sort(tl, dim=1, descending=True)[0]
+        ks = [1, 3, 5, 10, 20, 50]
+        add(store, f"permndcg/c{ci}", preds=preds, labels=labels, ks=np.asarray(ks, np.int32),
+            ndcg=_ndcg_ks(sys_sorted, ideal, ks=ks, label_type=LABEL_TYPE.Permutation).numpy().astype(np.float32),
+            ndcg_k=_ndcg_k(sys_sorted, ideal, k=min(5, L), label_type=LABEL_TYPE.Permutation).numpy().astype(np.float32))
     zp = np.zeros((2, 5), np.float32)                                  # zero score vector: CosineSimilarity's eps path
     zl = np.array([[2, 1, 1, 0, 0], [1, 0, 0, 0, 0]], np.float32)
     loss, grad = run_loss(RankCosine(sf_para_dict=SF, device="cpu"), zp, zl)

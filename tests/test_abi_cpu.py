@@ -71,8 +71,12 @@ def test_argument_errors_need_no_gpu(lib_path):
     rc = lib.ptr_approxndcg_fwd_bwd(one, one, None, 1, 8, ctypes.c_float(-1.0), 1, 1, ctypes.c_float(0.0), one, one, one, one, one, None)
     assert rc == 1001 and b"alpha" in lib.ptr_last_error()
     ks = (ctypes.c_int32 * 40)(*range(1, 41))
-    rc = lib.ptr_metrics_at_ks(one, one, None, 1, 8, ks, 40, 1, ctypes.c_float(4.0), None, one, None, None, None, None)
+    rc = lib.ptr_metrics_at_ks(one, one, None, 1, 8, ks, 40, 1, 0, ctypes.c_float(4.0), None, one, None, None, None, None)
     assert rc == 1002
+    rc = lib.ptr_metrics_at_ks(one, one, None, 1, 8, ks, 3, 1, 1, ctypes.c_float(4.0), None, one, one, None, None, None)
+    assert rc == 1002 and b"nERR" in lib.ptr_last_error()          # nERR is undefined for LABEL_TYPE.Permutation
+    rc = lib.ptr_metrics_at_ks(one, one, None, 1, 8, ks, 3, 1, 7, ctypes.c_float(4.0), None, one, None, None, None, None)
+    assert rc == 1001 and b"label_type" in lib.ptr_last_error()
 
 
 def test_product_path_fails_loudly_on_cpu_tensors():

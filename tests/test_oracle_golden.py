@@ -241,3 +241,17 @@ def test_lambdaloss1_oracles(name):
     G.assert_close(loss.numpy(), c["loss"], "torch loss"); G.assert_close(grad.numpy(), c["grad"], "torch grad")
     lq, g = CO.lambdaloss(c["preds"], c["labels"], k=int(c["k"]), sigma=float(c["sigma"]), loss_type=0)
     G.assert_close(lq.astype(np.float64).sum(), c["loss"], "C loss"); G.assert_close(g, c["grad"], "C grad")
+
+
+@pytest.mark.parametrize("name", G.case_ids("permndcg", "siblings"))
+def test_ndcg_with_permutation_labels_oracles(name):
+    """LABEL_TYPE.Permutation: nDCG's gain is the label itself (adhoc_metric.py:207-212,225-230)."""
+    c = G.siblings()["permndcg"][name]
+    tp, tl = _t(c["preds"]), _t(c["labels"])
+    _, idx = torch.sort(tp, dim=1, descending=True)
+    sys_sorted = torch.gather(tl, 1, idx)
+    ideal = torch.sort(tl, dim=1, descending=True)[0]
+    ks = [int(k) for k in c["ks"]]
+    G.assert_close(T.ndcg_at_ks(sys_sorted, ideal, ks, permutation_labels=True).numpy(), c["ndcg"], "torch ndcg")
+    out = CO.metrics_at_ks(c["preds"], c["labels"], ks, presort=False, max_label=1.0, permutation_labels=True)
+    G.assert_close(out["ndcg"], c["ndcg"], "C ndcg")

@@ -101,3 +101,24 @@ def test_sibling_rankers_train():
         before = r.point_sf.flat.detach().clone()
         loss, stop = r.train_op(X, Y, epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
         assert torch.isfinite(loss) and not stop and not torch.equal(before, r.point_sf.flat), name
+
+
+@pytest.mark.parametrize("name", G.case_ids("permndcg", "siblings"))
+def test_golden_ndcg_permutation_labels(F, name):
+    """nDCG with LABEL_TYPE.Permutation (gain = label) through the metric kernel and the Evaluator surface."""
+    import ptranking_amd as pa
+    c = G.siblings()["permndcg"][name]
+    ks = [int(k) for k in c["ks"]]
+    out = F.metrics_at_ks(dev(c["preds"]), dev(c["labels"]), ks, presort=False, which=("ndcg", "ap", "p"), permutation_labels=True)
+    G.assert_close(out["ndcg"].cpu().numpy(), c["ndcg"], "ndcg")
+    with pytest.raises(NotImplementedError):
+        F.metrics_at_ks(dev(c["preds"]), dev(c["labels"]), ks, presort=False, permutation_labels=True)     # nERR undefined
+
+    class Fixed(pa.host.DeviceEvaluator):
+        device = "cuda:0"
+        def eval_mode(self): pass
+        def predict(self, X): return X[:, :, 0]
+    ev = Fixed()
+    X = dev(c["preds"]).unsqueeze(2).contiguous()
+    got = ev.ndcg_at_ks(test_data=[(list(range(X.size(0))), X, dev(c["labels"]))], ks=ks, label_type=pa.LABEL_TYPE.Permutation, presort=False)
+    G.assert_close(got.numpy(), c["ndcg"].mean(axis=0), "Evaluator.ndcg_at_ks")
