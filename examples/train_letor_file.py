@@ -29,7 +29,9 @@ def main():
     ap.add_argument("--scaler", default=None, choices=[None, "StandardScaler", "MinMaxScaler", "RobustScaler", "SLog1P"])
     ap.add_argument("--rough-batch-size", type=int, default=262144, help="documents (incl. padding) per batch")
     ap.add_argument("--min-docs", type=int, default=10)
+    ap.add_argument("--seed", type=int, default=137, help="torch seed: initial weights and dropout streams (ltr_global.py:7)")
     args = ap.parse_args()
+    torch.manual_seed(args.seed)
     if not torch.cuda.is_available():
         raise SystemExit("needs an MI355X: ptranking_amd has no CPU fallback")
     dev = "cuda:0"
