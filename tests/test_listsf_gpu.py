@@ -142,9 +142,9 @@ def test_c5_ranker_trains(LS):
     listsf = dict(num_features=136, ff_dims=[128, 256, 512], AF='R', TL_AF='GE', apply_tl_af=False, BN=False, bn_type='BN2',
                   bn_affine=False, n_heads=2, encoder_layers=6, encoder_type='DASALC')
     sf = dict(sf_id='listsf', opt='Adagrad', lr=0.001, listsf=listsf)
+    torch.manual_seed(3)
     r = pa.LambdaLoss(sf_para_dict=copy.deepcopy(sf), model_para_dict=dict(pa.DEFAULT_PARAS["LambdaLoss"]), gpu=True, device=DEV)
     r.init(); r.train_mode()
-    torch.manual_seed(3)
     X = torch.randn(8, 256, 136, device=DEV)
     Y = torch.sort(torch.randint(0, 5, (8, 256), device=DEV).float(), dim=1, descending=True)[0].contiguous()
     before = [p.detach().clone() for p in r.get_parameters()]
@@ -218,9 +218,9 @@ def test_dasalc_ranker_trains(LS):
     listsf = dict(num_features=24, ff_dims=[16, 32], AF='R', TL_AF='GE', apply_tl_af=False, BN=False, bn_type='BN2', bn_affine=False,
                   n_heads=2, encoder_layers=2, encoder_type='DASALC')
     sf = dict(sf_id='listsf', opt='Adagrad', lr=0.01, listsf=listsf)
+    torch.manual_seed(4)
     r = pa.DASALC(sf_para_dict=copy.deepcopy(sf), gpu=True, device=DEV)
     r.init(); r.train_mode()
-    torch.manual_seed(4)
     X = torch.randn(16, 40, 24, device=DEV)
     Y = torch.sort(torch.randint(0, 5, (16, 40), device=DEV).float(), dim=1, descending=True)[0].contiguous()
     losses = [float(r.train_op(X, Y, epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)[0]) for _ in range(30)]
