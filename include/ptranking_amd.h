@@ -109,6 +109,13 @@ int ptr_rankcosine_fwd_bwd(const float *preds, const float *labels, const int32_
 int ptr_listmle_fwd_bwd(const float *preds, const int64_t *perm, const int32_t *lens, int B, int L, float *loss_out,
                         float *loss_q, float *grad, void *stream);
 
+/* MDPRank — replaces ptranking/ltr_adhoc/listwise/mdprank.py:46-75 and its backward: ListMLE on a SAMPLED ranking `perm`
+ * (int64[B,L], drawn by the caller from the Plackett-Luce model, sampling_utils.py:32-83) whose first top_k positions are
+ * weighted with the discounted long-term return G_t = gamma^(t+1) * sum_{t'=t}^{top_k-1} (2^l - 1)/log2(2 + t').
+ * top_k <= 0: the whole list (top_k=None).  The reference only accepts batch size 1; here every query is independent. */
+int ptr_mdprank_fwd_bwd(const float *preds, const float *labels, const int64_t *perm, const int32_t *lens, int B, int L, int top_k,
+                        float gamma, float *loss_out, float *loss_q, float *grad, void *stream);
+
 /* Device tie-shuffled label-descending order (the role of arg_shuffle_ties, sampling_utils.py:13-28) from a
  * counter-based RNG: same distribution, NOT the torch.randperm stream (not parity-checked, statistically tested). */
 int ptr_shuffle_ties_order(const float *labels, const int32_t *lens, int B, int L, uint64_t seed, int64_t *perm,

@@ -120,6 +120,15 @@ def listmle(preds, perm, lens=None):
     return loss_q, grad
 
 
+def mdprank(preds, labels, perm, top_k=10, gamma=1.0, lens=None):
+    preds, labels = _f(preds), _f(labels); B, L = preds.shape; lens = _lens(lens)
+    perm = np.ascontiguousarray(perm, dtype=np.int64)
+    loss_q = np.empty(B, np.float32); grad = np.empty((B, L), np.float32)
+    _chk(lib().orc_mdprank(_p(preds), _p(labels), _p(perm, _i64p), _p(lens, _i32p), B, L, C.c_int(int(top_k) if top_k else 0),
+                           C.c_float(gamma), _p(loss_q), _p(grad)), "mdprank")
+    return loss_q, grad
+
+
 def metrics_at_ks(preds, labels, ks, presort, max_label=None, lens=None, permutation_labels=False):
     """-> dict(ndcg, nerr, ap, p) of [B, len(ks)] float32."""
     preds, labels = _f(preds), _f(labels); B, L = preds.shape; lens = _lens(lens)

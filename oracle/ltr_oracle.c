@@ -267,6 +267,43 @@ int orc_softrank(const float *preds, const float *labels, const int32_t *lens, i
     return ORC_OK;
 }
 
+/* MDPRank — ptranking/ltr_adhoc/listwise/mdprank.py:46-75 on a given sampled ranking perm (first len_q entries of row q).
+ * G_t = gamma^(t+1) * sum_{t'=t}^{top-1} (2^l - 1)/log2(2 + t'); loss_q = sum_{t<top} G_t*(log sum_{j>=t} exp(u_j) - u_t);
+ * dL/du_j = e^{u_j - m} * sum_{i <= min(j, top-1)} G_i/T_i - (j < top ? G_j : 0). */
+int orc_mdprank(const float *preds, const float *labels, const int64_t *perm, const int32_t *lens, int B, int L, int top_k, float gamma,
+                float *loss_q, float *grad) {
+    size_t Ls = (size_t)(L > 0 ? L : 1);
+    double *T = (double *)malloc(sizeof(double) * Ls * 2);
+    if (!T) return ORC_ENOMEM;
+    double *W = T + Ls;
+    for (int q = 0; q < B; ++q) {
+        const float *s = preds + (size_t)q * L, *y = labels + (size_t)q * L;
+        const int64_t *p = perm + (size_t)q * L;
+        float *g = grad + (size_t)q * L;
+        int n = qlen(lens, q, L);
+        memset(g, 0, sizeof(float) * (size_t)L);
+        int top = (top_k <= 0 || top_k > n) ? n : top_k;
+        float m = -INFINITY;
+        for (int k = 0; k < n; ++k) if (s[p[k]] > m) m = s[p[k]];
+        double tail = 0.0, rtail = 0.0, loss = 0.0;
+        for (int k = n - 1; k >= 0; --k) {
+            tail += (double)expf(s[p[k]] - m);
+            T[k] = tail;
+            if (k < top) rtail += (double)(gain(y[p[k]]) / log2f(2.0f + (float)k));
+            W[k] = k < top ? (double)((float)rtail * (gamma == 1.0f ? 1.0f : powf(gamma, (float)(k + 1)))) : 0.0;
+            if (k < top) loss += W[k] * (double)((logf((float)T[k]) + m) - s[p[k]]);
+        }
+        double pre = 0.0;
+        for (int k = 0; k < n; ++k) {
+            pre += W[k] / T[k];
+            g[p[k]] = (float)((double)expf(s[p[k]] - m) * pre - W[k]);
+        }
+        loss_q[q] = (float)loss;
+    }
+    free(T);
+    return ORC_OK;
+}
+
 /* Robust_Sigmoid forward — ptranking/base/utils.py:57-81. */
 static inline float robust_sigmoid(float x_in, float sigma) {
     float x = sigma * x_in;

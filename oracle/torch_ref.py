@@ -196,6 +196,25 @@ def rankcosine_loss(preds, labels):
     return torch.sum((1.0 - torch.nn.CosineSimilarity(dim=1)(preds, labels)) / 0.5)
 
 
+def mdprank_loss(preds, labels, perm, top_k=10, gamma=1.0):
+    """ptranking/ltr_adhoc/listwise/mdprank.py:46-75 on a given sampled ranking `perm` (int64 [B, L]); `preds` = action scores by
+    original document index.  Restated per query (the reference asserts batch size 1)."""
+    B, L = preds.shape
+    top = L if not top_k else min(int(top_k), L)
+    u = torch.gather(preds, 1, perm)
+    stds = torch.gather(labels, 1, perm)
+    gains = torch.pow(2.0, stds) - 1.0
+    disc = torch.log2(2.0 + torch.arange(top, dtype=torch.float32)).view(1, -1)
+    rewards = gains[:, :top] / disc
+    G = torch.flip(torch.cumsum(torch.flip(rewards, dims=[1]), dim=1), dims=[1])
+    if gamma != 1.0:
+        G = G * torch.cumprod(torch.ones(top).view(1, -1) * gamma, dim=1)
+    m, _ = torch.max(u, dim=1, keepdim=True)
+    y = torch.exp(u - m)
+    lcse = torch.log(torch.flip(torch.cumsum(torch.flip(y, dims=[1]), dim=1), dims=[1])) + m
+    return torch.sum(torch.sum((lcse[:, :top] - u[:, :top]) * G[:, :top], dim=1))
+
+
 def arg_shuffle_ties(labels, generator=None):
     """Random tie-broken descending order; ptranking/ltr_adhoc/util/sampling_utils.py:13-28."""
     B, L = labels.shape

@@ -27,6 +27,7 @@ SIGNATURES = {
     "ptr_approxndcg_fwd_bwd": [_vp, _vp, _vp, _i, _i, _f, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp],
     "ptr_softrank_fwd_bwd": [_vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp],
     "ptr_listnet_fwd_bwd": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
+    "ptr_mdprank_fwd_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
     "ptr_listmle_fwd_bwd": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
     "ptr_stlistnet_fwd_bwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp],
     "ptr_rankmse_fwd_bwd": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],

@@ -128,6 +128,81 @@ listmle_kernel(const float *__restrict__ preds, const int64_t *__restrict__ perm
     if (lane == 0) loss_q[q] = loss;
 }
 
+// MDPRank (ptranking/ltr_adhoc/listwise/mdprank.py:24-78): a policy-gradient ListMLE.  pi is a ranking SAMPLED from the
+// Plackett-Luce model (the host draws it), u = scores in sampled order, and the first top_k positions are weighted with the
+// discounted long-term return of the episode:
+//   reward_t = (2^{l_pi(t)} - 1) / log2(2 + t)  (t < top_k),   G_t = gamma^{t+1} * sum_{t' = t}^{top_k - 1} reward_t'
+//   loss = sum_{t < top_k} G_t * ( log sum_{j >= t} exp(u_j) - u_t )
+// Gradient: dL/du_j = e^{u_j - m} * sum_{i <= min(j, top_k-1)} G_i / T_i  -  (j < top_k ? G_j : 0).
+// One wavefront per query, same scans as listmle_kernel plus a suffix scan of the rewards.
+// LDS per query: s[Lp] | T[Lp] | E[Lp] | W[Lp] | pi[Lp]
+__global__ void __launch_bounds__(kBlock)
+mdprank_kernel(const float *__restrict__ preds, const float *__restrict__ labels, const int64_t *__restrict__ perm,
+               const int32_t *__restrict__ lens, int B, int L, int Lp, int top_k, float gamma, float *__restrict__ loss_q,
+               float *__restrict__ grad) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    const int q = blockIdx.x * wpb + wv;
+    if (q >= B) return;
+    const int n = query_len(lens, q, L);
+    float *s = smem + (size_t)wv * 5 * Lp;
+    float *T = s + Lp, *E = T + Lp, *W = E + Lp;
+    int *pi = reinterpret_cast<int *>(W + Lp);
+    const float *ps = preds + (size_t)q * L, *ys = labels + (size_t)q * L;
+    const int64_t *pp = perm + (size_t)q * L;
+    const int top = (top_k <= 0 || top_k > n) ? n : top_k;       // top_k=None -> the whole list (mdprank.py:46)
+
+    float m = -INFINITY;
+    for (int i = lane; i < n; i += 64) {
+        const float a = ps[i];
+        s[i] = a;
+        m = fmaxf(m, a);
+        long long k = pp[i];
+        pi[i] = (k < 0 || k >= n) ? i : (int)k;
+    }
+    m = wave_max(m);                                             // mdprank.py:65
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    const int nchunk = (n + 63) >> 6;
+    float carry = 0.0f, rcarry = 0.0f, loss = 0.0f;
+    for (int c = nchunk - 1; c >= 0; --c) {                      // both tail sums, chunk by chunk from the tail
+        const int k = c * 64 + lane;
+        const bool in = k < n;
+        const int src = in ? pi[k] : 0;
+        const float u = in ? s[src] : 0.0f;
+        const float e = in ? expf(u - m) : 0.0f;
+        const float r = (in && k < top) ? gain_of(ys[src]) / log2f(2.0f + (float)k) : 0.0f;     // mdprank.py:53-56
+        const float Tk = wave_incl_suffix_sum(e, lane) + carry;
+        const float Rk = wave_incl_suffix_sum(r, lane) + rcarry;                                // :59
+        carry = __shfl(Tk, 0, 64);
+        rcarry = __shfl(Rk, 0, 64);
+        if (in) {
+            const float w = k < top ? Rk * (gamma == 1.0f ? 1.0f : powf(gamma, (float)(k + 1))) : 0.0f;   // :61-63
+            T[k] = Tk; E[k] = e; W[k] = w;
+            loss += w * ((logf(Tk) + m) - u);                                                   // :68-70
+        }
+    }
+    loss = wave_sum(loss);
+    __builtin_amdgcn_wave_barrier();
+    float pc = 0.0f;
+    for (int c = 0; c < nchunk; ++c) {
+        const int k = c * 64 + lane;
+        const bool in = k < n;
+        const float term = in ? W[k] / T[k] : 0.0f;
+        const float P = wave_incl_sum(term, lane) + pc;
+        pc = __shfl(P, 63, 64);
+        if (in) s[pi[k]] = E[k] * P - W[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    float *g = grad + (size_t)q * L;
+    for (int i = lane; i < L; i += 64) g[i] = i < n ? s[i] : 0.0f;
+    if (lane == 0) loss_q[q] = loss;
+}
+
 // ------------------------------------------------------------------------------------------------ RankMSE / RankCosine
 // RankMSE (ptranking/ltr_adhoc/pointwise/rank_mse.py:13-22): mean over queries of sum_i (s_i - y_i)^2.  loss_q holds the
 // per-query sums; the caller's reduction applies 1/B, the gradient 2 (s - y) / B is written here.
@@ -342,6 +417,25 @@ extern "C" int ptr_listmle_fwd_bwd(const float *preds, const int64_t *perm, cons
         if (int e = allow_lds(listmle_kernel, wpb * per_q)) return e;
         hipLaunchKernelGGL(listmle_kernel, dim3((B + wpb - 1) / wpb), dim3(wpb * kWave), wpb * per_q, as_stream(stream), preds, perm,
                            lens, B, L, Lp, loss_q, grad);
+        if (int rc = check_hip(hipGetLastError(), who)) return rc;
+    }
+    return loss_out ? ptr_sum_f32(loss_q, B, 1.0f, loss_out, stream) : 0;
+}
+
+extern "C" int ptr_mdprank_fwd_bwd(const float *preds, const float *labels, const int64_t *perm, const int32_t *lens, int B, int L,
+                                   int top_k, float gamma, float *loss_out, float *loss_q, float *grad, void *stream) {
+    using namespace ptr;
+    const char *who = "ptr_mdprank_fwd_bwd";
+    if (int rc = check_batch(preds, perm, B, L, who)) return rc;
+    if (B > 0 && (!labels || !loss_q || !grad)) { set_error("%s: NULL pointer", who); return PTR_ERR_INVALID_ARG; }
+    if (!(gamma > 0.0f)) { set_error("%s: gamma must be > 0 (got %g)", who, (double)gamma); return PTR_ERR_INVALID_ARG; }
+    if (B > 0) {
+        const int Lp = round_up(L, 4);
+        const size_t per_q = 5 * (size_t)Lp * sizeof(float);
+        const int wpb = waves_per_block(per_q);
+        if (int e = allow_lds(mdprank_kernel, wpb * per_q)) return e;
+        hipLaunchKernelGGL(mdprank_kernel, dim3((B + wpb - 1) / wpb), dim3(wpb * kWave), wpb * per_q, as_stream(stream), preds, labels,
+                           perm, lens, B, L, Lp, top_k, gamma, loss_q, grad);
         if (int rc = check_hip(hipGetLastError(), who)) return rc;
     }
     return loss_out ? ptr_sum_f32(loss_q, B, 1.0f, loss_out, stream) : 0;

@@ -14,7 +14,7 @@ from . import _lib
 
 __all__ = ["ranknet_loss", "lambdarank_loss", "lambdaloss_loss", "approxndcg_loss", "listnet_loss", "listmle_loss",
            "stlistnet_loss", "rankmse_loss", "rankcosine_loss",
-           "softrank_loss", "shuffle_ties_order", "sort_desc", "metrics_at_ks", "sum_f32", "LAMBDALOSS_TYPES"]
+           "softrank_loss", "mdprank_loss", "shuffle_ties_order", "sort_desc", "metrics_at_ks", "sum_f32", "LAMBDALOSS_TYPES"]
 
 LAMBDALOSS_TYPES = {"NDCG_Loss1": 0, "NDCG_Loss2": 1, "NDCG_Loss2++": 2}   # ptranking/ltr_adhoc/listwise/lambdaloss.py:27
 
@@ -173,6 +173,27 @@ def listmle_loss(preds, perm, lens=None):
         with torch.cuda.device(dev):
             _lib.call("ptr_listmle_fwd_bwd", _lib.ptr(p), _lib.ptr(perm), _lib.ptr(lens), B, L, None, _lib.ptr(loss_q),
                       _lib.ptr(grad), _lib.current_stream(dev))
+            return _reduce(loss_q, B, dev), grad
+
+    if preds.requires_grad:
+        return _FusedLoss.apply(preds if preds.is_contiguous() else preds.contiguous(), lambda p: launch(p.detach()))
+    return launch(preds_c)[0]
+
+
+def mdprank_loss(preds, labels, perm, top_k=10, gamma=1.0, lens=None):
+    """MDPRank, ptranking/ltr_adhoc/listwise/mdprank.py:46-75: return-weighted ListMLE on the sampled ranking `perm` (int64 [B,L]).
+    `preds` are the action scores by ORIGINAL document index (for 'STPL' the caller passes (preds + gumbel) / temperature)."""
+    preds_c, perm, lens, B, L = _batch(preds.detach(), perm, lens, torch.int64, "perm")
+    labels = _check("labels", labels, shape=(B, L)).contiguous()
+    dev = preds_c.device
+
+    def launch(p):
+        loss_q = torch.empty(max(B, 1), device=dev, dtype=torch.float32)
+        grad = torch.empty((B, L), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.call("ptr_mdprank_fwd_bwd", _lib.ptr(p), _lib.ptr(labels), _lib.ptr(perm), _lib.ptr(lens), B, L,
+                      int(top_k) if top_k else 0, C.c_float(float(gamma)), None, _lib.ptr(loss_q), _lib.ptr(grad),
+                      _lib.current_stream(dev))
             return _reduce(loss_q, B, dev), grad
 
     if preds.requires_grad:

@@ -17,7 +17,7 @@ from .host import DeviceEvaluator, DeviceTrainLoop, PointScorerRanker, is_multil
 from .listsf import FusedListScorerMixin
 from .scorer import FusedScorerMixin
 
-RANKER_NAMES = ("RankNet", "LambdaRank", "LambdaLoss", "ApproxNDCG", "ListNet", "ListMLE", "STListNet", "RankCosine", "RankMSE", "SoftRank", "DASALC")
+RANKER_NAMES = ("RankNet", "LambdaRank", "LambdaLoss", "ApproxNDCG", "ListNet", "ListMLE", "STListNet", "RankCosine", "RankMSE", "SoftRank", "DASALC", "MDPRank")
 
 # default hyper-parameters = the reference's `default_para_dict()`s
 DEFAULT_PARAS = {
@@ -32,6 +32,7 @@ DEFAULT_PARAS = {
     "RankMSE": dict(model_id="RankMSE"),
     "SoftRank": dict(model_id="SoftRank", delta=2.0, metric='nDCG', top_k=None),       # listwise/softrank.py:97
     "DASALC": dict(model_id="DASALC"),
+    "MDPRank": dict(model_id="MDPRank", temperature=1.0, gamma=1.0, top_k=10, distribution='PL'),   # listwise/mdprank.py:95-96
 }
 
 
@@ -137,6 +138,37 @@ class SoftRankLoss(FusedStepMixin):
         assert is_multilabel(kwargs['label_type'])
         return self._fused_step(F_.softrank_loss(batch_preds, batch_std_labels, delta=self.delta_value, top_k=self.top_k,
                                                  lens=kwargs.get('lens')))
+
+
+class MDPRankLoss(FusedStepMixin):
+    def custom_loss_function(self, batch_preds, batch_std_labels, **kwargs):
+        """ptranking/ltr_adhoc/listwise/mdprank.py:24-78.  The reference asserts batch size 1 ("aiming for meaningful
+        batch-normalization"); every query is an independent episode here, so any batch size works and B = 1 reproduces it."""
+        assert 'presort' in kwargs and kwargs['presort'] is True  # aiming for direct usage of ideal ranking
+        lens = kwargs.get('lens')
+        with torch.no_grad():
+            det = batch_preds.detach()
+            if lens is not None:      # padded documents must be sampled last: they get (numerically) zero probability mass
+                pad = torch.arange(det.size(1), device=det.device)[None, :] >= lens[:, None].to(det.device)
+                det = det.masked_fill(pad, -1e30)
+            if 'PL' == self.distribution:           # sampling_utils.py:32-58 (torch.multinomial without replacement)
+                t = det / self.temperature if 1.0 != self.temperature else det
+                probs = torch.exp(t - torch.max(t, dim=1, keepdim=True)[0]).clamp_min(1e-38)
+                perm = torch.multinomial(probs, num_samples=det.size(1), replacement=False)
+                noise = None
+            elif 'STPL' == self.distribution:       # sampling_utils.py:61-83 (Gumbel perturbation, then sort)
+                unif = torch.rand(det.size(), device=det.device)
+                noise = -torch.log(-torch.log(unif + 1e-20) + 1e-20)
+                logits = det + noise if 1.0 == self.temperature else (det + noise) / self.temperature
+                perm = torch.sort(logits, dim=1, descending=True)[1]
+            else:
+                raise NotImplementedError
+        if noise is None:
+            action_preds = batch_preds                                   # gathered in sample order inside the kernel
+        else:
+            action_preds = batch_preds + noise if 1.0 == self.temperature else (batch_preds + noise) / self.temperature
+        loss = F_.mdprank_loss(action_preds, batch_std_labels, perm, top_k=self.top_k, gamma=self.gamma, lens=lens)
+        return self._fused_step(loss)
 
 
 class ListNetLoss(FusedStepMixin):
@@ -256,8 +288,17 @@ def make_ranker_classes(base=PointScorerRanker):
             base.__init__(self, id='DASALC', sf_para_dict=sf_para_dict, gpu=gpu, device=device)
             assert 'listsf' == sf_para_dict['sf_id']
 
+    class MDPRank(MDPRankLoss, FusedScorerMixin, FusedListScorerMixin, DeviceTrainLoop, DeviceEvaluator, base):
+        def __init__(self, sf_para_dict=None, model_para_dict=None, gpu=False, device=None):
+            base.__init__(self, id='MDPRank', sf_para_dict=sf_para_dict, gpu=gpu, device=device)
+            self.gamma = model_para_dict['gamma']
+            self.top_k = model_para_dict['top_k']
+            self.temperature = model_para_dict['temperature']
+            self.distribution = model_para_dict['distribution']  # 'PL', 'STPL'
+            self.pg_checking = False
+
     out = dict(RankNet=RankNet, LambdaRank=LambdaRank, LambdaLoss=LambdaLoss, ApproxNDCG=ApproxNDCG, ListNet=ListNet,
-               ListMLE=ListMLE, STListNet=STListNet, RankCosine=RankCosine, RankMSE=RankMSE, SoftRank=SoftRank, DASALC=DASALC)
+               ListMLE=ListMLE, STListNet=STListNet, RankCosine=RankCosine, RankMSE=RankMSE, SoftRank=SoftRank, DASALC=DASALC, MDPRank=MDPRank)
     for name, cls in out.items():
         cls.__name__ = cls.__qualname__ = name
         cls.__module__ = __name__
@@ -268,4 +309,4 @@ _standalone = make_ranker_classes(PointScorerRanker)
 RankNet, LambdaRank, LambdaLoss = _standalone["RankNet"], _standalone["LambdaRank"], _standalone["LambdaLoss"]
 ApproxNDCG, ListNet, ListMLE = _standalone["ApproxNDCG"], _standalone["ListNet"], _standalone["ListMLE"]
 STListNet, RankCosine, RankMSE = _standalone["STListNet"], _standalone["RankCosine"], _standalone["RankMSE"]
-SoftRank, DASALC = _standalone["SoftRank"], _standalone["DASALC"]
+SoftRank, DASALC, MDPRank = _standalone["SoftRank"], _standalone["DASALC"], _standalone["MDPRank"]

@@ -270,6 +270,28 @@ def gen_siblings():
         add(store, f"permndcg/c{ci}", preds=preds, labels=labels, ks=np.asarray(ks, np.int32),
             ndcg=_ndcg_ks(sys_sorted, ideal, ks=ks, label_type=LABEL_TYPE.Permutation).numpy().astype(np.float32),
             ndcg_k=_ndcg_k(sys_sorted, ideal, k=min(5, L), label_type=LABEL_TYPE.Permutation).numpy().astype(np.float32))
+    # MDPRank (mdprank.py:24-78; the reference only accepts batch size 1): the sampled ranking is captured by wrapping the
+    # module-level sampling function, the fixture stores it next to the loss / gradient
+    import ptranking.ltr_adhoc.listwise.mdprank as _mdp
+    for ci, L in enumerate([12, 40, 150]):
+        preds, labels = synth(rng, 1, L)
+        for top_k, gamma in ((10, 1.0), (None, 0.9)):
+            captured = {}
+            orig = _mdp.sample_ranking_PL
+
+            def spy(*a, **k):
+                out = orig(*a, **k)
+                captured["perm"] = out[0].numpy().astype(np.int64).copy()
+                return out
+
+            _mdp.sample_ranking_PL = spy
+            try:
+                mpd = dict(gamma=gamma, top_k=top_k, temperature=1.0, distribution='PL')
+                loss, grad = run_loss(_mdp.MDPRank(sf_para_dict=SF, model_para_dict=mpd, device="cpu"), preds, labels)
+            finally:
+                _mdp.sample_ranking_PL = orig
+            add(store, f"mdprank/c{ci}_k{top_k or 0}", preds=preds, labels=labels, perm=captured["perm"], top_k=np.int32(top_k or 0),
+                gamma=np.float32(gamma), loss=loss, grad=grad)
     zp = np.zeros((2, 5), np.float32)                                  # zero score vector: CosineSimilarity's eps path
     zl = np.array([[2, 1, 1, 0, 0], [1, 0, 0, 0, 0]], np.float32)
     loss, grad = run_loss(RankCosine(sf_para_dict=SF, device="cpu"), zp, zl)

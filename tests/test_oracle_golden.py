@@ -255,3 +255,15 @@ def test_ndcg_with_permutation_labels_oracles(name):
     G.assert_close(T.ndcg_at_ks(sys_sorted, ideal, ks, permutation_labels=True).numpy(), c["ndcg"], "torch ndcg")
     out = CO.metrics_at_ks(c["preds"], c["labels"], ks, presort=False, max_label=1.0, permutation_labels=True)
     G.assert_close(out["ndcg"], c["ndcg"], "C ndcg")
+
+
+@pytest.mark.parametrize("name", G.case_ids("mdprank", "siblings"))
+def test_mdprank_oracles(name):
+    """MDPRank (mdprank.py:46-75) on the ranking the reference sampled (captured in the fixture)."""
+    c = G.siblings()["mdprank"][name]
+    tk = int(c["top_k"]) or None
+    perm = torch.from_numpy(c["perm"])
+    loss, grad = T.loss_and_grad(lambda p, y: T.mdprank_loss(p, y, perm, top_k=tk, gamma=float(c["gamma"])), _t(c["preds"]), _t(c["labels"]))
+    G.assert_close(loss.numpy(), c["loss"], "torch loss"); G.assert_close(grad.numpy(), c["grad"], "torch grad")
+    lq, g = CO.mdprank(c["preds"], c["labels"], c["perm"], top_k=tk, gamma=float(c["gamma"]))
+    G.assert_close(lq.astype(np.float64).sum(), c["loss"], "C loss"); G.assert_close(g, c["grad"], "C grad")

@@ -122,3 +122,46 @@ def test_golden_ndcg_permutation_labels(F, name):
     X = dev(c["preds"]).unsqueeze(2).contiguous()
     got = ev.ndcg_at_ks(test_data=[(list(range(X.size(0))), X, dev(c["labels"]))], ks=ks, label_type=pa.LABEL_TYPE.Permutation, presort=False)
     G.assert_close(got.numpy(), c["ndcg"].mean(axis=0), "Evaluator.ndcg_at_ks")
+
+
+@pytest.mark.parametrize("name", G.case_ids("mdprank", "siblings"))
+def test_golden_mdprank(F, name):
+    c = G.siblings()["mdprank"][name]
+    perm = torch.from_numpy(c["perm"]).cuda()
+    loss, grad = loss_and_grad(lambda p, y: F.mdprank_loss(p, y, perm, top_k=int(c["top_k"]) or None, gamma=float(c["gamma"])),
+                               c["preds"], dev(c["labels"]))
+    G.assert_close(loss, c["loss"], "loss"); G.assert_close(grad, c["grad"], "grad")
+
+
+@pytest.mark.parametrize("B,L", [(9, 7), (33, 128), (5, 700), (2, 4096)])
+@pytest.mark.parametrize("use_lens", [False, True])
+def test_oracle_mdprank(F, B, L, use_lens):
+    from oracle import c_oracle as CO
+    preds, labels, ln = synth(9000 + L, B, L, lens=use_lens)
+    rng = np.random.default_rng(L)
+    perm = np.stack([np.concatenate([rng.permutation(L if ln is None else int(ln[b])), np.arange(L if ln is None else int(ln[b]), L)])
+                     for b in range(B)]).astype(np.int64)
+    lens_t = None if ln is None else dev(ln)
+    for top_k, gamma in ((10, 1.0), (None, 0.95), (3, 0.5)):
+        loss, grad = loss_and_grad(lambda p, y: F.mdprank_loss(p, y, torch.from_numpy(perm).cuda(), top_k=top_k, gamma=gamma, lens=lens_t),
+                                   preds, dev(labels))
+        lq, g = CO.mdprank(preds, labels, perm, top_k=top_k, gamma=gamma, lens=ln)
+        G.assert_close(loss, lq.astype(np.float64).sum(), "loss"); G.assert_close(grad, g, "grad")
+
+
+@pytest.mark.parametrize("dist", ["PL", "STPL"])
+def test_mdprank_ranker_trains(dist):
+    import ptranking_amd as pa
+    sf = {"sf_id": "pointsf", "opt": "Adam", "lr": 1e-3,
+          "pointsf": dict(num_features=24, num_layers=3, AF="R", TL_AF="S", apply_tl_af=False, BN=False, bn_type=None, bn_affine=False)}
+    X = torch.randn(6, 40, 24, device="cuda")
+    Y = torch.sort(torch.randint(0, 5, (6, 40), device="cuda").float(), dim=1, descending=True)[0].contiguous()
+    paras = dict(pa.DEFAULT_PARAS["MDPRank"], distribution=dist, temperature=1.0 if dist == "PL" else 2.0)
+    r = pa.MDPRank(sf_para_dict=copy.deepcopy(sf), model_para_dict=paras, gpu=True, device="cuda:0")
+    r.init(); r.train_mode()
+    before = r.point_sf.flat.detach().clone()
+    lens = torch.tensor([40, 40, 17, 40, 3, 40], dtype=torch.int32, device="cuda")
+    for kw in ({}, {"lens": lens}):
+        loss, stop = r.train_op(X, Y, epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel, **kw)
+        assert torch.isfinite(loss) and not stop
+    assert not torch.equal(before, r.point_sf.flat)
