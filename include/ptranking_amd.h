@@ -151,10 +151,13 @@ int ptr_sum_f32(const float *x, int n, float scale, float *out, void *stream);
  * X is [R][F] row-major (R = B*L documents), preds [R].  train != 0: dropout p_drop from the counter-based generator
  * seeded by `seed`, and the post-dropout activations needed by backward are written to acts [NL][R][PTR_MLP_ACT_LD]
  * (rows padded to 112 floats = 7 aligned 64-byte sectors).
- * ptr_mlp_backward: dpreds [R] -> grad (every entry overwritten); dz [NL][R][PTR_MLP_ACT_LD] and ws (ptr_mlp_backward_ws_floats)
- * are caller-provided scratch; p_drop / seed must be the forward call's.  All calls are deterministic. */
+ * ptr_mlp_backward: dpreds [R] -> grad (every entry overwritten); ws (ptr_mlp_backward_ws_floats) and dz (ptr_mlp_backward_dz_floats
+ * floats: [NL][R][PTR_MLP_ACT_LD] for the layer-wise kernels, 0 => may be NULL when the single-pass fused backward serves the
+ * configuration — NL = 3, 129..144 features, F % 4 == 0) are caller-provided scratch; p_drop / seed must be the forward call's.
+ * All calls are deterministic. */
 size_t ptr_mlp_num_params(int F, int NL);
 size_t ptr_mlp_backward_ws_floats(int F, int NL);
+size_t ptr_mlp_backward_dz_floats(int R, int F, int NL);
 int ptr_mlp_forward(const float *X, const float *params, int R, int F, int NL, int train, float p_drop, uint64_t seed,
                     float *preds, float *acts, void *stream);
 int ptr_mlp_backward(const float *X, const float *params, const float *acts, const float *dpreds, int R, int F, int NL,

@@ -15,8 +15,8 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 OBJ_DIR = os.path.join(PKG_DIR, "csrc", "build")
 LIB_PATH = os.path.join(PKG_DIR, "libptranking_amd.so")
 ARCH = "gfx950"
-SOURCES = ["abi.hip", "pairwise.hip", "lambdaloss.hip", "approxndcg.hip", "listwise.hip", "metrics.hip", "scorer.hip", "listsf.hip", "letor.cpp"]
-HEADERS = ["ptr_device.h", "ptr_dropout.h", os.path.join("..", "..", "include", "ptranking_amd.h")]
+SOURCES = ["abi.hip", "pairwise.hip", "lambdaloss.hip", "approxndcg.hip", "listwise.hip", "metrics.hip", "scorer.hip", "scorer_bwd.hip", "listsf.hip", "letor.cpp"]
+HEADERS = ["ptr_device.h", "ptr_dropout.h", "ptr_mlp.h", os.path.join("..", "..", "include", "ptranking_amd.h")]
 CXXFLAGS = ["-O3", "-std=c++20", "-fPIC", "-fno-gpu-rdc", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
             "-ffp-contract=off"]
 
@@ -33,6 +33,28 @@ def _stale(target, deps):
         return True
     t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_variant(tag, defines, sources=("scorer_bwd.hip",), verbose=False):
+    """Experiment helper: libptranking_amd.<tag>.so = the current objects with `sources` recompiled under extra -D defines.
+    Selected at run time with PTR_LIB=<path> (see _lib.py).  Not used by the product path."""
+    hipcc = _hipcc()
+    build()
+    vdir = os.path.join(OBJ_DIR, tag)
+    os.makedirs(vdir, exist_ok=True)
+    objs = []
+    for s in SOURCES:
+        obj = os.path.join(OBJ_DIR, os.path.splitext(s)[0] + ".o")
+        if s in sources:
+            obj = os.path.join(vdir, os.path.splitext(s)[0] + ".o")
+            cmd = [hipcc] + CXXFLAGS + [f"-D{d}" for d in defines] + ["-c", os.path.join(CSRC, s), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        objs.append(obj)
+    out = os.path.join(PKG_DIR, f"libptranking_amd.{tag}.so")
+    subprocess.run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out] + objs, check=True)
+    return out
 
 
 def build(force=False, verbose=False):
@@ -68,4 +90,13 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":      # python -m ptranking_amd.build --variant TAG DEF[=V] ... [--src a.hip,b.hip]
+        args = sys.argv[3:]
+        srcs = ("scorer_bwd.hip",)
+        if "--src" in args:
+            i = args.index("--src")
+            srcs = tuple(args[i + 1].split(","))
+            args = args[:i] + args[i + 2:]
+        print(build_variant(sys.argv[2], args, srcs, verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,46 @@
+// Shared definitions of the fused pointsf scorer kernels (scorer.hip: forward, layer-wise backward, Adam; scorer_bwd.hip: the
+// single-pass fused backward).  Reference: ptranking/base/point_ranker.py:30-55, ptranking/base/utils.py:288-356.
+#pragma once
+#include <stdlib.h>
+#include <utility>
+
+#include "ptr_device.h"
+#include "ptr_dropout.h"
+
+namespace ptr {
+
+constexpr int kH = 100;          // hidden width, hard-wired in the reference (point_ranker.py:30)
+constexpr int kHP = 112;         // padded to 7 MFMA tiles of 16
+constexpr int kMT = 7;
+constexpr int kMaxLayers = 8;
+constexpr int kAL = 112;         // leading dimension of the stored activations / dZ: rows are 448 B = 7 aligned 64-B sectors,
+                                 // one per (row, 16-feature tile); features 100..111 are padding
+
+// flat parameter layout:  W1[100][F] b1[100] | W2[100][100] b2[100] | ... | w_out[100] b_out[1]
+__host__ __device__ inline size_t off_W(int l, int F) { return l == 0 ? 0 : (size_t)kH * F + kH + (size_t)(l - 1) * (kH * kH + kH); }
+__host__ __device__ inline size_t off_b(int l, int F) { return off_W(l, F) + (l == 0 ? (size_t)kH * F : (size_t)kH * kH); }
+__host__ __device__ inline size_t off_wout(int NL, int F) { return off_W(NL, F); }
+__host__ __device__ inline size_t n_params(int NL, int F) { return off_wout(NL, F) + kH + 1; }
+
+struct MlpArgs {
+    int R, F, NL;
+    float p_drop;            // 0 => no dropout (eval mode)
+    uint32_t seed_lo, seed_hi;
+};
+
+int mlp_num_cus();
+
+// ---- compile-time loop with a constexpr index: f(std::integral_constant<int, I>{}) for I = 0..N-1
+template <int N, class Fn> __device__ __forceinline__ void static_for(Fn &&f) {
+    [&]<int... I>(std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, N>{});
+}
+
+// ---- single-pass fused backward (scorer_bwd.hip)
+// true when the (F, NL) configuration and the pointer alignments are served by the fused kernel
+bool bwd_fused_supported(int F, int NL, const void *X, const void *acts);
+// enqueue; ws must hold bwd_fused_grid(R) * n_params floats; returns the number of per-block partials written (0 on error, error set)
+int bwd_fused_grid(int R);
+int launch_bwd_fused(const float *X, const float *params, const float *acts, const float *dpreds, const MlpArgs &a, float *ws,
+                     hipStream_t st, const char *who);
+
+}  // namespace ptr

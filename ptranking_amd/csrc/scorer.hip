@@ -21,34 +21,14 @@
 //
 // HBM traffic per row (F = 136, 3 hidden layers, training): forward reads 4F, writes 3*400 + 4; dZ reads 3*400 + 4, writes
 // 3*400; dW reads 4F + 5*400.  MFMA work per row: 2*(100F + 2*100*100 + 100) flop forward, about twice that backward.
-#include <stdlib.h>
-
-#include "ptr_device.h"
-#include "ptr_dropout.h"
+#include "ptr_mlp.h"
 
 namespace ptr {
 
-constexpr int kH = 100;          // hidden width, hard-wired in the reference (point_ranker.py:30)
-constexpr int kHP = 112;         // padded to 7 MFMA tiles of 16
-constexpr int kMT = 7;
-constexpr int kMaxLayers = 8;
 #ifndef DW_U
 #define DW_U 4
 #endif
-constexpr int kAL = 112;         // leading dimension of the stored activations / dZ: rows are 448 B = 7 aligned 64-B sectors,
-                                 // one per (row, 16-feature tile); features 100..111 are zero padding
-
-__host__ __device__ inline size_t off_W(int l, int F) { return l == 0 ? 0 : (size_t)kH * F + kH + (size_t)(l - 1) * (kH * kH + kH); }
-__host__ __device__ inline size_t off_b(int l, int F) { return off_W(l, F) + (l == 0 ? (size_t)kH * F : (size_t)kH * kH); }
-__host__ __device__ inline size_t off_wout(int NL, int F) { return off_W(NL, F); }
-__host__ __device__ inline size_t n_params(int NL, int F) { return off_wout(NL, F) + kH + 1; }
 __host__ __device__ inline int ld_w1(int F) { return (F + 3) / 4 * 4 + 4; }   // LDS leading dimension of W1 (bank spread)
-
-struct MlpArgs {
-    int R, F, NL;
-    float p_drop;            // 0 => no dropout (eval mode)
-    uint32_t seed_lo, seed_hi;
-};
 
 
 // Stage a [rows_valid][cols_valid] row-major matrix into LDS as [kHP][ld], zero padded.  transpose: dst[c][r] = src[r][c].
@@ -786,7 +766,7 @@ static int dw_staged() { static int v = -1; if (v < 0) v = env_flag("PTR_DW_STAG
 static int dw_rb() { static int v = -1; if (v < 0) { const char *e = getenv("PTR_DW_RB"); v = (e && atoi(e) == 32) ? 32 : 16; } return v; }   // 16 measured best (32: 1.09 vs 1.05 ms backward)
 static int dz_wide() { static int v = -1; if (v < 0) v = env_flag("PTR_DZ_WIDE", 0); return v; }
 
-static int num_cus() {
+int mlp_num_cus() {
     static int n = 0;
     if (!n) {
         hipDeviceProp_t prop;
@@ -803,7 +783,13 @@ extern "C" size_t ptr_mlp_num_params(int F, int NL) { return ptr::n_params(NL, F
 
 // floats of workspace ptr_mlp_backward needs
 extern "C" size_t ptr_mlp_backward_ws_floats(int F, int NL) {
-    return (size_t)ptr::dw_blocks_per_cu() * ptr::num_cus() * ptr::n_params(NL, F);
+    return (size_t)ptr::dw_blocks_per_cu() * ptr::mlp_num_cus() * ptr::n_params(NL, F);
+}
+
+// floats of dZ scratch ptr_mlp_backward needs for (R, F, NL): 0 when the single-pass fused backward serves the configuration
+// (X / acts assumed 16-byte aligned, as every torch allocation is)
+extern "C" size_t ptr_mlp_backward_dz_floats(int R, int F, int NL) {
+    return ptr::bwd_fused_supported(F, NL, nullptr, nullptr) ? 0 : (size_t)NL * (size_t)R * ptr::kAL;
 }
 
 extern "C" int ptr_mlp_forward(const float *X, const float *params, int R, int F, int NL, int train, float p_drop, uint64_t seed,
@@ -820,7 +806,7 @@ extern "C" int ptr_mlp_forward(const float *X, const float *params, int R, int F
     const bool wide = fwd_wide() != 0;            // 16 waves x 16-row tiles (4 waves/SIMD) or 8 waves x 32-row tiles
     const int rows_per_tile = wide ? 16 : 32, wpb = wide ? 16 : 8;
     const int ntiles = (R + rows_per_tile - 1) / rows_per_tile;
-    const int grid = ntiles < wpb * num_cus() ? (ntiles + wpb - 1) / wpb : num_cus();
+    const int grid = ntiles < wpb * mlp_num_cus() ? (ntiles + wpb - 1) / wpb : mlp_num_cus();
     auto launch = [&](auto kern) -> int {
         if (int e = allow_lds(kern, lds)) return e;
         hipLaunchKernelGGL(kern, dim3(grid > 0 ? grid : 1), dim3(wpb * 64), lds, as_stream(stream), X, params, a, preds, acts);
@@ -844,11 +830,20 @@ extern "C" int ptr_mlp_backward(const float *X, const float *params, const float
     using namespace ptr;
     const char *who = "ptr_mlp_backward";
     if (int rc = check_mlp(who, R, F, NL, p_drop)) return rc;
-    if (!X || !params || !acts || !dpreds || !dz || !ws || !grad) { set_error("%s: NULL pointer", who); return PTR_ERR_INVALID_ARG; }
+    if (!X || !params || !acts || !dpreds || !ws || !grad) { set_error("%s: NULL pointer", who); return PTR_ERR_INVALID_ARG; }
     hipStream_t st = as_stream(stream);
     MlpArgs a{R, F, NL, p_drop, (uint32_t)seed, (uint32_t)(seed >> 32)};
+    if (R > 0 && bwd_fused_supported(F, NL, X, acts)) {
+        // single pass: X and the stored activations are read once, dZ never leaves the chip (scorer_bwd.hip); dz is not touched
+        if (int e = launch_bwd_fused(X, params, acts, dpreds, a, ws, st, who)) return e;
+        const int nb = bwd_fused_grid(R);
+        const size_t NPf = n_params(NL, F);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((NPf + 63) / 64)), dim3(1024), 0, st, ws, nb, nb, NPf, NPf, NPf, grad);
+        return check_hip(hipGetLastError(), who);
+    }
+    if (!dz) { set_error("%s: dz scratch is required for this configuration (ptr_mlp_backward_dz_floats)", who); return PTR_ERR_INVALID_ARG; }
     // 1. dZ chain (+ partial d w_out / d b_out)
-    const int ncu = num_cus();
+    const int ncu = mlp_num_cus();
     const int nblk = dw_blocks_per_cu() * ncu;
     const size_t NP = n_params(NL, F);
     const bool wide = dz_wide() != 0;

@@ -55,7 +55,8 @@ class _ScorerFn(torch.autograd.Function):
         R, F, NL, p, seed = ctx.meta
         dev = X2d.device
         dpreds = dpreds.contiguous()
-        dz = torch.empty((NL, R, ACT_LD), device=dev, dtype=torch.float32)
+        ndz = _lib.query("ptr_mlp_backward_dz_floats", R, F, NL)     # 0: the single-pass fused backward needs no dZ scratch
+        dz = torch.empty(ndz, device=dev, dtype=torch.float32) if ndz else None
         ws = torch.empty(_lib.query("ptr_mlp_backward_ws_floats", F, NL), device=dev, dtype=torch.float32)
         grad = torch.empty_like(flat)
         with torch.cuda.device(dev):

@@ -1,0 +1,26 @@
+"""Dump the phase stamps of the fused backward (PTR_LIB=...trace.so): per slab and wave, cycles spent per phase."""
+import os, sys, torch, ctypes as C
+import numpy as np
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from ptranking_amd import _lib
+torch.manual_seed(0)
+F, NL = 136, 3
+R = 4096 * 128
+X = torch.randn(R, F, device="cuda"); dp = torch.randn(R, device="cuda")
+NP = _lib.query("ptr_mlp_num_params", F, NL)
+P = torch.randn(NP, device="cuda") * 0.1
+preds = torch.empty(R, device="cuda"); acts = torch.empty((NL, R, 112), device="cuda")
+ws = torch.zeros(_lib.query("ptr_mlp_backward_ws_floats", F, NL), device="cuda"); grad = torch.empty(NP, device="cuda")
+st = _lib.current_stream(X.device)
+_lib.call("ptr_mlp_forward", _lib.ptr(X), _lib.ptr(P), R, F, NL, 1, C.c_float(0.1), C.c_uint64(5), _lib.ptr(preds), _lib.ptr(acts), st)
+for _ in range(2):
+    _lib.call("ptr_mlp_backward", _lib.ptr(X), _lib.ptr(P), _lib.ptr(acts), _lib.ptr(dp), R, F, NL, C.c_float(0.1), C.c_uint64(5), None, _lib.ptr(ws), _lib.ptr(grad), st)
+torch.cuda.synchronize()
+tr = ws[256 * NP:256 * NP + 8 * 8 * 16 * 2].cpu().numpy().view(np.uint64).reshape(8, 8, 16).astype(np.int64)
+names = ["P0", "issue", "B1wait", "chain0", "B2wait", "chain1", "B3wait", "P3", "vmcnt", "B4wait"]
+t0 = tr[0, :, 0].min()
+for s_ in range(1, 6):
+    print(f"slab {s_}: start {tr[s_, :, 0] - t0}")
+    d = np.diff(tr[s_, :, :11], axis=1)
+    for w in range(8):
+        print("   w%d " % w + " ".join(f"{names[i]}={d[w, i]:5d}" for i in range(10)) + f"  total={tr[s_, w, 10] - tr[s_, w, 0]}")
