@@ -213,8 +213,12 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
                         uint32_t w0, w1;
                         drop_bits(a.seed_lo, a.seed_hi, l, row[rt], 4 * mt + g, w0, w1);
                         h = drop4(h, w0, w1, thr, scale);
-                        if (row[rt] < R)
-                            *reinterpret_cast<f32x4 *>(acts + ((size_t)(l - 1) * R + row[rt]) * kAL + 16 * mt + 4 * g) = h;
+                        if (row[rt] < R) {
+                            f32x4 hs = h;
+                            if (mt == kMT - 1) hs[0] = g == 1 ? 1.0f : hs[0];   // feature 100 (padding) = 1: the fused backward reads db_l
+                                                                               // off this ones column of its A image (scorer_bwd.hip)
+                            *reinterpret_cast<f32x4 *>(acts + ((size_t)(l - 1) * R + row[rt]) * kAL + 16 * mt + 4 * g) = hs;
+                        }
                     }
                     hin[mt][rt] = h;
                 }

@@ -23,6 +23,8 @@
 //     the row contraction needs is done by the LDS addressing.  The 7*NT1 + 49*(NL-1) accumulator tiles are distributed over
 //     the 8 waves at COMPILE time (TileMap): wave 7 owns no chain tile and instead multiplies a 3x2 block of dW_l during the
 //     chain phase in which dZ_l is already available, so every wave issues the same number of MFMAs between two barriers.
+// Bias gradients cost nothing: every A image carries a column of ones behind its last real feature (X: written with the image;
+// activations: stored by the forward at feature 100), so column K of a dW tile row IS db.
 // NL + 1 workgroup barriers per slab; 994 MFMAs per 16 documents (layer-wise kernels: 1036 + the 7.1x HBM traffic).
 // Results are bit-stable: fixed tile ownership, fixed row order, per-workgroup partials reduced by reduce_partials_kernel.
 #include "ptr_mlp.h"
@@ -33,10 +35,25 @@ constexpr int kSR = 32;            // rows per slab
 constexpr int kBW = 8;             // waves per workgroup
 constexpr int kBT = kBW * 64;
 constexpr int kSlabF = kSR * kAL;  // floats of one activation / dZ image
+// The short VALU / LDS / VMEM bursts that prepare the next slab run at raised wave priority: beside a partner wave that streams
+// MFMAs they otherwise only get the issue slots the stream leaves over (measured 4x slower than alone).
+#ifndef BWD_PREP_PRIO
+#define BWD_PREP_PRIO 1
+#endif
+#if BWD_PREP_PRIO
+#define PREP_BEGIN() __builtin_amdgcn_s_setprio(2)
+#define PREP_END() __builtin_amdgcn_s_setprio(0)
+#else
+#define PREP_BEGIN() do { } while (0)
+#define PREP_END() do { } while (0)
+#endif
+#ifndef BWD_KS_UNROLL
+#define BWD_KS_UNROLL 2            // unroll of the dW k-step loop (register pressure vs load batching)
+#endif
 
 __host__ __device__ constexpr int ldx_of(int NT1) { return (NT1 & 1) ? 16 * NT1 : 16 * NT1 + 16; }   // = 16 (mod 32)
 __host__ __device__ constexpr size_t bwd_fused_lds_floats(int NL, int NT1) {
-    return (size_t)2 * NL * kSlabF + (size_t)(NL - 1) * kSlabF + (size_t)kSR * ldx_of(NT1) + 2 * kSR + kHP;
+    return (size_t)2 * NL * kSlabF + (size_t)(NL - 1) * kSlabF + (size_t)2 * kSR * ldx_of(NT1) + 2 * kSR + kHP + kAL + 256 * 4;
 }
 
 // Compile-time distribution of the dW accumulator tiles (l, nt, mt) over waves and phases.
@@ -51,8 +68,9 @@ template <int NL, int NT1> struct TileMap {
     int cnt[kBW][NPH];
     int lst[kBW][NPH][MAXL];
     int ntiles[kBW];
+    int maxtiles;
     static constexpr int ntl(int l) { return l == 0 ? NT1 : 7; }
-    constexpr TileMap() : tl{}, tn{}, tm{}, slot{}, cnt{}, lst{}, ntiles{} {
+    constexpr TileMap() : tl{}, tn{}, tm{}, slot{}, cnt{}, lst{}, ntiles{}, maxtiles(0) {
         int id = 0;
         for (int l = 0; l < NL; ++l)
             for (int n = 0; n < ntl(l); ++n)
@@ -63,20 +81,58 @@ template <int NL, int NT1> struct TileMap {
             for (int t = 0; t < NT; ++t)
                 if (tl[t] == l && tn[t] >= ntl(l) - 2 && tm[t] < 3) { taken[t] = true; lst[7][c][cnt[7][c]++] = t; }
         }
+        // all-wave phase: waves 0..6 (which also hold the chain weights) get layer-pure runs of `take[l]` tiles in (nt, mt) order
+        // (at most 7 dZ fragments + 3-4 A fragments per k-step); wave 7 collects every layer's leftover
+        int T[NL] = {}, k[NL] = {}, take[NL] = {}, left[NL] = {};
         int rem = 0;
-        for (int t = 0; t < NT; ++t) rem += taken[t] ? 0 : 1;
-        const int base = rem / kBW, extra = rem % kBW;
-        int w = 0, inw = 0;
-        for (int t = 0; t < NT; ++t) {
-            if (taken[t]) continue;
-            lst[w][CH][cnt[w][CH]++] = t;
-            if (++inw == base + (w < extra ? 1 : 0)) { ++w; inw = 0; }
+        for (int t = 0; t < NT; ++t)
+            if (!taken[t]) { ++T[tl[t]]; ++rem; }
+        const int base = rem / kBW;                  // wave 7 (no chain weights in registers) may end up with more accumulator tiles
+        const int quota7 = base;
+        int ksum = 0;
+        for (int l = 0; l < NL; ++l) { k[l] = base > 0 ? T[l] / base : 0; ksum += k[l]; }
+        while (ksum > kBW - 1) {                       // too many runs: drop one from the layer with the smallest remainder
+            int best = -1;
+            for (int l = 0; l < NL; ++l)
+                if (k[l] > 0 && (best < 0 || T[l] - k[l] * base < T[best] - k[best] * base)) best = l;
+            --k[best]; --ksum;
+        }
+        while (ksum < kBW - 1) {                       // too few: add one to the layer with the largest leftover
+            int best = 0;
+            for (int l = 1; l < NL; ++l)
+                if (T[l] - k[l] * base > T[best] - k[best] * base) best = l;
+            ++k[best]; ++ksum;
+        }
+        int L = 0;
+        for (int l = 0; l < NL; ++l) { take[l] = k[l] > 0 ? (T[l] / k[l] < base ? T[l] / k[l] : base) : 0; left[l] = T[l] - k[l] * take[l]; L += left[l]; }
+        for (bool moved = true; moved && L > quota7 + 1;) {   // wave 7 overloaded: lengthen the runs of the layer with the most runs
+            moved = false;
+            int best = -1;
+            for (int l = 0; l < NL; ++l)
+                if (k[l] > 0 && left[l] >= k[l] && (best < 0 || k[l] > k[best])) best = l;
+            if (best >= 0) { ++take[best]; left[best] -= k[best]; L -= k[best]; moved = true; }
+        }
+        {
+            int w = 0;
+            for (int l = 0; l < NL; ++l) {
+                int given = 0, run = 0;
+                for (int t = 0; t < NT; ++t) {
+                    if (taken[t] || tl[t] != l) continue;
+                    if (run < k[l]) {
+                        lst[w][CH][cnt[w][CH]++] = t;
+                        if (++given == take[l]) { given = 0; ++run; ++w; }
+                    } else {
+                        lst[kBW - 1][CH][cnt[kBW - 1][CH]++] = t;
+                    }
+                }
+            }
         }
         for (int v = 0; v < kBW; ++v) {
             int s = 0;
             for (int ph = 0; ph < NPH; ++ph)
                 for (int k = 0; k < cnt[v][ph]; ++k) slot[lst[v][ph][k]] = s++;
             ntiles[v] = s;
+            if (s > maxtiles) maxtiles = s;
         }
     }
     // first use of the dZ fragment (l, mt) / the A fragment (l, nt) inside a wave's phase list => it has to be read from LDS
@@ -93,6 +149,7 @@ template <int NL, int NT1> struct TileMap {
 };
 template <int NL, int NT1> inline constexpr TileMap<NL, NT1> kTM{};
 
+using lds_f = __attribute__((address_space(3))) float;
 __device__ __forceinline__ uint32_t lds_byte_addr(const void *p) {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
 }
@@ -119,6 +176,14 @@ __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 #define BWD_STAMP(i) do { } while (0)
 #endif
 
+// Per slab s (parity p) a workgroup runs three barrier-separated phases; the LDS images of slab s+1 are prepared while slab s
+// is multiplied, by the half of the waves that is NOT on the matrix pipe at that moment (waves w and w+4 share a SIMD):
+//   A  chain 0 (waves 0-6; wave 7: its dW block) | waves 0-3 first issue the LDS-DMA + X loads of slab s+1, waves 4-7 issue
+//      their DMA share after their MFMAs
+//   B  chain 1 ... (NL-1 chain phases in general); then the DMA has landed (vmcnt(0)) and dLoss/dscore of slab s+1 is published
+//   C  all remaining dW tiles of slab s | waves 0-3 first turn their X registers into the XS image of slab s+1 (input dropout
+//      recomputed), waves 4-7 run the top-layer pass of slab s+1 (dZ in place, d w_out, d b_out, db_top) after their MFMAs
+// Every wave runs its own specialisation of this body (tile lists, accumulator registers and roles are compile-time per wave).
 template <int NL, int NT1, int W>
 __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const float *__restrict__ P, const float *__restrict__ acts,
                                          const float *__restrict__ dpreds, const MlpArgs a, float *__restrict__ ws, size_t np_stride,
@@ -126,177 +191,243 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
     using TMt = TileMap<NL, NT1>;
     constexpr int CH = NL - 1, LDX = ldx_of(NT1), NTMAX = NT1 > 7 ? NT1 : 7;
     constexpr int NACC = kTM<NL, NT1>.ntiles[W];
+    constexpr bool loader = W < 4;                        // X staging + early DMA issue; the others: top-layer pass + late DMA issue
     const int F = a.F, R = a.R;
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
     float *bufA = smem;                                   // [2][NL][kSlabF]  stored activations (top layer: dZ in place)
     float *Zb = bufA + 2 * NL * kSlabF;                   // [CH][kSlabF]     dZ_0 .. dZ_{NL-2}
-    float *XS = Zb + CH * kSlabF;                         // [kSR][LDX]       dropped input features
-    float *dsb = XS + kSR * LDX;                          // [2][kSR]         dLoss/dscore
+    float *XSb = Zb + CH * kSlabF;                        // [2][kSR][LDX]    dropped input features
+    float *dsb = XSb + 2 * kSR * LDX;                     // [2][kSR]         dLoss/dscore
     float *wo = dsb + 2 * kSR;                            // [kHP]            w_out
+    float *junk_row = wo + kHP;                           // [kAL]            image row for the idle slots of the top-layer pass
+    float *junk_x = junk_row + kAL;                       // [256][4]         store target of the idle X-staging slots
     const uint32_t bufA_addr = lds_byte_addr(bufA);
     const int nslabs = (R + kSR - 1) / kSR;
     const uint32_t thr = drop_thr(a.p_drop);
     const float inv_keep = a.p_drop > 0.0f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
 
     // ---- one-time: w_out to LDS, this wave's W^T fragments to registers
-    for (int i = tid; i < kHP; i += kBT) wo[i] = i < kH ? P[off_wout(NL, F) + i] : 0.0f;
+    for (int i = tid; i < kHP; i += kBT) { wo[i] = i < kH ? P[off_wout(NL, F) + i] : 0.0f; junk_row[i] = 0.0f; }
     float wf[CH > 0 ? CH : 1][25];
-    if constexpr (W < 7) {
-        static_for<CH>([&](auto c_) {
-            constexpr int c = c_, l = NL - 1 - c;
-            const float *Wl = P + off_W(l, F);
-            const int k = 16 * W + j;
-            const bool kok = k < kH;
-            const int kc = kok ? k : 0;
+    static_for<CH>([&](auto c_) {
+        constexpr int c = c_, l = NL - 1 - c;
+        const float *Wl = P + off_W(l, F);
+        const int k = 16 * W + j;
+        const bool kok = W < 7 && k < kH;
+        const int kc = kok ? k : 0;
 #pragma unroll
-            for (int S = 0; S < 6; ++S)
+        for (int S = 0; S < 6; ++S)
 #pragma unroll
-                for (int c4 = 0; c4 < 4; ++c4) {
-                    const float v = Wl[(size_t)(16 * S + 4 * g + c4) * kH + kc];
-                    wf[c][4 * S + c4] = kok ? v : 0.0f;
-                }
-            const float v = Wl[(size_t)(96 + g) * kH + kc];
-            wf[c][24] = kok ? v : 0.0f;
-        });
-    }
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const float v = Wl[(size_t)(16 * S + 4 * g + c4) * kH + kc];
+                wf[c][4 * S + c4] = kok ? v : 0.0f;
+            }
+        const float v = Wl[(size_t)(96 + g) * kH + kc];
+        wf[c][24] = kok ? v : 0.0f;
+    });
+    // consume the fragments HERE: hipcc otherwise sinks the waits for these loads to their first use inside the slab loop, as
+    // s_waitcnt vmcnt(N) with N counted without the LDS-DMA in flight there — every slab would wait for its own prefetch
+#pragma unroll
+    for (int c = 0; c < (CH > 0 ? CH : 1); ++c)
+#pragma unroll
+        for (int i = 0; i < 25; ++i) asm volatile("" : "+v"(wf[c][i]));
 
-    // ---- loop-invariant slot geometry of the X staging
-    constexpr int XTOT = kSR * 4 * NT1, XSL = (XTOT + kBT - 1) / kBT;
-    auto x_slot = [&](int u, int &xr, int &xc) -> bool {      // slot u of this thread -> (slab row, float4 column); recomputed at use
-        const int idx = tid + kBT * u;
+    // ---- X staging (waves 0-3, 256 threads): slot u of thread t -> (slab row, float4 column), recomputed at use
+    constexpr int XTOT = kSR * 4 * NT1, XSL = (XTOT + 255) / 256;
+    auto x_slot = [&](int t, int u, int &xr, int &xc) -> bool {
+        const int idx = t + 256 * u;
         const bool in = idx < XTOT;
         xr = in ? idx / (4 * NT1) : 0;
         xc = in ? idx - xr * (4 * NT1) : 0;
         return in;
     };
-    f32x4 xraw[XSL];
+    f32x4 xraw[loader ? XSL : 1];
     float dsraw = 0.0f;
 
-    auto issue_loads = [&](int slab, int buf) {
+    // this wave's share of the activation DMA (chunks of 64 lanes x 16 B)
+    auto issue_dma = [&](int slab, int buf, int lane_o) {
+        // a slab image is CONTIGUOUS in global memory (row stride = image stride = 448 B): float offset row0*112 + chunk*256 + lane*4,
+        // clamped to the last float4 of the layer for the tail slab (rows >= R only need finite values: their dLoss/dscore is 0)
+        const int off0 = slab * kSlabF + 4 * lane_o;
+        const int last = R * kAL - 4;
+#pragma unroll
+        for (int q = 0; q < (NL * 14 + kBW - 1) / kBW; ++q) {
+            const int k = W + kBW * q;                     // scalar
+            if (k < NL * 14) {
+                const int layer = k / 14, ch = k - 14 * layer;
+                const float *src = acts + (size_t)layer * R * kAL + min(off0 + ch * 256, last);
+                const uint32_t dst = bufA_addr + (uint32_t)(((buf * NL + layer) * kSlabF + ch * 256) * 4);
+                glds16(src, __builtin_amdgcn_readfirstlane(dst));
+            }
+        }
+    };
+    auto load_x = [&](int slab, int tid_o) {              // raw loads, no consumer until finish_x (waves 0-3); dLoss/dscore: every wave
         const int row0 = slab * kSR;
-        static_for<(NL * 14 - W + kBW - 1) / kBW>([&](auto q_) {
-            constexpr int k = W + kBW * q_, layer = k / 14, ch = k % 14;
-            const int idx4 = ch * 64 + lane;
-            const int row = idx4 / 28, c4 = idx4 - row * 28;
-            const int gr = min(row0 + row, R - 1);
-            const float *src = acts + ((size_t)layer * R + gr) * kAL + 4 * c4;
-            const uint32_t dst = bufA_addr + (uint32_t)(((buf * NL + layer) * kSlabF + ch * 256) * 4);
-            glds16(src, __builtin_amdgcn_readfirstlane(dst));
-        });
+        if constexpr (loader) {
+#pragma unroll
+            for (int u = 0; u < XSL; ++u) {
+                int xr, xc;
+                x_slot(tid_o, u, xr, xc);
+                const int gr = min(row0 + xr, R - 1);
+                const int cc = 4 * xc < F ? 4 * xc : 0;
+                xraw[u] = *reinterpret_cast<const f32x4 *>(X + (size_t)gr * F + cc);
+            }
+        }
+        dsraw = dpreds[min(row0 + (tid_o & (kSR - 1)), R - 1)];
+    };
+    auto finish_x = [&](int slab, int buf, int tid_o) {
+      if constexpr (loader) {
+        const int row0 = slab * kSR;
+        float *XS = XSb + buf * kSR * LDX;
+        const uint32_t thr_e = a.p_drop > 0.0f ? thr : 0u;          // threshold 0 keeps everything: no branch around the hash, so the
+        // XSL slots form ONE basic block and their (serially dependent) hash chains interleave
 #pragma unroll
         for (int u = 0; u < XSL; ++u) {
             int xr, xc;
-            x_slot(u, xr, xc);
-            const int gr = min(row0 + xr, R - 1);
-            const int cc = 4 * xc < F ? 4 * xc : 0;
-            xraw[u] = *reinterpret_cast<const f32x4 *>(X + (size_t)gr * F + cc);
+            const bool in = x_slot(tid_o, u, xr, xc);
+            uint32_t w0, w1;
+#ifdef BWD_NO_HASH                                                       // timing experiment only (wrong masks)
+            w0 = w1 = 0xFFFFFFFFu;
+#else
+            drop_bits(a.seed_lo, a.seed_hi, 0, min(row0 + xr, R - 1), xc, w0, w1);
+#endif
+            f32x4 v = drop4(xraw[u], w0, w1, thr_e, inv_keep);
+            const float okf = 4 * xc < F ? 1.0f : 0.0f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] *= okf;
+            v[0] = 4 * xc == F ? 1.0f : v[0];                        // the ones column: dW_0's column F is db_0
+            float *dst = in ? XS + xr * LDX + 4 * xc : junk_x + 4 * tid_o;      // idle slots store to a pad instead of branching
+            *reinterpret_cast<f32x4 *>(dst) = v;
         }
-        dsraw = dpreds[min(row0 + (tid & (kSR - 1)), R - 1)];      // every thread (unconditional load / use, see P0)
+      }
+    };
+    // top layer (waves 4-7, 252 threads = 9 row slots x 28 feature groups): dZ_top = ds * w_out * [h > 0] in place,
+    // d w_out += h * ds, d b_out += ds
+    f32x4 dwo4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dbo = 0.0f;
+    auto top_pass = [&](int buf, int tid_o) {
+      if constexpr (!loader) {
+        const int t = tid_o - 256;
+        const int rs = t / 28, f4 = t - rs * 28;
+        const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wo + 4 * f4);
+        float *img = bufA + (buf * NL + NL - 1) * kSlabF;
+        const float first = f4 == 0 ? 1.0f : 0.0f;
+        // branch-free: slots without a row (thread >= 252, or row >= 32 in the last pass) work on a zeroed pad row with ds = 0
+        float *pa[4];
+        f32x4 h4[4];
+        float ds[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {                      // all reads first: the in-place update must not serialise the four rows
+            const int r = rs + 9 * h;
+            const bool ok = rs < 9 && r < kSR;
+            pa[h] = ok ? img + r * kAL + 4 * f4 : junk_row + 4 * f4;
+            h4[h] = *reinterpret_cast<const f32x4 *>(pa[h]);
+            const float dsr = dsb[buf * kSR + (ok ? r : 0)];
+            ds[h] = ok ? dsr : 0.0f;
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            f32x4 d;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                d[c] = (ds[h] * w4[c]) * (h4[h][c] > 0.0f ? 1.0f : 0.0f);
+                dwo4[c] = fmaf(h4[h][c], ds[h], dwo4[c]);
+            }
+            *reinterpret_cast<f32x4 *>(pa[h]) = d;
+            dbo = fmaf(first, ds[h], dbo);
+        }
+      }
     };
 
     f32x4 acc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float dbv[NL][kMT];
-#pragma unroll
-    for (int l = 0; l < NL; ++l)
-#pragma unroll
-        for (int m = 0; m < kMT; ++m) dbv[l][m] = 0.0f;
-    f32x4 dwo4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    float dbo = 0.0f;
-    const int f4 = tid % 28, r0t = tid / 28;             // top-layer pass: thread -> (feature group, row) for tid < 448
 
-    // dW tiles of phase PH over the slab's 8 k-steps (4 rows each)
-    auto dw_phase = [&](auto ph_, const float *cur) {
-        constexpr int PH = ph_;
-        constexpr int CNT = kTM<NL, NT1>.cnt[W][PH];
+    // dW tiles of wave WV in phase PH over the slab's 8 k-steps (4 rows each), software-pipelined by hand: two k-steps per loop
+    // iteration, the operands of the next k-step are read into the other register set while the current one is multiplied
+    auto dw_phase = [&](auto wv_, auto ph_, const float *cur, const float *XS) {
+        constexpr int WV = wv_, PH = ph_;
+        constexpr int CNT = kTM<NL, NT1>.cnt[WV][PH];
         if constexpr (CNT > 0) {
-#pragma unroll 2
-            for (int ks = 0; ks < kSR / 4; ++ks) {
-                float av[NL][kMT], bv[NL][NTMAX];
+            float av[2][NL][kMT], bv[2][NL][NTMAX];
+            // One OPAQUE base address per LDS image (lane part included): every read below is base + a small constant that fits the
+            // ds_read offset field.  Without it each read address (image offset > 64 KB + constant) is a loop-invariant VGPR of its
+            // own, hoisted out of the slab loop by the hundred and spilled to scratch.
+            uint32_t zb[NL], ab[NL];
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                zb[l] = lds_byte_addr(l == NL - 1 ? cur + (NL - 1) * kSlabF : Zb + l * kSlabF) + (uint32_t)((g * kAL + j) * 4);
+                ab[l] = l == 0 ? lds_byte_addr(XS) + (uint32_t)((g * LDX + j) * 4)
+                               : lds_byte_addr(cur + (l - 1) * kSlabF) + (uint32_t)((g * kAL + j) * 4);
+                asm volatile("" : "+v"(zb[l]), "+v"(ab[l]));
+            }
+            auto rd = [&](int ks, auto set_) {
+                constexpr int set = set_;
                 static_for<CNT>([&](auto k_) {
-                    constexpr int t = kTM<NL, NT1>.lst[W][PH][k_];
-                    constexpr int l = kTM<NL, NT1>.tl[t], n = kTM<NL, NT1>.tn[t], m = kTM<NL, NT1>.tm[t], s = kTM<NL, NT1>.slot[t];
-                    if constexpr (kTM<NL, NT1>.first_a(W, PH, k_)) {
-                        const float *zsrc = l == NL - 1 ? cur + (NL - 1) * kSlabF : Zb + l * kSlabF;
-                        av[l][m] = zsrc[(4 * ks + g) * kAL + 16 * m + j];
-                        if constexpr (n == 0) dbv[l][m] += av[l][m];
-                    }
-                    if constexpr (kTM<NL, NT1>.first_b(W, PH, k_)) {
-                        if constexpr (l == 0) bv[l][n] = XS[(4 * ks + g) * LDX + 16 * n + j];
-                        else bv[l][n] = cur[(l - 1) * kSlabF + (4 * ks + g) * kAL + 16 * n + j];
-                    }
-                    acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[l][m], bv[l][n], acc[s], 0, 0, 0);
+                    constexpr int t = kTM<NL, NT1>.lst[WV][PH][k_];
+                    constexpr int l = kTM<NL, NT1>.tl[t], n = kTM<NL, NT1>.tn[t], m = kTM<NL, NT1>.tm[t];
+                    if constexpr (kTM<NL, NT1>.first_a(WV, PH, k_))
+                        av[set][l][m] = *reinterpret_cast<lds_f *>((uintptr_t)(zb[l] + (uint32_t)((4 * ks * kAL + 16 * m) * 4)));
+                    if constexpr (kTM<NL, NT1>.first_b(WV, PH, k_))
+                        bv[set][l][n] = *reinterpret_cast<lds_f *>((uintptr_t)(ab[l] + (uint32_t)((4 * ks * (l == 0 ? LDX : kAL) + 16 * n) * 4)));
                 });
+            };
+            auto mma = [&](auto set_) {
+                constexpr int set = set_;
+                static_for<CNT>([&](auto k_) {
+                    constexpr int t = kTM<NL, NT1>.lst[WV][PH][k_];
+                    constexpr int l = kTM<NL, NT1>.tl[t], n = kTM<NL, NT1>.tn[t], m = kTM<NL, NT1>.tm[t], s = kTM<NL, NT1>.slot[t];
+                    acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][l][m], bv[set][l][n], acc[s], 0, 0, 0);
+                });
+            };
+            using S0 = std::integral_constant<int, 0>;
+            using S1 = std::integral_constant<int, 1>;
+            rd(0, S0{});
+#pragma unroll
+            for (int ks = 0; ks < kSR / 4; ks += 2) {
+                rd(ks + 1, S1{});
+                mma(S0{});
+                rd(ks + 2 < kSR / 4 ? ks + 2 : ks + 1, S0{});      // last iteration: a harmless re-read instead of a branch
+                mma(S1{});
             }
         }
     };
-
     int slab = blockIdx.x, p = 0;
     int nslab_done = 0;
     (void)nslab_done;
-    issue_loads(slab, 0);
+    // ---- prologue: slab 0's images
+    issue_dma(slab, 0, lane);
+    load_x(slab, tid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     {
         const float dsv = slab * kSR + (tid & (kSR - 1)) < R ? dsraw : 0.0f;
         if (tid < kSR) dsb[tid] = dsv;
     }
+    if (loader) finish_x(slab, 0, tid);
+    wg_barrier();
+    if (!loader) top_pass(0, tid);
     wg_barrier();
 
     for (; slab < nslabs; slab += gridDim.x, p ^= 1) {
-        const int row0 = slab * kSR;
-        const int next = slab + gridDim.x;
-        const bool has_next = next < nslabs;
+        // The preparation of the next slab is UNCONDITIONAL (the last iteration redundantly re-prepares its own slab into the other
+        // buffers): loads issued and consumed under a run-time `has_next` look pending to hipcc's waitcnt pass on the impossible
+        // issue-but-skip-use path, and the s_waitcnt vmcnt(N) it then places at the next reuse of those registers lands right
+        // behind freshly issued LDS-DMA (which it does not count) — a full HBM round trip per slab in the chain phase.
+        const bool real_next = slab + gridDim.x < nslabs;
+        const int next = real_next ? slab + gridDim.x : slab;        // redundant pass: its dLoss/dscore is published as 0 (no double count)
         float *cur = bufA + p * NL * kSlabF;
+        // opaque copies: address arithmetic derived from them is recomputed per slab instead of being hoisted out of the loop
+        // and kept in registers across the MFMA phases
+        int tid_o = tid, lane_o = lane;
+        asm volatile("" : "+v"(tid_o), "+v"(lane_o));
         BWD_STAMP(0);
 
-        // ---- P0: X image (input dropout recomputed), top-layer dZ in place, d w_out / d b_out; then the next slab's loads
-#pragma unroll
-        for (int u = 0; u < XSL; ++u) {
-            // the loaded registers are consumed UNCONDITIONALLY (only the store is predicated): a use inside a branch leaves the
-            // load "pending" on the skipping path in hipcc's waitcnt model, and the s_waitcnt vmcnt(0) it then places at the
-            // next write of those registers lands behind the LDS-DMA issues below — a full HBM round trip per slab
-            int xr, xc;
-            const bool in = x_slot(u, xr, xc);
-            f32x4 v = xraw[u];
-            if (a.p_drop > 0.0f) {
-                uint32_t w0, w1;
-                drop_bits(a.seed_lo, a.seed_hi, 0, min(row0 + xr, R - 1), xc, w0, w1);
-                v = drop4(v, w0, w1, thr, inv_keep);
-            }
-            const float okf = 4 * xc < F ? 1.0f : 0.0f;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] *= okf;
-            if (in) *reinterpret_cast<f32x4 *>(XS + xr * LDX + 4 * xc) = v;
-        }
-        if (tid < 448) {
-            const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wo + 4 * f4);
-#pragma unroll
-            for (int h = 0; h < kSR / 16; ++h) {
-                const int r = r0t + 16 * h;
-                float *pa = cur + (NL - 1) * kSlabF + r * kAL + 4 * f4;
-                const f32x4 h4 = *reinterpret_cast<const f32x4 *>(pa);
-                const float ds = dsb[p * kSR + r];
-                f32x4 d;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    d[c] = (ds * w4[c]) * (h4[c] > 0.0f ? 1.0f : 0.0f);
-                    dwo4[c] = fmaf(h4[c], ds, dwo4[c]);
-                }
-                *reinterpret_cast<f32x4 *>(pa) = d;
-            }
-        } else if (tid < 448 + kSR) {
-            dbo += dsb[p * kSR + tid - 448];
-        }
-        BWD_STAMP(1);
-        if (has_next) issue_loads(next, p ^ 1);
-        BWD_STAMP(2);
-        wg_barrier();
-        BWD_STAMP(3);
-
-        // ---- chain phases: dZ_{l-1} = (W_l^T dZ_l) gated by the stored activation; wave 7 multiplies dW_l tiles instead
+        // ---- phases A, B, ...: chain (waves 0-6) / wave 7's dW blocks
         static_for<CH>([&](auto c_) {
             constexpr int c = c_, l = NL - 1 - c;
+            if constexpr (c == 0) {
+                if constexpr (loader) { PREP_BEGIN(); issue_dma(next, p ^ 1, lane_o); load_x(next, tid_o); PREP_END(); }
+            }
             if constexpr (W < 7) {
                 const float *src = c == 0 ? cur + (NL - 1) * kSlabF : Zb + l * kSlabF;
                 float *dst = Zb + (l - 1) * kSlabF;
@@ -326,65 +457,73 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
                     *reinterpret_cast<f32x4 *>(dst + row * kAL + 16 * W + 4 * g) = d;
                 }
             } else {
-                dw_phase(c_, cur);
+                dw_phase(std::integral_constant<int, 7>{}, c_, cur, XSb + p * kSR * LDX);
             }
-            BWD_STAMP(4 + 2 * c);
+            if constexpr (c == 0) {
+                if constexpr (!loader) { PREP_BEGIN(); issue_dma(next, p ^ 1, lane_o); load_x(next, tid_o); PREP_END(); }
+            }
+            if constexpr (c == CH - 1) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // slab s+1's images have landed
+                const float dsv = (real_next && next * kSR + (tid_o & (kSR - 1)) < R) ? dsraw : 0.0f;
+                if (tid_o < kSR) dsb[(p ^ 1) * kSR + tid_o] = dsv;
+            }
+            BWD_STAMP(1 + 2 * c);
             wg_barrier();
-            BWD_STAMP(5 + 2 * c);
+            BWD_STAMP(2 + 2 * c);
         });
 
-        // ---- all-wave dW phase
-        dw_phase(std::integral_constant<int, CH>{}, cur);
-        BWD_STAMP(4 + 2 * CH);
-
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        BWD_STAMP(5 + 2 * CH);          // the next slab's LDS-DMA has landed (issued a whole slab ago)
-        {
-            const float dsv = next * kSR + (tid & (kSR - 1)) < R ? dsraw : 0.0f;
-            if (has_next && tid < kSR) dsb[(p ^ 1) * kSR + tid] = dsv;
-        }
+        // ---- phase C: all-wave dW of slab s; preparation of slab s+1 by the wave half that is off the matrix pipe
+        if constexpr (loader) { PREP_BEGIN(); finish_x(next, p ^ 1, tid_o); PREP_END(); }
+        BWD_STAMP(1 + 2 * CH);
+        dw_phase(std::integral_constant<int, W>{}, std::integral_constant<int, CH>{}, cur, XSb + p * kSR * LDX);
+        BWD_STAMP(2 + 2 * CH);
+        if constexpr (!loader) { PREP_BEGIN(); top_pass(p ^ 1, tid_o); PREP_END(); }
+        BWD_STAMP(3 + 2 * CH);
         wg_barrier();
-        BWD_STAMP(6 + 2 * CH);
+        BWD_STAMP(4 + 2 * CH);
         ++nslab_done;
     }
 
     // ---- epilogue: this workgroup's partial gradient in the flat parameter layout
     float *out = ws + (size_t)blockIdx.x * np_stride;
-    static_for<TMt::NPH>([&](auto ph_) {
-        constexpr int PH = ph_;
-        static_for<kTM<NL, NT1>.cnt[W][PH]>([&](auto k_) {
-            constexpr int t = kTM<NL, NT1>.lst[W][PH][k_];
-            constexpr int l = kTM<NL, NT1>.tl[t], n = kTM<NL, NT1>.tn[t], m = kTM<NL, NT1>.tm[t], s = kTM<NL, NT1>.slot[t];
-            const int K = l == 0 ? F : kH;
-            const int k = 16 * n + j;
-            float *o = out + off_W(l, F);
+    auto store_tiles = [&](auto wv_) {
+        constexpr int WV = wv_;
+        static_for<TMt::NPH>([&](auto ph_) {
+            constexpr int PH = ph_;
+            static_for<kTM<NL, NT1>.cnt[WV][PH]>([&](auto k_) {
+                constexpr int t = kTM<NL, NT1>.lst[WV][PH][k_];
+                constexpr int l = kTM<NL, NT1>.tl[t], n = kTM<NL, NT1>.tn[t], m = kTM<NL, NT1>.tm[t], s = kTM<NL, NT1>.slot[t];
+                const int K = l == 0 ? F : kH;
+                const int k = 16 * n + j;
+                float *o = out + off_W(l, F);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int of = 16 * m + 4 * g + c;
-                if (of < kH && k < K) o[(size_t)of * K + k] = acc[s][c];
-            }
-            if constexpr (n == 0) {
-                float v = dbv[l][m];
-                v += __shfl_xor(v, 16, 64);
-                v += __shfl_xor(v, 32, 64);
-                const int of = 16 * m + j;
-                if (g == 0 && of < kH) out[off_b(l, F) + of] = v;
-            }
+                for (int c = 0; c < 4; ++c) {
+                    const int of = 16 * m + 4 * g + c;
+                    if (of < kH && k < K) o[(size_t)of * K + k] = acc[s][c];
+                    if (of < kH && k == K) out[off_b(l, F) + of] = acc[s][c];        // the ones column of the A image
+                }
+            });
         });
-    });
-    // d w_out / d b_out: fixed-order sums over the 16 row slots / 32 rows (Zb and XS are free after the loop's last barrier)
-    if (tid < 448) *reinterpret_cast<f32x4 *>(Zb + r0t * kAL + 4 * f4) = dwo4;
-    else if (tid < 448 + kSR) XS[tid - 448] = dbo;
+    };
+    store_tiles(std::integral_constant<int, W>{});
+    // d w_out / d b_out: fixed-order sums over the 9 row slots of the top-layer pass (Zb is free after the last barrier)
+    if (!loader) {
+        const int t = tid - 256, rs = t / 28, f4 = t - rs * 28;
+        if (rs < 9) {
+            *reinterpret_cast<f32x4 *>(Zb + rs * kAL + 4 * f4) = dwo4;
+            if (f4 == 0) Zb[18 * kAL + rs] = dbo;
+        }
+    }
     wg_barrier();
     if (tid < kH) {
         float s = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s += Zb[r * kAL + tid];
+        for (int r = 0; r < 9; ++r) s += Zb[r * kAL + tid];
         out[off_wout(NL, F) + tid] = s;
     } else if (tid == kH) {
         float s = 0.0f;
 #pragma unroll
-        for (int r = 0; r < kSR; ++r) s += XS[r];
+        for (int r = 0; r < 9; ++r) s += Zb[18 * kAL + r];
         out[off_wout(NL, F) + kH] = s;
     }
 }

@@ -17,10 +17,10 @@ for _ in range(2):
     _lib.call("ptr_mlp_backward", _lib.ptr(X), _lib.ptr(P), _lib.ptr(acts), _lib.ptr(dp), R, F, NL, C.c_float(0.1), C.c_uint64(5), None, _lib.ptr(ws), _lib.ptr(grad), st)
 torch.cuda.synchronize()
 tr = ws[256 * NP:256 * NP + 8 * 8 * 16 * 2].cpu().numpy().view(np.uint64).reshape(8, 8, 16).astype(np.int64)
-names = ["P0", "issue", "B1wait", "chain0", "B2wait", "chain1", "B3wait", "P3", "vmcnt", "B4wait"]
+names = ["chainA", "waitA", "chainB", "waitB", "finX", "P3", "top", "waitC"]
 t0 = tr[0, :, 0].min()
-for s_ in range(1, 6):
+for s_ in range(2, 5):
     print(f"slab {s_}: start {tr[s_, :, 0] - t0}")
-    d = np.diff(tr[s_, :, :11], axis=1)
+    d = np.diff(tr[s_, :, :9], axis=1)
     for w in range(8):
-        print("   w%d " % w + " ".join(f"{names[i]}={d[w, i]:5d}" for i in range(10)) + f"  total={tr[s_, w, 10] - tr[s_, w, 0]}")
+        print("   w%d " % w + " ".join(f"{names[i]}={d[w, i]:5d}" for i in range(8)) + f"  total={tr[s_, w, 8] - tr[s_, w, 0]}")
