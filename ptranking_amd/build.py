@@ -47,7 +47,7 @@ def build_variant(tag, defines, sources=("scorer_bwd.hip",), verbose=False):
         obj = os.path.join(OBJ_DIR, os.path.splitext(s)[0] + ".o")
         if s in sources:
             obj = os.path.join(vdir, os.path.splitext(s)[0] + ".o")
-            cmd = [hipcc] + CXXFLAGS + [f"-D{d}" for d in defines] + ["-c", os.path.join(CSRC, s), "-o", obj]
+            cmd = [hipcc] + CXXFLAGS + [d if d.startswith("-") else f"-D{d}" for d in defines] + ["-c", os.path.join(CSRC, s), "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)

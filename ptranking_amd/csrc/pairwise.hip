@@ -18,6 +18,8 @@
 //   times sigmoid' = p(1-p) (=> gradient exactly 0 once p rounds to 1.0f).
 // Reference: ptranking/ltr_adhoc/listwise/lambdarank.py:39-56, ptranking/ltr_adhoc/pairwise/ranknet.py:32-36,
 //            ptranking/ltr_adhoc/util/lambda_utils.py:5-23, ptranking/metric/metric_utils.py:19-45.
+#include <stdlib.h>
+
 #include "ptr_device.h"
 
 namespace ptr {
@@ -191,6 +193,229 @@ pairwise_bce_kernel(const float *__restrict__ preds, const float *__restrict__ l
     }
 }
 
+
+// =====================================================================================================================
+// LambdaRank "ring" kernel (list lengths up to 256, sigma > 0): ONE wavefront per query, the pair loop runs entirely out of
+// registers with wavefront shuffles — no LDS access, no address arithmetic, no branch inside the O(L^2) loop.
+//
+// Documents sit at their rank position p = DPT*lane + slot (DPT = ceil(L/64) per lane, ring size RS = 64*DPT; positions
+// n..RS-1 hold padding records).  Every lane keeps its own records {s, G, D} fixed and owns DPT travelling records
+// {s, G, D, g}; one ring step moves the travelling records to the neighbouring lane (v_mov_b32_dpp wave_rol:1) and pairs every
+// own slot with every travelling slot: after r steps lane a meets the records of lane a+r, i.e. the circulant schedule of the
+// LDS kernel above, with the partner's gradient share accumulated in the travelling g instead of an LDS read-modify-write.
+// After 32 steps the travelling g of a position sits 32 lanes away from its owner and is added back with one shuffle.
+//
+// Per pair: ~17 VALU-issue slots incl. 3 transcendentals (the LDS kernel: ~42 + 3 + 3 LDS).  What makes the body that short:
+//   * D = 1/log2(rank+2) is strictly decreasing in the rank, so the sign of dD = D_own - D_T tells which of the two is ranked
+//     first: no position arithmetic and no wrap-around bookkeeping.  prod = (G_own-G_T)*dD > 0  <=>  the first-ranked document
+//     has the larger gain (target 1); wsg = sigma*|dG|*dD is the pair weight carrying the orientation sign, so the own
+//     gradient share is wsg*(p - t) and the partner's its negative, for either orientation;
+//   * s_first - s_second = |s_own - s_T| (rank order = score order), so x = sigma*|ds| needs no select;
+//   * padding needs no mask: s = -1e30 (=> p = 1, q = 0, gradient factor 0), G = -1 (=> target 1, log p = 0) make every pair
+//     with a padding record contribute exactly 0 to loss and gradients;
+//   * the loss is accumulated as sum |wsg| * max(log2(.), -100/ln2) and scaled by ln2/sigma once per query.
+// Arithmetic per pair is otherwise the reference's (see the header): p = fl(1/(1+e^-x)), q = fl(1-p), BCE's -100 clamp, and a
+// gradient that is exactly 0 once p rounds to 1.
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ float dpp_rol1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x134 /* wave_rol:1 */, 0xF, 0xF, false));
+}
+
+template <int DPT>
+__global__ void __launch_bounds__(kBlock)
+lambdarank_ring_kernel(const float *__restrict__ preds, const float *__restrict__ labels, const int32_t *__restrict__ lens,
+                       int B, int L, float sigma, float *__restrict__ loss_q, float *__restrict__ grad) {
+    constexpr int RS = 64 * DPT, QPB = kBlock / kWave;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int q = blockIdx.x * QPB + wv;
+    const bool valid = q < B;
+    const int n = valid ? query_len(lens, q, L) : 0;
+    float *keys = smem + (size_t)wv * (3 * RS);            // raw scores for the counting sort; later: gradients by position
+    float *ps = keys + RS;                                 // scores by rank position
+    float *pg = ps + RS;                                   // normalised gains by rank position
+
+    // ---- coalesced load, rank by score (counting sort, ties by original index), IDCG
+    float si[DPT], li[DPT];
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int i = lane + 64 * m;
+        const bool in = i < n;
+        si[m] = in ? preds[(size_t)q * L + i] : -INFINITY;
+        li[m] = in ? labels[(size_t)q * L + i] : 0.0f;
+        keys[i] = si[m];
+    }
+    __syncthreads();
+    // rank = #{j : s_j > s_i}: one compare + one add-with-carry per key.  Ties (equal scores; rare) are detected by a marker
+    // collision — every real document writes its index at its rank, a document that reads back another index shares its rank —
+    // and only then the wave recounts with the index tie-break (count_ranks).
+    int rk[DPT];
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) rk[m] = 0;
+    {
+        const float4 *k4 = reinterpret_cast<const float4 *>(keys);
+        const int n4 = (n + 3) >> 2;
+        for (int j4 = 0; j4 < n4; ++j4) {
+            const float4 v = k4[j4];
+#pragma unroll
+            for (int m = 0; m < DPT; ++m) rk[m] += (v.x > si[m]) + (v.y > si[m]) + (v.z > si[m]) + (v.w > si[m]);
+        }
+    }
+    int *mark = reinterpret_cast<int *>(ps);
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int i = lane + 64 * m;
+        if (i < n) mark[rk[m]] = i;
+    }
+    __syncthreads();
+    bool tie = false;
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int i = lane + 64 * m;
+        tie |= i < n && mark[rk[m]] != i;
+    }
+    if (__any(tie)) count_ranks<kWave, DPT>(keys, n, lane, si, rk);
+    __syncthreads();                                      // mark (= ps) is rewritten below
+    float part = 0.0f;
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int i = lane + 64 * m;
+        if (i < n) part += gain_of(li[m]) / log2f((float)i + 2.0f);      // labels arrive in ideal order: DCG(input order) = IDCG
+    }
+    const float idcg = wave_sum(part);
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int i = lane + 64 * m;
+        const bool in = i < n;
+        const int r = in ? rk[m] : i;                      // padding keeps positions n..RS-1
+        ps[r] = in ? si[m] : -1e30f;
+        pg[r] = in ? gain_of(li[m]) / idcg : -1.0f;
+    }
+    __syncthreads();
+
+    // ---- own records by position p = DPT*lane + slot; travelling copies
+    const float c2 = sigma * 1.4426950408889634f;          // x*log2(e) folded into sigma
+    const float kClamp = -100.0f * 1.4426950408889634f;    // BCE's -100 clamp in the log2 domain
+    float ga[DPT], Tacc[DPT];
+    float lacc = 0.0f;
+    if constexpr (DPT == 1) {
+        // one document per lane: scalar pair body, the travelling record moves one lane per step
+        const float so = ps[lane], go = pg[lane], Do = 1.0f / log2f((float)lane + 2.0f);
+        float Ts = so, Tg = go, Td = Do;
+        ga[0] = 0.0f; Tacc[0] = 0.0f;
+        for (int step = 1; step <= 32; ++step) {
+            Ts = dpp_rol1(Ts); Tg = dpp_rol1(Tg); Td = dpp_rol1(Td); Tacc[0] = dpp_rol1(Tacc[0]);
+            const float e = __builtin_amdgcn_exp2f(-fabsf((so - Ts) * c2));
+            const float dd = 1.0f + e;
+            float p = __builtin_amdgcn_rcpf(dd);
+            p = fmaf(p, fmaf(-dd, p, 1.0f), p);
+            const float qv = 1.0f - p;
+            const float dDn = Td - Do;
+            float un = ((go - Tg) * dDn) * sigma;
+            if (step == 32) un = dDn < 0.0f ? un : 0.0f;     // half step: every pair is seen from both ends, keep the first-ranked one's
+            const bool t1 = un < 0.0f;
+            lacc = fmaf(fabsf(un), fmaxf(__builtin_amdgcn_logf(t1 ? p : qv), kClamp), lacc);
+            const float m = __builtin_copysignf(t1 ? qv : __builtin_amdgcn_fractf(p), dDn);
+            ga[0] = fmaf(-un, m, ga[0]);
+            Tacc[0] = fmaf(un, m, Tacc[0]);
+        }
+    } else {
+        // DPT >= 2: two pairs per instruction with packed fp32 (v_pk_add/mul/fma_f32) — the kernel is VALU-issue bound and a plain
+        // wave64 VALU instruction occupies the SIMD as long as a packed one.  Outer loop: the travelling slots move r lanes; inner:
+        // own slot k against the travelling pair (2j, 2j+1), all register indices static, the own value broadcast by op_sel.
+        // Orientation-free form: with dDn = D_T - D_own (< 0: own is ranked first) and un = sigma*(G_own-G_T)*dDn,
+        //   target 1 <=> un < 0;   own gradient += -un * m,  partner's += un * m,   m = sign(dDn) * (t1 ? q : fract(p))
+        // (fract(p) = p for p in [0.5, 1) and 0 at p == 1: the factor that vanishes once p(1-p) underflows).
+        f32x2 so2[DPT], go2[DPT], Do2[DPT];                  // own records, broadcast pairs {v, v}
+        f32x2 Ts[DPT / 2], Tg[DPT / 2], Td[DPT / 2], Ta[DPT / 2], ga2[DPT];
+#pragma unroll
+        for (int k = 0; k < DPT; ++k) {
+            const int pos = DPT * lane + k;
+            const float s_ = ps[pos], g_ = pg[pos], d_ = 1.0f / log2f((float)pos + 2.0f);
+            so2[k] = f32x2{s_, s_}; go2[k] = f32x2{g_, g_}; Do2[k] = f32x2{d_, d_};
+            ga2[k] = f32x2{0.f, 0.f};
+            Ts[k / 2][k & 1] = s_; Tg[k / 2][k & 1] = g_; Td[k / 2][k & 1] = d_; Ta[k / 2][k & 1] = 0.0f;
+        }
+        const f32x2 c22 = {c2, c2}, sg2 = {sigma, sigma}, one2 = {1.0f, 1.0f};
+        auto pair2 = [&](int k, int j, f32x2 mask, bool use_mask) {
+            const f32x2 x = (so2[k] - Ts[j]) * c22;
+            const f32x2 e = {__builtin_amdgcn_exp2f(-fabsf(x.x)), __builtin_amdgcn_exp2f(-fabsf(x.y))};
+            const f32x2 dd = one2 + e;
+            f32x2 p = {__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y)};
+            p = __builtin_elementwise_fma(p, __builtin_elementwise_fma(-dd, p, one2), p);
+            const f32x2 qv = one2 - p;
+            const f32x2 dDn = Td[j] - Do2[k];
+            f32x2 un = ((go2[k] - Tg[j]) * dDn) * sg2;
+            if (use_mask) un = un * mask;
+            f32x2 m;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const bool t1 = un[h] < 0.0f;
+                lacc = fmaf(fabsf(un[h]), fmaxf(__builtin_amdgcn_logf(t1 ? p[h] : qv[h]), kClamp), lacc);
+                m[h] = __builtin_copysignf(t1 ? qv[h] : __builtin_amdgcn_fractf(p[h]), dDn[h]);      // one v_bfi_b32
+            }
+            ga2[k] = __builtin_elementwise_fma(-un, m, ga2[k]);
+            Ta[j] = __builtin_elementwise_fma(un, m, Ta[j]);
+        };
+        // r = 0: pairs inside a lane (travelling slot t > own slot k)
+#pragma unroll
+        for (int k = 0; k < DPT; ++k)
+#pragma unroll
+            for (int j = 0; j < DPT / 2; ++j)
+                if (2 * j + 1 > k) pair2(k, j, f32x2{2 * j > k ? 1.0f : 0.0f, 1.0f}, !(2 * j > k));
+        // r = 1..31: every own slot against every travelling slot
+        for (int r = 1; r < 32; ++r) {
+#pragma unroll
+            for (int j = 0; j < DPT / 2; ++j)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    Ts[j][h] = dpp_rol1(Ts[j][h]); Tg[j][h] = dpp_rol1(Tg[j][h]); Td[j][h] = dpp_rol1(Td[j][h]); Ta[j][h] = dpp_rol1(Ta[j][h]);
+                }
+#pragma unroll
+            for (int k = 0; k < DPT; ++k)
+#pragma unroll
+                for (int j = 0; j < DPT / 2; ++j) pair2(k, j, one2, false);
+        }
+        // r = 32: lanes a and a+32 see each other from both ends — the lower half keeps the pairs
+        {
+#pragma unroll
+            for (int j = 0; j < DPT / 2; ++j)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    Ts[j][h] = dpp_rol1(Ts[j][h]); Tg[j][h] = dpp_rol1(Tg[j][h]); Td[j][h] = dpp_rol1(Td[j][h]); Ta[j][h] = dpp_rol1(Ta[j][h]);
+                }
+            const float lm = lane < 32 ? 1.0f : 0.0f;
+#pragma unroll
+            for (int k = 0; k < DPT; ++k)
+#pragma unroll
+                for (int j = 0; j < DPT / 2; ++j) pair2(k, j, f32x2{lm, lm}, true);
+        }
+#pragma unroll
+        for (int k = 0; k < DPT; ++k) { ga[k] = ga2[k].x + ga2[k].y; Tacc[k] = Ta[k / 2][k & 1]; }
+    }
+    // the travelling accumulators are half a ring (32 lanes) away from their owners
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) {
+        const float tot = ga[k] + __shfl_xor(Tacc[k], 32, 64);
+        keys[DPT * lane + k] = tot;
+    }
+    __syncthreads();
+    const float loss = wave_sum(lacc) * (-0.6931471805599453f / sigma);
+    if (valid) {
+#pragma unroll
+        for (int m = 0; m < DPT; ++m) {
+            const int i = lane + 64 * m;
+            if (i < L) grad[(size_t)q * L + i] = i < n ? keys[rk[m]] : 0.0f;
+        }
+        if (lane == 0) loss_q[q] = loss;
+    }
+}
+
+static int ring_enabled() {                       // PTR_LAMBDARANK_RING=0 selects the LDS kernel (A/B measurements, tests)
+    const char *e = getenv("PTR_LAMBDARANK_RING");
+    return e ? (atoi(e) != 0) : 1;
+}
+
 template <bool WEIGHTED>
 static int launch_pairwise(const float *preds, const float *labels, const int32_t *lens, int B, int L, float sigma,
                            float *loss_out, float *loss_q, float *grad, void *stream, const char *who) {
@@ -198,7 +423,15 @@ static int launch_pairwise(const float *preds, const float *labels, const int32_
     if (B > 0 && (!loss_q || !grad)) { set_error("%s: NULL output pointer", who); return PTR_ERR_INVALID_ARG; }
     if (WEIGHTED && !(sigma >= 0.0f)) { set_error("%s: sigma must be >= 0 (got %g)", who, (double)sigma); return PTR_ERR_INVALID_ARG; }
     hipStream_t st = as_stream(stream);
-    if (B > 0) {
+    if (WEIGHTED && B > 0 && L <= 256 && sigma > 0.0f && ring_enabled()) {
+        auto go = [&](auto kern, int dpt) -> int {
+            const size_t lds = (size_t)(kBlock / kWave) * 3 * 64 * dpt * sizeof(float);
+            hipLaunchKernelGGL(kern, dim3((B + 3) / 4), dim3(kBlock), lds, st, preds, labels, lens, B, L, sigma, loss_q, grad);
+            return check_hip(hipGetLastError(), who);
+        };
+        int rc = L <= 64 ? go(lambdarank_ring_kernel<1>, 1) : L <= 128 ? go(lambdarank_ring_kernel<2>, 2) : go(lambdarank_ring_kernel<4>, 4);
+        if (rc) return rc;
+    } else if (B > 0) {
         const int Lp = round_up(L, 4);
         int rc = dispatch_tiling(L, [&]<int G, int DPT>() -> int {
             constexpr int QPB = kBlock / G, NW = G / kWave;
