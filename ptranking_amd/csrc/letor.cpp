@@ -38,11 +38,12 @@ int read_file(const char *path, FileBuf &fb) {
     fseek(f, 0, SEEK_END);
     long n = ftell(f);
     fseek(f, 0, SEEK_SET);
-    fb.data.resize((size_t)n + 1);
+    fb.data.resize((size_t)n + 2);                       // '\n' sentinel + NUL terminator: strtod / strtoll never run off the buffer
     size_t got = n > 0 ? fread(fb.data.data(), 1, (size_t)n, f) : 0;
     fclose(f);
     if ((long)got != n) { ptr::set_error("ptr_letor: short read on %s", path); return PTR_ERR_INVALID_ARG; }
     fb.data[(size_t)n] = '\n';
+    fb.data[(size_t)n + 1] = '\0';
     size_t pos = 0, end = (size_t)n;
     while (pos < end) {
         const char *nl = (const char *)memchr(fb.data.data() + pos, '\n', end - pos + 1);
@@ -113,6 +114,8 @@ LineInfo parse_line(const char *p, int one_indexed, T *X_row, int32_t n_features
     p = skip_ws(endp);
     if (strncmp(p, "qid:", 4) != 0) { li.bad = true; return li; }
     p += 4;
+    if (*p == '\n' || *p == '\r' || *p == '\0' || *p == '#' || *p == ' ' || *p == '\t') { li.bad = true; return li; }   // "qid:" with nothing
+    // behind it: strtoll would skip the newline and swallow the next line's target
     li.qid = strtoll(p, &endp, 10);
     if (endp == p) {   // non-numeric query id: stable 63-bit FNV-1a hash of the token
         uint64_t h = 1469598103934665603ull;
@@ -127,6 +130,8 @@ LineInfo parse_line(const char *p, int one_indexed, T *X_row, int32_t n_features
         long fid = strtol(p, &endp, 10);
         if (endp == p || *endp != ':') { li.bad = true; return li; }
         p = endp + 1;
+        if (*p == '\n' || *p == '\r' || *p == '\0' || *p == '#' || *p == ' ' || *p == '\t') { li.bad = true; return li; }   // "fid:" without a
+        // value (strtod skips leading whitespace, newlines included)
         const char *vend = p;
         double val = 0.0;
         if (X_row) {

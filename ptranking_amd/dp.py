@@ -1,7 +1,8 @@
 """Data-parallel training of the hot path: one process per GPU, queries sharded across ranks, replicated scorer.
 
 The reference is single-device (no torch.distributed call site anywhere); queries are independent
-units in every in-scope loss, and every loss is a SUM over queries (lambdarank.py:56, listnet.py:39, ...), so the
+units in every in-scope loss, and every loss but one is a SUM over queries (lambdarank.py:56, listnet.py:39, ...; RankMSE is
+a batch MEAN — its ranker re-scales around the collective, rankers.py), so the
 only exchange step is ONE `all_reduce(SUM)` of the flattened parameter gradient per iteration —
 136 KB for the 136-feature scorer: latency-bound on xGMI, so everything is kept in a single bucket.
 

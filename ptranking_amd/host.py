@@ -64,6 +64,7 @@ class DeviceEvaluator:
             if min_len is not None and lens is None and batch_std_labels.size(1) < min_len:
                 continue  # skip if the number of documents is smaller than k (ranker.py:41-42)
             lens_d = None if lens is None else self._to_dev(lens).to(torch.int32)
+            _reject_padding_with_batchnorm(self, lens_d)
             self._batch_lens = lens_d
             batch_preds = self.predict(self._to_dev(batch_q_doc_vectors))
             self._batch_lens = None
@@ -157,6 +158,27 @@ class DeviceEvaluator:
         return avg["ndcg"], avg["nerr"], avg["ap"], avg["p"]
 
 
+def _reject_padding_with_batchnorm(ranker, lens):
+    """Padded batches (`lens` given) and batch normalisation do not mix: zero-padded rows would enter the 'BN' (batch x docs) and
+    'BN2' (per-query) statistics and change the scores of real documents — the reference never pads (data_utils.py:683-742
+    batches equal-length lists only).  Fails loudly instead of silently training on different statistics."""
+    if lens is None:
+        return
+    has_bn = getattr(ranker, "_scorer_has_bn", None)
+    if has_bn is None:
+        mods = []
+        for name in ("point_sf", "list_sf"):
+            sf = getattr(ranker, name, None)
+            if isinstance(sf, nn.Module):
+                mods += list(sf.modules())
+        has_bn = any(type(m).__name__ in ("_BatchNormOverDocs", "_BatchNormPerQuery", "LTRBatchNorm", "LTRBatchNorm2", "BatchNorm1d")
+                     for m in mods)
+        ranker._scorer_has_bn = has_bn
+    if has_bn:
+        raise NotImplementedError("padded query batches (lens) cannot be scored by a scoring function with batch normalisation: the "
+                                  "padded rows would enter the BN statistics; batch equal-length lists or build the scorer with BN=False")
+
+
 # ------------------------------------------------------------------------------------------------ training loop
 class DeviceTrainLoop:
     """train / train_op with the reference's contract (ranker.py:565-603) minus the per-batch `.item()` host sync:
@@ -186,6 +208,7 @@ class DeviceTrainLoop:
     def train_op(self, batch_q_doc_vectors, batch_std_labels, **kwargs):
         stop_training = False
         self._batch_lens = kwargs.get('lens')          # padded batches: the listwise scorer masks padded documents as keys
+        _reject_padding_with_batchnorm(self, self._batch_lens)
         batch_preds = self.forward(batch_q_doc_vectors)
         self._batch_lens = None
         if 'epoch_k' in kwargs and kwargs['epoch_k'] % self.stop_check_freq == 0:

@@ -59,6 +59,8 @@ class FusedStepMixin:
                 # (no bucket memset, no accumulate-into-view copy)
                 self.optimizer.zero_grad()
                 loss.backward()
+                if self._dp_single.grad is None:          # no gradient on this rank (e.g. an all-padding shard): every rank
+                    self._dp_single.grad = torch.zeros_like(self._dp_single)   # must still join the collective
                 dp.all_reduce_sum(self._dp_single.grad)
             else:
                 bucket = self._bucket()
@@ -155,6 +157,10 @@ class MDPRankLoss(FusedStepMixin):
                 t = det / self.temperature if 1.0 != self.temperature else det
                 probs = torch.exp(t - torch.max(t, dim=1, keepdim=True)[0]).clamp_min(1e-38)
                 perm = torch.multinomial(probs, num_samples=det.size(1), replacement=False)
+                if lens is not None:  # real documents whose exp() underflowed to the same clamp as the padding may be drawn AFTER a
+                    # padded one: stable-partition every sampled ranking so that all real documents come first
+                    is_pad = (perm >= lens[:, None].to(perm.device)).to(torch.int8)
+                    perm = torch.gather(perm, 1, torch.sort(is_pad, dim=1, stable=True)[1])
                 noise = None
             elif 'STPL' == self.distribution:       # sampling_utils.py:61-83 (Gumbel perturbation, then sort)
                 unif = torch.rand(det.size(), device=det.device)
@@ -193,8 +199,24 @@ class RankCosineLoss(FusedStepMixin):
 
 class RankMSELoss(FusedStepMixin):
     def custom_loss_function(self, batch_preds, batch_std_labels, **kwargs):
-        """ptranking/ltr_adhoc/pointwise/rank_mse.py:29-40"""
-        return self._fused_step(F_.rankmse_loss(batch_preds, batch_std_labels, lens=kwargs.get('lens')))
+        """ptranking/ltr_adhoc/pointwise/rank_mse.py:29-40.  The loss is a MEAN over the batch (the one in-scope loss that is not
+        a sum over queries): under data parallelism the local gradient (scaled 1/B_local) is turned back into a sum, shipped with
+        B_local in the same bucket, and divided by the global batch size after the single all-reduce."""
+        loss = F_.rankmse_loss(batch_preds, batch_std_labels, lens=kwargs.get('lens'))
+        if not (self.data_parallel and dp.is_distributed()):
+            return self._fused_step(loss)
+        b_local = float(batch_preds.size(0))
+        bucket = self._bucket(extra=2)
+        bucket.zero()
+        loss.backward()
+        bucket.flat[:bucket.numel].mul_(b_local)
+        bucket.extras[0] = b_local
+        bucket.extras[1] = loss.detach() * b_local
+        bucket.all_reduce()
+        b_global = bucket.extras[0].clone()
+        bucket.flat[:bucket.numel].div_(b_global)
+        self.optimizer.step()
+        return bucket.extras[1] / b_global
 
 
 class ListMLELoss(FusedStepMixin):

@@ -218,6 +218,7 @@ def gen_siblings():
     """STListNet (st_listnet.py:33-55), RankCosine (rank_cosine.py:24-38), RankMSE (rank_mse.py:13-40)."""
     store = {}
     rng = np.random.default_rng(SEED + 7)
+    torch.manual_seed(SEED + 7)          # STListNet's torch.rand draws and MDPRank's multinomial samples: reproducible fixtures
     for ci, (B, L) in enumerate([(3, 8), (4, 32), (2, 128), (2, 300)]):
         preds, labels = synth(rng, B, L)
         loss, grad = run_loss(RankMSE(sf_para_dict=SF, device="cpu"), preds, labels)
@@ -300,6 +301,50 @@ def gen_siblings():
     print(f"siblings.npz: {len(store)} arrays")
 
 
+def gen_big():
+    """Reference outputs at BASELINE.json's config shapes: C1 RankNet 8x32, C2 LambdaRank 4x128, the north-star
+    kernel at 4x256, C3 ListNet / ListMLE 4x256 (label ties -> the reference's tie shuffle, captured), C4 ApproxNDCG 2x512 with the
+    Yahoo label mix, C5's loss LambdaLoss NDCG_Loss2 2x256.  Kept in a file of its own so that losses.npz stays byte-identical."""
+    store = {}
+    rng = np.random.default_rng(SEED + 11)
+    torch.manual_seed(SEED + 11)
+    preds, labels = synth(rng, 8, 32)
+    loss, grad = run_loss(RankNet(sf_para_dict=SF, model_para_dict={"sigma": 1.0}, device="cpu"), preds, labels)
+    add(store, "ranknet/C1_8x32", preds=preds, labels=labels, sigma=np.float32(1.0), loss=loss, grad=grad)
+    for tag, (B, L) in (("C2_4x128", (4, 128)), ("NS_4x256", (4, 256))):
+        preds, labels = synth(rng, B, L)
+        loss, grad = run_loss(LambdaRank(sf_para_dict=SF, model_para_dict={"sigma": 1.0}, device="cpu"), preds, labels)
+        add(store, f"lambdarank/{tag}", preds=preds, labels=labels, sigma=np.float32(1.0), loss=loss, grad=grad,
+            sort_idx=pred_sort_idx(preds))
+    preds, labels = synth(rng, 4, 256)
+    loss, grad = run_loss(ListNet(sf_para_dict=SF, device="cpu"), preds, labels)
+    add(store, "listnet/C3_4x256", preds=preds, labels=labels, loss=loss, grad=grad)
+    captured = {}
+    orig = ref_listmle_mod.arg_shuffle_ties
+
+    def spy(batch_rankings, descending=True, device=None):
+        out = orig(batch_rankings=batch_rankings, descending=descending, device=device)
+        captured["perm"] = out.numpy().astype(np.int64)
+        return out
+
+    ref_listmle_mod.arg_shuffle_ties = spy
+    try:
+        loss, grad = run_loss(ListMLE(sf_para_dict=SF, device="cpu"), preds, labels)
+    finally:
+        ref_listmle_mod.arg_shuffle_ties = orig
+    add(store, "listmle/C3_4x256", preds=preds, labels=labels, perm=captured["perm"], loss=loss, grad=grad)
+    preds, labels = synth(rng, 2, 512, p=YAHOO_P)
+    loss, grad = run_loss(ApproxNDCG(sf_para_dict=SF, model_para_dict={"alpha": 10.0}, device="cpu"), preds, labels)
+    add(store, "approxndcg/C4_2x512_yahoo", preds=preds, labels=labels, alpha=np.float32(10.0), loss=loss, grad=grad)
+    preds, labels = synth(rng, 2, 256)
+    mpd = dict(k=5, sigma=1.0, loss_type="NDCG_Loss2", mu=5.0)
+    loss, grad = run_loss(LambdaLoss(sf_para_dict=SF, model_para_dict=mpd, device="cpu"), preds, labels)
+    add(store, "lambdaloss/C5_2x256_k5", preds=preds, labels=labels, sigma=np.float32(1.0), k=np.int32(5), mu=np.float32(5.0),
+        loss_type=np.int32(1), loss=loss, grad=grad)
+    np.savez_compressed(os.path.join(HERE, "losses_big.npz"), **store)
+    print(f"losses_big.npz: {len(store)} arrays")
+
+
 def gen_metrics():
     store = {}
     # --- the reference's own known-answer vectors, testing/metric/testing_metric.py:17-61 ---
@@ -354,8 +399,13 @@ def gen_metrics():
 
 
 if __name__ == "__main__":
-    if "--only-siblings" not in sys.argv:
+    if "--only-big" in sys.argv:
+        gen_big()
+    elif "--only-siblings" in sys.argv:
+        gen_siblings()
+    else:
         gen_losses()
         gen_metrics()
-    gen_siblings()
+        gen_siblings()
+        gen_big()
     print("torch", torch.__version__, "numpy", np.__version__)

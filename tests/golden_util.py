@@ -11,6 +11,10 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # magnitude <= 1, relative 1e-5 above that (fp32 summation order alone moves a sum of ~1e4 terms by ~1e-6 rel).
 RTOL = 1e-5
 ATOL = 1e-5
+# second, ELEMENT-WISE gate: an entry far below the row maximum must still be right to 1e-3 relative (or 1e-6 of the maximum,
+# whichever is larger) — the max-norm rule alone would let a gradient element 1000x smaller than the maximum be 100 % wrong
+EL_RTOL = 1e-3
+EL_FLOOR = 1e-6
 
 
 def tol(ref):
@@ -26,6 +30,13 @@ def assert_close(got, ref, what=""):
         return
     err = np.max(np.abs(got - ref))
     assert err <= tol(ref), f"{what}: max|diff|={err:.3e} > tol={tol(ref):.3e} (scale {np.max(np.abs(ref)):.3e})"
+    both_nan = np.isnan(got) & np.isnan(ref)
+    el_tol = EL_RTOL * np.abs(ref) + EL_FLOOR * max(1.0, float(np.nanmax(np.abs(ref))))
+    bad = ~both_nan & ~(np.abs(got - ref) <= el_tol)
+    if bad.any():
+        i = int(np.argmax(np.where(bad, np.abs(got - ref) - el_tol, -np.inf)))
+        raise AssertionError(f"{what}: element-wise gate failed at flat index {i}: got {got.flat[i]!r} ref {ref.flat[i]!r} "
+                             f"(|diff| {abs(got.flat[i] - ref.flat[i]):.3e} > {el_tol.flat[i]:.3e}); {int(bad.sum())} of {ref.size} entries")
 
 
 def _load(fname):
@@ -41,8 +52,14 @@ _CACHE = {}
 
 
 def losses():
+    """losses.npz (edge cases, small shapes) merged with losses_big.npz (reference outputs at BASELINE.json's config shapes)."""
     if "l" not in _CACHE:
-        _CACHE["l"] = _load("losses.npz")
+        d = _load("losses.npz")
+        big = os.path.join(GOLDEN_DIR, "losses_big.npz")
+        if os.path.exists(big):
+            for fam, cases in _load("losses_big.npz").items():
+                d.setdefault(fam, {}).update(cases)
+        _CACHE["l"] = d
     return _CACHE["l"]
 
 

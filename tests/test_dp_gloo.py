@@ -55,15 +55,22 @@ def _patch_functional_with_oracle():
         parts = dict(scale=torch.stack([inv.sum() if grad_scale_override <= 0 else torch.tensor(grad_scale_override), inv.sum()]))
         return (loss, parts) if return_parts else loss
 
+    def rankmse_loss(preds, labels, lens=None):
+        return T.rankmse_loss(preds, labels)
+
     F_.lambdarank_loss = lambdarank_loss
     F_.approxndcg_loss = approxndcg_loss
+    F_.rankmse_loss = rankmse_loss
 
 
 def _make(name):
     import ptranking_amd as pa
     torch.manual_seed(11)
-    paras = {"LambdaRank": {"sigma": 1.0}, "ApproxNDCG": {"alpha": 10.0}}[name]
-    r = getattr(pa, name)(sf_para_dict=copy.deepcopy(SF), model_para_dict=paras, gpu=False, device="cpu")
+    paras = {"LambdaRank": {"sigma": 1.0}, "ApproxNDCG": {"alpha": 10.0}, "RankMSE": None}[name]
+    if paras is None:
+        r = getattr(pa, name)(sf_para_dict=copy.deepcopy(SF), gpu=False, device="cpu")
+    else:
+        r = getattr(pa, name)(sf_para_dict=copy.deepcopy(SF), model_para_dict=paras, gpu=False, device="cpu")
     r.init()
     r.train_mode()
     return r
@@ -77,7 +84,7 @@ def _worker(rank, world, port, name, out_dir):
     _patch_functional_with_oracle()
     rk, ws, _ = dp.init_from_env(backend="gloo")
     assert (rk, ws) == (rank, world) and dp.is_distributed()
-    X, Y = _data()
+    X, Y = _data(B=9 if name == "RankMSE" else 8)          # RankMSE (a batch mean): unequal shards 5 + 4
     lo, hi = dp.shard_queries(X.size(0))
     r = _make(name)
     dp.broadcast_parameters(r.get_parameters())
@@ -93,21 +100,21 @@ def _worker(rank, world, port, name, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["LambdaRank", "ApproxNDCG"])
+@pytest.mark.parametrize("name", ["LambdaRank", "ApproxNDCG", "RankMSE"])
 def test_two_rank_step_equals_single_process_full_batch(name, tmp_path):
     import ptranking_amd as pa
     import ptranking_amd.functional as F_
-    saved = (F_.lambdarank_loss, F_.approxndcg_loss)
+    saved = (F_.lambdarank_loss, F_.approxndcg_loss, F_.rankmse_loss)
     port = _free_port()
     mp.spawn(_worker, args=(2, port, name, str(tmp_path)), nprocs=2, join=True)
     r0, r1 = (torch.load(tmp_path / f"rank{i}.pt") for i in range(2))
-    assert r0["shard"] == (0, 4) and r1["shard"] == (4, 8)
+    assert (r0["shard"], r1["shard"]) == (((0, 5), (5, 9)) if name == "RankMSE" else ((0, 4), (4, 8)))
     for a, b in zip(r0["params"], r1["params"]):
         assert torch.equal(a, b), "replicas diverged"
     # single-process reference run on the full batch
     try:
         _patch_functional_with_oracle()
-        X, Y = _data()
+        X, Y = _data(B=9 if name == "RankMSE" else 8)
         r = _make(name)
         ref_losses, ref_grads1 = [], None
         for step in range(3):
@@ -116,7 +123,7 @@ def test_two_rank_step_equals_single_process_full_batch(name, tmp_path):
             if step == 0:
                 ref_grads1 = [p.grad.detach().clone() for p in r.get_parameters()]
     finally:
-        F_.lambdarank_loss, F_.approxndcg_loss = saved
+        F_.lambdarank_loss, F_.approxndcg_loss, F_.rankmse_loss = saved
     names = [n for n, _ in r.point_sf.named_parameters()]
     # the exchanged gradient equals the full-batch gradient (sum over queries is what the reference's losses compute)
     gmax = max(float(g.abs().max()) for g in ref_grads1)
@@ -129,7 +136,7 @@ def test_two_rank_step_equals_single_process_full_batch(name, tmp_path):
     if name == "LambdaRank":     # per-rank loss = loss of its shard; the shards sum to the full-batch loss
         for step in range(3):
             assert abs(r0["losses"][step] + r1["losses"][step] - ref_losses[step]) <= 1e-4 * abs(ref_losses[step])
-    else:                        # ApproxNDCG under DP returns the GLOBAL coupled loss on every rank
+    else:                        # ApproxNDCG / RankMSE under DP return the GLOBAL (coupled / batch-mean) loss on every rank
         for step in range(3):
             assert abs(r0["losses"][step] - ref_losses[step]) <= 1e-4 * abs(ref_losses[step])
             assert abs(r1["losses"][step] - ref_losses[step]) <= 1e-4 * abs(ref_losses[step])

@@ -144,3 +144,22 @@ def test_install_drops_into_the_reference_driver():
         assert ref_ltr.LambdaRank is original
     finally:
         sys.path.remove(REF)
+
+
+def test_padded_batches_with_batch_normalisation_are_rejected():
+    """PaddedQueryBatches zero-pads rows; with BN they would enter the statistics — the loops must refuse, not drift."""
+    import torch
+    from ptranking_amd import host
+
+    class R:
+        pass
+
+    r = R()
+    r.point_sf = torch.nn.Sequential(torch.nn.Linear(4, 4), host._BatchNormOverDocs(4))
+    lens = torch.tensor([3, 2], dtype=torch.int32)
+    host._reject_padding_with_batchnorm(r, None)                 # equal-length batches: fine
+    with pytest.raises(NotImplementedError, match="batch normalisation"):
+        host._reject_padding_with_batchnorm(r, lens)
+    r2 = R()
+    r2.point_sf = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.ReLU())
+    host._reject_padding_with_batchnorm(r2, lens)                # no BN: padding is masked by the kernels

@@ -142,3 +142,16 @@ def test_value_spellings_round_like_python_float(tmp_path):
     same = (got == want) | (np.isnan(got) & np.isnan(want))
     assert same.all(), [(toks[i], got[i], want[i]) for i in np.flatnonzero(~same)[:5]]
     assert np.array_equal(np.signbit(got), np.signbit(want))
+
+
+@pytest.mark.parametrize("text,line", [("1 qid:1 1:0.5 2:\n2 qid:2 1:0.25\n", 1),      # "fid:" with no value at the end of a line
+                                       ("1 qid:\n2 qid:2 1:0.25\n", 1),                # "qid:" with nothing behind it
+                                       ("1 qid:1 1:0.5\n0 qid:2 1:", 2)])              # ... on the last line, no trailing newline
+def test_truncated_tokens_are_flagged_not_read_through(tmp_path, text, line):
+    """strtod / strtoll skip leading whitespace INCLUDING newlines: a value or query id that is missing at the end of a line must
+    not be taken from the next line (or from beyond the buffer on the last one)."""
+    from ptranking_amd import letor
+    f = tmp_path / "trunc.txt"
+    f.write_text(text)
+    with pytest.raises(ValueError, match=f"malformed line {line}"):
+        letor.parse_letor_file(str(f))
