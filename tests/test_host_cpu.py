@@ -163,3 +163,69 @@ def test_padded_batches_with_batch_normalisation_are_rejected():
     r2 = R()
     r2.point_sf = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.ReLU())
     host._reject_padding_with_batchnorm(r2, lens)                # no BN: padding is masked by the kernels
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
+def test_reference_kfold_cv_eval_runs_on_the_installed_ranker(tmp_path, monkeypatch):
+    """the REFERENCE's own driver loop (ptranking/ltr_adhoc/eval/ltr.py:291-369 — load_ranker -> init -> train ->
+    scheduler.step -> validation (ValidationTape: save of the best epoch) -> load of the optimal checkpoint -> CVTape.fold_evaluation)
+    executed on the class install() put into its module, on CPU, with only `ptranking_amd.functional`'s two device entry points
+    replaced by the oracle (test infrastructure) and the data loader replaced by synthetic batches."""
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    import ptranking_amd.functional as F_
+    from oracle import torch_ref as T
+    try:
+        import ptranking.ltr_adhoc.eval.ltr as ref_ltr
+        from ptranking.data.data_utils import LABEL_TYPE as REF_LABEL_TYPE
+        installed = pa.install()
+        try:
+            calls = {"loss": 0, "metrics": 0}
+
+            def lambdarank_loss(preds, labels, sigma=1.0, lens=None):
+                calls["loss"] += 1
+                return T.lambdarank_loss(preds, labels, sigma=sigma)
+
+            def metrics_at_ks(preds, labels, ks, presort=False, max_label=None, lens=None, which=("ndcg", "nerr", "ap", "p"),
+                              permutation_labels=False):
+                calls["metrics"] += 1
+                out = T.evaluate_at_ks(preds, labels, list(ks), presort, max_label=max_label)
+                return {m: out[m] for m in which}
+
+            monkeypatch.setattr(F_, "lambdarank_loss", lambdarank_loss)
+            monkeypatch.setattr(F_, "metrics_at_ks", metrics_at_ks)
+
+            gen = torch.Generator().manual_seed(5)
+
+            def batches(n, B=4, L=12, F=8):
+                out = []
+                for _ in range(n):
+                    X = torch.randn(B, L, F, generator=gen)
+                    Y = torch.sort(torch.randint(0, 5, (B, L), generator=gen).float(), dim=1, descending=True)[0]
+                    Y[:, 0] = torch.clamp(Y[:, 0], min=1.0)
+                    out.append((list(range(B)), X, Y))
+                return out
+
+            folds = {k: (batches(3), batches(2), batches(2)) for k in (1, 2)}
+            ev = ref_ltr.LTREvaluator()
+            ev.dir_run = str(tmp_path) + "/"
+            monkeypatch.setattr(ev, "display_information", lambda *a, **k: None)
+            monkeypatch.setattr(ev, "check_consistency", lambda *a, **k: None)
+            monkeypatch.setattr(ev, "setup_eval", lambda *a, **k: None)
+            monkeypatch.setattr(ev, "load_data", lambda eval_dict, data_dict, fold_k: folds[fold_k])
+            data_dict = dict(data_id="synthetic", fold_num=2, label_type=REF_LABEL_TYPE.MultiLabel, max_rele_level=4, train_presort=True,
+                             validation_presort=True, test_presort=True)
+            eval_dict = dict(epochs=3, loss_guided=False, vali_k=5, log_step=1, cutoffs=[1, 3, 5], do_validation=True, vali_metric="nDCG",
+                             do_summary=False, do_log=False)
+            sf = {"sf_id": "pointsf", "opt": "Adam", "lr": 1e-2,
+                  "pointsf": dict(num_features=8, num_layers=3, AF="R", TL_AF="S", apply_tl_af=False, BN=False, bn_type=None, bn_affine=False)}
+            scores = ev.kfold_cv_eval(data_dict=data_dict, eval_dict=eval_dict, sf_para_dict=sf,
+                                      model_para_dict={"model_id": "LambdaRank", "sigma": 1.0})
+            scores = torch.as_tensor(scores)
+            assert scores.shape == (3,) and bool(torch.isfinite(scores).all()) and bool((scores > 0).all()) and bool((scores <= 1).all())
+            assert calls["loss"] == 2 * 3 * 3                     # folds x epochs x train batches went through OUR custom_loss_function
+            assert calls["metrics"] >= 2 * (3 * 2 + 2)            # per-epoch validation + the final test evaluation of every fold
+        finally:
+            pa.uninstall()
+    finally:
+        sys.path.remove(REF)

@@ -157,3 +157,33 @@ def test_device_evaluator_matches_cpu_metric_loop(tmp_path):
     # a checkpoint written by the fused scorer loads into the plain torch module (reference key names)
     plain = T.build_pointsf(24, dropout=0.0)
     plain.load_state_dict(torch.load(str(tmp_path) + "/net.pkl", map_location="cpu"))
+
+
+def test_need_per_q_lists_hold_the_per_query_values():
+    """`adhoc_performance_at_ks(need_per_q=True)` (ranker.py:202-263) returns, per metric, one [B, len(ks)] CPU tensor
+    per batch — value-checked here against the oracle's metric loop, and against the averages of the same call."""
+    from oracle import torch_ref as T
+    import ptranking_amd as pa
+    torch.manual_seed(2)
+    ranker = _make("LambdaRank", dict(sigma=1.0))
+    ranker.init()
+    loaders = []
+    for seed, (B, L) in enumerate([(6, 20), (3, 55), (5, 9)]):
+        X, Y = make_data(40 + seed, B, L, 24)
+        loaders.append((list(range(B)), X, Y))
+    ks = [1, 3, 5, 10, 20]
+    out = ranker.adhoc_performance_at_ks(test_data=loaders, ks=ks, label_type=pa.LABEL_TYPE.MultiLabel, presort=True, device="cpu",
+                                         need_per_q=True)
+    assert len(out) == 8
+    avgs, lists = out[:4], out[4:]
+    ranker.eval_mode()
+    for mi, m in enumerate(("ndcg", "nerr", "ap", "p")):
+        assert len(lists[mi]) == len(loaders)
+        tot, nq = torch.zeros(len(ks)), 0
+        for (ids, X, Y), got in zip(loaders, lists[mi]):
+            assert not got.is_cuda and got.shape == (len(ids), len(ks))
+            ref = T.evaluate_at_ks(ranker.predict(X.cuda()).detach().cpu(), Y, ks, presort=True)[m]
+            G.assert_close(got.numpy(), ref.numpy(), f"{m} per query")
+            tot += got.sum(0)
+            nq += len(ids)
+        G.assert_close(avgs[mi].numpy(), (tot / nq).numpy(), f"{m} average = mean of the per-query values")
