@@ -7,13 +7,20 @@ configs[1]).  One process per GPU:
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline      the dominant kernel of the step (the fused fp32-MFMA scorer forward): algorithmic flops per launch / its
-                average launch duration measured with HIP events on the launch stream during the timed region, vs the
-                157.3 TFLOP/s fp32 MFMA peak; `kernels.lambdarank_loss_grad` carries the same for the north-star loss kernel
-                against the HBM roofline (12*L+4 bytes per query)
-  cpu_baseline  the oracle's torch-CPU restatement of the reference train step, timed on this box's host cores on a
-                bounded sample of the same workload (rank 0, N=1 only)
+Rank 0 prints ONE JSON line (contract in the task statement).  `value` is measured at --batch queries per GPU per step (default
+4096; weak scaling — or --global-batch G for strong scaling); `by_batch` carries SURVEY.md 8(d)'s sweep 64 / 256 / 1024 / 4096
+queries per GPU (1024 is the survey's headline batch) measured the same way with fewer steps.  Extra objects:
+  roofline      the dominant kernel of the step by time (the fused single-pass scorer backward, fp32 MFMA): algorithmic flops per
+                launch / its average launch duration measured with HIP events on the launch stream during the timed region, vs
+                the 157.3 TFLOP/s fp32 MFMA peak; `traffic` = PMC HBM bytes (profiles/r02_pmc_traffic.json), `algorithmic_bytes_*`
+                = SURVEY 8(d)'s definition (features + scores), `design_bytes_*` = what the design additionally moves (stored
+                activations, partial gradients)
+  kernels       the other kernels of the step: scorer forward (MFMA roofline), the north-star LambdaRank loss kernel against the
+                HBM roofline (12L+4 bytes / query) AND against its VALU-issue bound (`valu_roofline`), the same kernel at
+                list_len=256, Adam; under data parallelism the gradient all-reduce (`allreduce_ms`)
+  cpu_baseline  the oracle's torch-CPU restatement of the reference train step, timed on this box's host cores on a bounded
+                sample of the same workload with a thread sweep (rank 0, N=1 only); the reference ITSELF timed beside the port on
+                the build container is committed as profiles/r02_reference_vs_port_cpu.json
 Inputs are resident in HBM before the timed region; a step does no host synchronisation.
 """
 import argparse
@@ -36,6 +43,12 @@ HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E spec peak (/opt/skills/guides/M
 MFMA_F32_PEAK_TFLOPS = 157.3      # dense fp32-input MFMA peak = fp32 vector peak (same guide)
 MSLR_P = [0.5147, 0.3250, 0.1339, 0.0183, 0.0081]   # label histogram of MSLR-WEB30K
 SEED = 137                        # ptranking/ltr_global.py:7
+NUM_SIMD = 256 * 4                # 256 CUs x 4 SIMDs
+PEAK_CLOCK_HZ = 2.4e9
+# pair-loop instructions per pair evaluation of lambdarank_ring_kernel<DPT> read off the gfx950 ISA; a wave64 VALU
+# instruction (packed or not) occupies its SIMD for 4 cycles (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU in profiles/r02_sq_c2.txt)
+RING_INSTR_PER_PAIR = {1: 28.0, 2: 19.2, 4: 19.8}
+VALU_CYCLES_PER_INSTR = 4.0
 
 
 def synth_batch(gen, B, L, F, device):
@@ -55,9 +68,10 @@ def sf_para_dict(F, lr=1e-3):
 
 
 def cpu_baseline(L, F, budget_s):
-    """Torch-CPU restatement of the reference's LambdaRank train step (oracle/torch_ref.py), all host cores.  Timed at the batch
-    sizes SURVEY.md 8(d) names: 1 (the reference's own default for lists of >= 100 documents, data_utils.py:713-716), 64 and 256;
-    `value` is the best of them.  Also a loss-only timing (leaf preds -> loss -> backward), kernel against kernel."""
+    """Torch-CPU restatement of the reference's LambdaRank train step (oracle/torch_ref.py).  Timed at the batch sizes SURVEY.md
+    8(d) names — 1 (the reference's own default for lists of >= 100 documents, data_utils.py:713-716), 64 and 256 — and, at 256, with
+    torch.set_num_threads in {8, 16, 32, 64, all}: more threads than the small GEMMs can use is slower, so `value` is the best
+    (batch, threads) found and `cores` the thread count that produced it.  Also a loss-only timing, kernel against kernel."""
     from oracle import torch_ref as T
     torch.manual_seed(SEED)
     gen = torch.Generator().manual_seed(SEED)
@@ -65,6 +79,7 @@ def cpu_baseline(L, F, budget_s):
     net = T.build_pointsf(F, seed=SEED)
     net.train()
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-3)
+    all_threads = torch.get_num_threads()
 
     def timed(fn, units, budget, max_iters):
         for _ in range(2):
@@ -78,12 +93,21 @@ def cpu_baseline(L, F, budget_s):
             if el >= budget or it >= max_iters:
                 return units * it / el, it, el
 
-    by_batch = {}
-    total = 0.0
-    for B, share, cap in ((1, 0.15, 2000), (64, 0.2, 400), (256, 0.5, 200)):
+    sweep, total = [], 0.0
+    cands = sorted({t for t in (8, 16, 32, 64, all_threads) if t <= all_threads})
+    X, Y = Xf, Yf
+    for nt in cands:
+        torch.set_num_threads(nt)
+        qps, it, el = timed(lambda: T.cpu_train_step(net, opt, X, Y, T.lambdarank_loss, sigma=1.0), 256, 0.45 * budget_s / len(cands), 200)
+        sweep.append({"threads": nt, "batch": 256, "queries_per_s": qps, "steps": it, "seconds": el})
+        total += el
+    best_t = max(sweep, key=lambda d: d["queries_per_s"])["threads"]
+    torch.set_num_threads(best_t)
+    by_batch = {"B256": max(sweep, key=lambda d: d["queries_per_s"])}
+    for B, share, cap in ((1, 0.15, 2000), (64, 0.2, 400)):
         X, Y = Xf[:B].contiguous(), Yf[:B].contiguous()
         qps, it, el = timed(lambda: T.cpu_train_step(net, opt, X, Y, T.lambdarank_loss, sigma=1.0), B, share * budget_s, cap)
-        by_batch[f"B{B}"] = {"queries_per_s": qps, "steps": it, "seconds": el}
+        by_batch[f"B{B}"] = {"threads": best_t, "batch": B, "queries_per_s": qps, "steps": it, "seconds": el}
         total += el
     preds = torch.randn(256, L, generator=gen)
 
@@ -92,11 +116,26 @@ def cpu_baseline(L, F, budget_s):
         T.lambdarank_loss(p, Yf, sigma=1.0).backward()
 
     lq, lit, lel = timed(loss_only, 256, 0.15 * budget_s, 400)
+    torch.set_num_threads(all_threads)
     best = max(by_batch.values(), key=lambda d: d["queries_per_s"])
-    return {"value": best["queries_per_s"], "unit": "queries/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": best["queries_per_s"], "unit": "queries/s", "cores": best["threads"], "host_threads_available": all_threads,
+            "kind": "port",
             "sample": f"torch-CPU restatement of the reference train_op (pointsf scorer + LambdaRank + Adam) on {L} docs x {F} feats: "
-                      f"batch sizes 1 / 64 / 256 for {total:.1f} s in total, value = best; plus {lel:.1f} s loss-only",
-            "by_batch": by_batch, "loss_only_queries_per_s": lq}
+                      f"thread sweep {cands} at batch 256, then batch 1 / 64 at the best thread count, {total:.1f} s in total, "
+                      f"value = best; plus {lel:.1f} s loss-only.  The reference itself vs this port on the build container: "
+                      f"profiles/r02_reference_vs_port_cpu.json",
+            "thread_sweep": sweep, "by_batch": by_batch, "loss_only_queries_per_s": lq}
+
+
+def load_pmc(B, L, F):
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+            j = json.load(f)
+        if j["config"] == {"queries_per_gpu_per_step": B, "list_len": L, "features": F}:
+            return {k: v["hbm_bytes_per_launch"] for k, v in j["kernels"].items()}
+    except (OSError, KeyError, ValueError):
+        pass
+    return {}
 
 
 def main():
@@ -105,10 +144,13 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4096, help="queries per GPU per step (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=0, help="strong scaling: total queries per step, split evenly over the GPUs")
+    ap.add_argument("--sweep", default="64,256,1024,4096", help="SURVEY 8(d) per-GPU batch sweep reported in by_batch ('' = off)")
+    ap.add_argument("--sweep-steps", type=int, default=30)
     ap.add_argument("--list-len", type=int, default=128)
     ap.add_argument("--features", type=int, default=136)
     ap.add_argument("--nbatches", type=int, default=4, help="distinct HBM-resident batches cycled through (> L3 capacity)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=14.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--loss", default="LambdaRank", choices=["RankNet", "LambdaRank", "LambdaLoss", "ApproxNDCG", "ListNet", "ListMLE"],
                     help="ranker of the train step (the headline metric is LambdaRank; the others cover BASELINE.json configs 3-5)")
@@ -127,31 +169,32 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     device = f"cuda:{local}"
     torch.cuda.set_device(local)
+    scaling = "weak"
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit(f"--global-batch {args.global_batch} is not a multiple of {world} ranks")
+        args.batch, scaling = args.global_batch // world, "strong"
     B, L, F = args.batch, args.list_len, args.features
+    headline = (args.loss, L, F, args.scorer) == ("LambdaRank", 128, 136, "pointsf")
 
-    torch.manual_seed(SEED)                       # identical initial weights on every rank
-    cls = getattr(pa, args.loss)
-    if args.scorer == "listsf":      # ptranking/ltr_adhoc/eval/parameter.py:152-166 defaults
-        sfd = {"sf_id": "listsf", "opt": "Adagrad", "lr": 1e-3,
-               "listsf": dict(num_features=F, ff_dims=[128, 256, 512], AF="R", TL_AF="GE", apply_tl_af=False, BN=False, bn_type="BN2",
-                              bn_affine=False, n_heads=2, encoder_layers=6, encoder_type="DASALC")}
-    else:
-        sfd = sf_para_dict(F)
-    if args.loss == "ListNet":
-        ranker = cls(sf_para_dict=sfd, gpu=True, device=device)
-    else:
-        ranker = cls(sf_para_dict=sfd, model_para_dict=dict(pa.DEFAULT_PARAS[args.loss]), gpu=True, device=device)
-    if args.loss == "ListMLE":
-        ranker.tie_shuffle = "device"             # the reference's B host-side randperm calls per step would dominate
-    ranker.init()
-    ranker.train_mode()                           # dropout 0.1 active, exactly like the reference's train()
-    gen = torch.Generator(device=device).manual_seed(SEED + 1000 * rank)   # every rank owns different queries
-    batches = [synth_batch(gen, B, L, F, device) for _ in range(max(1, args.nbatches))]
-
-    def step(i):
-        X, Y = batches[i % len(batches)]
-        loss, _ = ranker.train_op(X, Y, epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
-        return loss
+    def build_ranker():
+        torch.manual_seed(SEED)                       # identical initial weights on every rank
+        cls = getattr(pa, args.loss)
+        if args.scorer == "listsf":      # ptranking/ltr_adhoc/eval/parameter.py:152-166 defaults
+            sfd = {"sf_id": "listsf", "opt": "Adagrad", "lr": 1e-3,
+                   "listsf": dict(num_features=F, ff_dims=[128, 256, 512], AF="R", TL_AF="GE", apply_tl_af=False, BN=False, bn_type="BN2",
+                                  bn_affine=False, n_heads=2, encoder_layers=6, encoder_type="DASALC")}
+        else:
+            sfd = sf_para_dict(F)
+        if args.loss == "ListNet":
+            r = cls(sf_para_dict=sfd, gpu=True, device=device)
+        else:
+            r = cls(sf_para_dict=sfd, model_para_dict=dict(pa.DEFAULT_PARAS[args.loss]), gpu=True, device=device)
+        if args.loss == "ListMLE":
+            r.tie_shuffle = "device"             # the reference's B host-side randperm calls per step would dominate
+        r.init()
+        r.train_mode()                           # dropout 0.1 active, exactly like the reference's train()
+        return r
 
     def sync():
         torch.cuda.synchronize()
@@ -159,36 +202,79 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_steps(n):
-        """n train steps, accumulating the loss on the device exactly like DeviceTrainLoop.train does (no host sync)."""
-        acc = torch.zeros((), device=device)
-        for i in range(n):
-            acc += step(i).detach()
-        return acc
+    def measure(ranker, Bq, steps, warmup, prewarm_rounds):
+        """Times `steps` train steps at Bq queries per GPU.  Returns (seconds [max over ranks], per-entry-point event timings,
+        all-reduce event timings, final accumulated loss)."""
+        gen = torch.Generator(device=device).manual_seed(SEED + 1000 * rank + Bq)   # every rank owns different queries
+        batches = [synth_batch(gen, Bq, L, F, device) for _ in range(max(1, args.nbatches))]
 
-    # Untimed pre-warm with EXACTLY the code of the timed region (event hook included): the first launch of every kernel
-    # lazily loads its code object (tens of ms each), and a fresh box needs a few hundred ms before clocks / allocator settle.
-    _lib.TIMING = {}
-    for _ in range(5):                # a FIXED count: every rank must issue the same number of all-reduces
-        float(run_steps(20).item())
-    _lib.TIMING = None
-    gc.collect()
-    gc.disable()                      # no collector pauses inside the timed region
-    run_steps(args.warmup)
-    sync()
-    _lib.TIMING = {}
-    t0 = time.perf_counter()
-    epoch_loss = run_steps(args.steps)
-    sync()
-    elapsed = time.perf_counter() - t0
-    timing, _lib.TIMING = _lib.TIMING, None
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    final_loss = float(epoch_loss.item())
-    if not np.isfinite(final_loss):
-        raise SystemExit(f"non-finite loss {final_loss}")
+        def run_steps(n):
+            """n train steps, accumulating the loss on the device exactly like DeviceTrainLoop.train does (no host sync)."""
+            acc = torch.zeros((), device=device)
+            for i in range(n):
+                X, Y = batches[i % len(batches)]
+                loss, _ = ranker.train_op(X, Y, epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
+                acc += loss.detach()
+            return acc
+
+        # Untimed pre-warm with EXACTLY the code of the timed region (event hooks included): the first launch of every kernel
+        # lazily loads its code object (tens of ms each), and a fresh box needs a few hundred ms before clocks / allocator settle.
+        _lib.TIMING, dp.TIMING = {}, []
+        for _ in range(prewarm_rounds):   # a FIXED count: every rank must issue the same number of all-reduces
+            float(run_steps(20).item())
+        _lib.TIMING, dp.TIMING = None, None
+        gc.collect()
+        gc.disable()                      # no collector pauses inside the timed region
+        run_steps(warmup)
+        sync()
+        _lib.TIMING, dp.TIMING = {}, []
+        t0 = time.perf_counter()
+        epoch_loss = run_steps(steps)
+        sync()
+        elapsed = time.perf_counter() - t0
+        timing, ar_timing = _lib.TIMING, dp.TIMING
+        _lib.TIMING, dp.TIMING = None, None
+        gc.enable()
+        if world > 1:
+            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        final_loss = float(epoch_loss.item())
+        if not np.isfinite(final_loss):
+            raise SystemExit(f"non-finite loss {final_loss}")
+        del batches
+        return elapsed, timing, ar_timing, final_loss
+
+    ranker = build_ranker()
+    elapsed, timing, ar_timing, final_loss = measure(ranker, B, args.steps, args.warmup, 5)
+
+    by_batch = {}
+    if args.sweep and world == 1 and args.scorer == "pointsf":
+        for bq in [int(x) for x in args.sweep.split(",") if x]:
+            if bq == B:
+                by_batch[str(bq)] = {"queries_per_s_per_gpu": B * args.steps / elapsed, "ms_per_step": 1e3 * elapsed / args.steps,
+                                     "steps": args.steps, "is_value": True}
+                continue
+            el, _, _, _ = measure(ranker, bq, args.sweep_steps, args.warmup, 1)
+            by_batch[str(bq)] = {"queries_per_s_per_gpu": bq * args.sweep_steps / el, "ms_per_step": 1e3 * el / args.sweep_steps,
+                                 "steps": args.sweep_steps, "is_value": False}
+
+    # the north-star kernel at its stated list length (BASELINE.json: list_len=256), same number of queries, loss kernel alone
+    l256 = None
+    if rank == 0 and headline:
+        gen = torch.Generator(device=device).manual_seed(SEED + 7)
+        p256 = torch.randn((B, 256), generator=gen, device=device)
+        _, Y256 = synth_batch(gen, B, 256, 1, device)
+        for _ in range(5):
+            pa.functional.lambdarank_loss(p256, Y256, sigma=1.0)
+        torch.cuda.synchronize()
+        _lib.TIMING = {}
+        for _ in range(30):
+            pa.functional.lambdarank_loss(p256, Y256, sigma=1.0)
+        torch.cuda.synchronize()
+        ev = _lib.TIMING["ptr_lambdarank_fwd_bwd"]
+        _lib.TIMING = None
+        l256 = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
     if rank == 0:
         def avg_ms(name):
@@ -198,18 +284,13 @@ def main():
         R = B * L
         NL = 3
         fwd_flop = 2.0 * (100 * F + (NL - 1) * 100 * 100 + 100) * R          # algorithmic: 2*(100F + 2*100*100 + 100) per document
+        bwd_flop = 2.0 * (100 * F + (NL - 1) * 100 * 100) * R + 2.0 * (NL - 1) * 100 * 100 * R + 2.0 * 100 * R   # dW + dZ chain + top
         step_ms = 1e3 * elapsed / args.steps
         loss_entry = {"RankNet": "ptr_ranknet_fwd_bwd", "LambdaRank": "ptr_lambdarank_fwd_bwd", "LambdaLoss": "ptr_lambdaloss_fwd_bwd",
                       "ApproxNDCG": "ptr_approxndcg_fwd_bwd", "ListNet": "ptr_listnet_fwd_bwd", "ListMLE": "ptr_listmle_fwd_bwd"}[args.loss]
-        t_fwd, t_loss, t_bwd, t_adam = (avg_ms(n) for n in ("ptr_mlp_forward", loss_entry, "ptr_mlp_backward", "ptr_adam_step"))
-        pmc = {}
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                j = json.load(f)
-            if j["config"] == {"queries_per_gpu_per_step": B, "list_len": L, "features": F}:
-                pmc = {k: v["hbm_bytes_per_launch"] for k, v in j["kernels"].items()}
-        except (OSError, KeyError, ValueError):
-            pass
+        t_fwd, t_loss, t_bwd, t_adam, t_sum = (avg_ms(n) for n in ("ptr_mlp_forward", loss_entry, "ptr_mlp_backward", "ptr_adam_step",
+                                                                    "ptr_sum_f32"))
+        pmc = load_pmc(B, L, F)
 
         def pmc_bytes(prefix):
             for k, v in pmc.items():
@@ -217,69 +298,97 @@ def main():
                     return v
             return None
 
-        loss_bytes = B * (12 * L + 4)
+        def loss_kernel_entry(Lk, t_ms, traffic):
+            bytes_ = B * (12 * Lk + 4)
+            pairs = B * (Lk * (Lk - 1) // 2)
+            gbps = bytes_ / (t_ms * 1e-3) / 1e9
+            dpt = 1 if Lk <= 64 else 2 if Lk <= 128 else 4
+            bound = NUM_SIMD * PEAK_CLOCK_HZ * 64.0 / (RING_INSTR_PER_PAIR[dpt] * VALU_CYCLES_PER_INSTR)
+            return {"kernel": f"lambdarank_ring_kernel<{dpt}> (fused LambdaRank dNDCG loss + gradient, one wavefront per query, register/DPP ring)",
+                    "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                    "traffic": traffic, "avg_launch_ms": t_ms, "algorithmic_bytes_per_launch": bytes_, "pairs_per_s": pairs / (t_ms * 1e-3),
+                    "valu_roofline": {"bound": "valu-issue", "achieved": pairs / (t_ms * 1e-3), "unit": "pairs/s", "peak": bound,
+                                      "frac": pairs / (t_ms * 1e-3) / bound, "instr_per_pair": RING_INSTR_PER_PAIR[dpt],
+                                      "cycles_per_wave64_valu_instr": VALU_CYCLES_PER_INSTR,
+                                      "note": "peak = 1024 SIMDs x 2.4 GHz x 64 lanes / (pair-loop instructions per pair x 4 cycles); "
+                                              "avg_launch_ms is a HIP-event bracket and includes ~10 us of launch overhead the rocprofv3 "
+                                              "kernel time (profiles/r02_*kernel_stats.csv) does not; SQ counters: profiles/r02_sq_c2.txt"},
+                    "note": "O(L^2) pair work per 12L+4 bytes: VALU-bound by construction (DESIGN.md 3.1)"}
+
         kernels = {}
         if t_loss:
-            gbps = loss_bytes / (t_loss * 1e-3) / 1e9
-            kernels["lambdarank_loss_grad" if args.loss == "LambdaRank" else "loss_grad"] = {
-                "kernel": ("pairwise_bce_kernel<64,2,WEIGHTED> (fused LambdaRank dNDCG loss + gradient)" if args.loss == "LambdaRank"
-                           else f"{loss_entry} (fused {args.loss} loss + gradient)"), "bound": "hbm",
-                "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
-                "traffic": pmc_bytes("ptr::pairwise_bce_kernel"), "avg_launch_ms": t_loss, "algorithmic_bytes_per_launch": loss_bytes,
-                "pairs_per_s": B * (L * (L - 1) // 2) / (t_loss * 1e-3),
-                "note": "O(L^2) pair work per 12L+4 bytes: VALU/transcendental-bound by construction (DESIGN.md 3.1)"}
-        if t_bwd:
-            kernels["scorer_backward"] = {"kernels": "mlp_bwd_dz + 3 x mlp_bwd_dw + reduce_partials", "avg_call_ms": t_bwd,
-                                          "algorithmic_flop_per_call": 2.0 * fwd_flop - 2.0 * 100 * F * R,
-                                          "achieved_TFLOPs": (2.0 * fwd_flop - 2.0 * 100 * F * R) / (t_bwd * 1e-3) / 1e12}
-        if t_adam:
-            kernels["adam"] = {"avg_launch_ms": t_adam}
+            if args.loss == "LambdaRank" and L <= 256:
+                kernels["lambdarank_loss_grad"] = loss_kernel_entry(L, t_loss, pmc_bytes("ptr::lambdarank_ring_kernel"))
+            else:
+                gbps = B * (12 * L + 4) / (t_loss * 1e-3) / 1e9
+                kernels["loss_grad"] = {"kernel": f"{loss_entry} (fused {args.loss} loss + gradient)", "bound": "hbm", "achieved": gbps,
+                                        "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS, "traffic": None,
+                                        "avg_launch_ms": t_loss, "algorithmic_bytes_per_launch": B * (12 * L + 4)}
+        if l256:
+            kernels["lambdarank_loss_grad_L256"] = loss_kernel_entry(256, l256, None)
         if t_fwd:
             tf = fwd_flop / (t_fwd * 1e-3) / 1e12
-            roofline = {"kernel": "mlp_fwd_kernel<2,TRAIN,VEC> (fused pointsf scorer forward, fp32 MFMA 16x16x4, dropout in-kernel)",
+            kernels["scorer_forward"] = {"kernel": "mlp_fwd_kernel<2,TRAIN,VEC> (fused pointsf scorer forward, fp32 MFMA 16x16x4, dropout in-kernel)",
+                                         "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                         "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_bytes("ptr::mlp_fwd_kernel"), "avg_launch_ms": t_fwd,
+                                         "algorithmic_flop_per_launch": fwd_flop, "algorithmic_bytes_per_launch": R * (4 * F + 4),
+                                         "design_bytes_per_launch": NL * R * 448}
+        if t_adam:
+            kernels["adam"] = {"avg_launch_ms": t_adam}
+        if t_sum:
+            kernels["loss_slot_sum"] = {"avg_launch_ms": t_sum}
+        if world > 1 and ar_timing:
+            kernels["gradient_allreduce"] = {"rccl_ranks": world, "allreduce_ms": float(np.mean([a.elapsed_time(b) for a, b in ar_timing])),
+                                             "bytes": 4 * (100 * F + 100 + (NL - 1) * 10100 + 101), "calls_per_step": len(ar_timing) / args.steps}
+        if t_bwd and args.scorer == "pointsf":
+            tf = bwd_flop / (t_bwd * 1e-3) / 1e12
+            fused = (NL == 3 and 129 <= F <= 144 and F % 4 == 0)
+            roofline = {"kernel": ("mlp_bwd_fused_kernel<3,9> (single-pass scorer backward: dZ chain + all weight gradients, fp32 MFMA 16x16x4) "
+                                   "+ reduce_partials_kernel" if fused else "mlp_bwd_dz + 3 x mlp_bwd_dw + reduce_partials (layer-wise backward)"),
                         "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
-                        "traffic": pmc_bytes("ptr::mlp_fwd_kernel"), "avg_launch_ms": t_fwd, "algorithmic_flop_per_launch": fwd_flop,
-                        "algorithmic_bytes_per_launch": R * (4 * F + 4) + NL * R * 448,
-                        "note": "dominant kernel of the step by time; traffic = PMC FETCH_SIZE(x2 on gfx950)+WRITE_SIZE from profiles/r01_pmc_traffic.json"}
+                        "traffic": pmc_bytes("ptr::mlp_bwd_fused_kernel"), "avg_launch_ms": t_bwd, "algorithmic_flop_per_launch": bwd_flop,
+                        "algorithmic_bytes_per_launch": R * (4 * F + 4),
+                        "design_bytes_per_launch": NL * R * 448 + 256 * 4 * (100 * F + 100 + (NL - 1) * 10100 + 101),
+                        "note": "dominant kernel of the step by time; avg_launch_ms brackets the whole ptr_mlp_backward entry point (fused kernel + "
+                                "the 136 KB partial reduction); algorithmic bytes = SURVEY 8(d) (features read once more for dW1 + dLoss/dscore), "
+                                "design bytes = the stored activations read back (3 x 448 B / document) + one partial gradient per workgroup; "
+                                "traffic = PMC FETCH_SIZE(x2 on gfx950)+WRITE_SIZE from profiles/r02_pmc_traffic.json"}
         elif args.scorer == "listsf" and avg_ms("ptr_mhsa_forward"):
             t_af, t_ab = avg_ms("ptr_mhsa_forward"), avg_ms("ptr_mhsa_backward")
             att_flop = 4.0 * B * L * L * F                         # QK^T and PV, 2 flop per MAC, all heads (H * d_h = F)
             tf = att_flop / (t_af * 1e-3) / 1e12
-            c5_traffic = None
-            try:
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_c5.json")) as f:
-                    j5 = json.load(f)
-                if j5["config"] == {"queries_per_gpu_per_step": B, "list_len": L, "features": F}:
-                    c5_traffic = next((v["hbm_bytes_per_launch"] for k, v in j5["kernels"].items() if k.startswith("ptr::mhsa_fwd_kernel")), None)
-            except (OSError, KeyError, ValueError):
-                pass
             roofline = {"kernel": "mhsa_fwd_kernel (fused attention core: QK^T/sqrt(d) -> online softmax -> dropout -> PV, fp32 MFMA 16x16x4)",
                         "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
-                        "traffic": c5_traffic, "avg_launch_ms": t_af, "algorithmic_flop_per_launch": att_flop,
+                        "traffic": None, "avg_launch_ms": t_af, "algorithmic_flop_per_launch": att_flop,
                         "algorithmic_bytes_per_launch": 4 * B * L * F * 4 + B * 2 * L * 4,
-                        "note": "one launch per encoder layer; the linear / feed-forward GEMMs of listsf are library calls"}
+                        "note": "one launch per encoder layer"}
             kernels["attention_backward"] = {"kernels": "attn_rowdot + mhsa_bwd_dq + mhsa_bwd_dkv", "avg_call_ms": t_ab,
                                              "achieved_TFLOPs": 2.5 * att_flop / (t_ab * 1e-3) / 1e12}
-            for nm in ("ptr_layernorm_forward", "ptr_layernorm_backward"):
+            for nm in ("ptr_layernorm_forward", "ptr_layernorm_backward", "ptr_linear_forward", "ptr_linear_backward"):
                 if avg_ms(nm):
-                    kernels[nm] = {"avg_launch_ms": avg_ms(nm), "hbm_GBps": (2 if "forward" in nm else 3) * B * L * F * 4 / (avg_ms(nm) * 1e-3) / 1e9}
-        else:   # scorer configuration not fusable: the north-star loss kernel is the only kernel of ours in the step
+                    kernels[nm] = {"avg_launch_ms": avg_ms(nm), "launches_per_step": len(timing[nm]) / args.steps}
+        else:   # scorer configuration not fusable: the loss kernel is the only kernel of ours in the step
             roofline = dict(kernels.get("lambdarank_loss_grad", kernels.get("loss_grad", {})))
         qps = world * B * args.steps / elapsed
+        step_alg_bytes = B * (2 * 4 * L * F + 12 * L + 4)
         out = {
-            "metric": ("queries/sec fwd+bwd LambdaRank, MSLR-WEB30K-shaped list_len=128"
-                       if (args.loss, L, F, args.scorer) == ("LambdaRank", 128, 136, "pointsf")
+            "metric": ("queries/sec fwd+bwd LambdaRank, MSLR-WEB30K-shaped list_len=128" if headline
                        else f"queries/sec fwd+bwd {args.loss}, synthetic list_len={L}, {F} feats"),
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": step_ms, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"{args.loss} train step (pointsf 3x100 ReLU scorer, dropout 0.1, Adam), " if args.scorer == "pointsf" else
                                     f"{args.loss} train step (listsf: 2-head 6-layer DASALC encoder + 128/256/512 feed-forward stacks, "
-                                    f"dropout 0.1, Adagrad), ") + f"MSLR-WEB30K-shaped synthetic, {F} feats, list_len={L}",
+                                    f"dropout 0.1, Adagrad), ") + f"MSLR-WEB30K-shaped synthetic, {F} feats, list_len={L}, "
+                                    f"{B} queries per GPU per step (`value`; by_batch = SURVEY 8(d) sweep, 1024 = the survey's headline batch)",
                        "queries_per_gpu_per_step": B, "global_batch": world * B, "list_len": L, "features": F,
-                       "parallelism": f"dp{world}", "resident_batches": len(batches)},
+                       "parallelism": f"dp{world}", "resident_batches": max(1, args.nbatches)},
+            "step_hbm_roofline": {"algorithmic_bytes_per_step": step_alg_bytes, "achieved_GBps": step_alg_bytes / (step_ms * 1e-3) / 1e9,
+                                  "frac_of_hbm_peak": step_alg_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                  "note": "SURVEY 8(d) end-to-end definition: 2*4*L*F + 12L + 4 bytes per query"},
             "roofline": roofline,
             "kernels": kernels,
+            "by_batch": by_batch,
             "final_epoch_loss": final_loss,
         }
         if world == 1 and not args.no_cpu_baseline and args.scorer == "pointsf":

@@ -17,6 +17,22 @@ import torch
 import torch.distributed as dist
 
 
+# Optional profiling hook (bench.py): TIMING = [] makes every gradient all-reduce record a (start, end) HIP event pair on the
+# current stream, so that a multi-GPU bench line can report what the exchange step costs.
+TIMING = None
+
+
+def _timed_all_reduce(t):
+    if TIMING is not None and t.is_cuda:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        ev1.record()
+        TIMING.append((ev0, ev1))
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
 def is_distributed():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
@@ -92,13 +108,13 @@ class FlatGradBucket:
 
     def all_reduce(self):
         if is_distributed():
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            _timed_all_reduce(self.flat)
 
 
 def all_reduce_sum(t):
     """In-place SUM all-reduce of one contiguous tensor (no-op when not distributed)."""
     if is_distributed():
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        _timed_all_reduce(t)
     return t
 
 
