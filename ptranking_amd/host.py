@@ -206,6 +206,11 @@ class DeviceTrainLoop:
         return epoch_loss, stop_training
 
     def train_op(self, batch_q_doc_vectors, batch_std_labels, **kwargs):
+        direct = getattr(self, "_direct_train_op", None)     # rankers.FusedStepMixin: five C-ABI calls instead of the autograd graph
+        if direct is not None:
+            out = direct(batch_q_doc_vectors, batch_std_labels, kwargs)
+            if out is not None:
+                return out
         stop_training = False
         self._batch_lens = kwargs.get('lens')          # padded batches: the listwise scorer masks padded documents as keys
         _reject_padding_with_batchnorm(self, self._batch_lens)

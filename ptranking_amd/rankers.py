@@ -9,13 +9,16 @@ interface: ptranking_amd.host.PointScorerRanker stand-alone, or the reference's 
 ptranking.base.adhoc_ranker.AdhocNeuralRanker when `ptranking_amd.install()` drops them into
 ptranking.ltr_adhoc.eval.ltr.
 """
+import ctypes as C
+
 import torch
 
+from . import _lib
 from . import dp
 from . import functional as F_
 from .host import DeviceEvaluator, DeviceTrainLoop, PointScorerRanker, is_multilabel
 from .listsf import FusedListScorerMixin
-from .scorer import FusedScorerMixin
+from .scorer import FlatAdam, FusedPointScorer, FusedScorerMixin
 
 RANKER_NAMES = ("RankNet", "LambdaRank", "LambdaLoss", "ApproxNDCG", "ListNet", "ListMLE", "STListNet", "RankCosine", "RankMSE", "SoftRank", "DASALC", "MDPRank")
 
@@ -43,6 +46,68 @@ class FusedStepMixin:
     data_parallel = True          # only takes effect when torch.distributed is initialised with world_size > 1
     _grad_bucket = None
     _dp_single = None
+
+    # ---- direct train step: scorer forward -> fused loss kernel -> scorer backward -> [all-reduce] -> Adam as five C-ABI calls
+    # One step of the autograd path costs ~0.37 ms of host time (autograd engine, tensor bookkeeping, optimizer hooks): at
+    # <= 1024 queries per step that is more than the GPU needs.  When the scorer is the fused pointsf scorer, the optimiser is
+    # FlatAdam and the ranker's loss is one of the single-kernel losses below, `DeviceTrainLoop.train_op` takes this path
+    # instead: the SAME kernels with the SAME arguments in the SAME order (bit-identical parameters), no autograd graph.
+    # A subclass that overrides custom_loss_function (the reference's plugin surface) is detected and keeps the autograd path.
+    use_direct_step = True
+    _direct_entry = None          # (C-ABI entry point, lambda self, kwargs: [loss parameters]) — set by the loss mixins that qualify
+    _direct_owner = None          # the class whose custom_loss_function the entry point implements
+
+    def _direct_check(self, kwargs):
+        """The reference's asserts of the loss (run on the direct path too)."""
+
+    def _direct_train_op(self, X, Y, kwargs):
+        spec = self._direct_entry
+        sf = getattr(self, "point_sf", None)
+        if (spec is None or not self.use_direct_step or not isinstance(sf, FusedPointScorer) or not isinstance(self.optimizer, FlatAdam)
+                or type(self).custom_loss_function is not self._direct_owner.custom_loss_function or not sf.training
+                or not torch.is_grad_enabled() or not (X.is_cuda and X.dim() == 3 and X.dtype == torch.float32 and X.is_contiguous())
+                or not (Y.is_cuda and Y.dtype == torch.float32 and Y.is_contiguous() and Y.shape == X.shape[:2])
+                or X.size(2) != sf.num_features or len(self.optimizer.param_groups) != 1):
+            return None
+        self._direct_check(kwargs)
+        lens = kwargs.get('lens')
+        if lens is not None and not (lens.is_cuda and lens.dtype == torch.int32 and lens.is_contiguous()):
+            return None
+        B, L, Fd = X.shape
+        R, NL, dev = B * L, sf.num_layers, X.device
+        cache = self.__dict__.setdefault("_direct_buffers", {})
+        buf = cache.get((B, L))
+        if buf is None:
+            if len(cache) >= 4:                      # a few length buckets at most: do not pin scratch for every shape ever seen
+                cache.pop(next(iter(cache)))
+            ndz = _lib.query("ptr_mlp_backward_dz_floats", R, Fd, NL)
+            buf = dict(preds=torch.empty((B, L), device=dev), acts=torch.empty((NL, R, 112), device=dev),
+                       loss_q=torch.empty(max(B, 1), device=dev), dpreds=torch.empty((B, L), device=dev),
+                       ws=torch.empty(_lib.query("ptr_mlp_backward_ws_floats", Fd, NL), device=dev),
+                       dz=torch.empty(ndz, device=dev) if ndz else None)
+            cache[(B, L)] = buf
+        flat = sf.flat
+        if flat.grad is None or flat.grad.shape != flat.shape or not flat.grad.is_contiguous():
+            flat.grad = torch.empty_like(flat)
+        p = sf.dropout
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0      # same CPU-generator draw as FusedPointScorer.forward
+        loss = torch.empty(1, device=dev)
+        entry, params = spec
+        with torch.cuda.device(dev):
+            st = _lib.current_stream(dev)
+            _lib.call("ptr_mlp_forward", _lib.ptr(X), _lib.ptr(flat), R, Fd, NL, 1, C.c_float(p), C.c_uint64(seed), _lib.ptr(buf["preds"]),
+                      _lib.ptr(buf["acts"]), st)
+            stop_training = False
+            if 'epoch_k' in kwargs and kwargs['epoch_k'] % self.stop_check_freq == 0:
+                stop_training = self.stop_training(buf["preds"])
+            _lib.call(entry, _lib.ptr(buf["preds"]), _lib.ptr(Y), _lib.ptr(lens), B, L, *params(self, kwargs), _lib.ptr(loss),
+                      _lib.ptr(buf["loss_q"]), _lib.ptr(buf["dpreds"]), st)
+            _lib.call("ptr_mlp_backward", _lib.ptr(X), _lib.ptr(flat), _lib.ptr(buf["acts"]), _lib.ptr(buf["dpreds"]), R, Fd, NL, C.c_float(p),
+                      C.c_uint64(seed), _lib.ptr(buf["dz"]), _lib.ptr(buf["ws"]), _lib.ptr(flat.grad), st)
+            if self.data_parallel and dp.is_distributed():
+                dp.all_reduce_sum(flat.grad)
+            self.optimizer.step_flat(flat)
+        return loss.reshape(()), stop_training
 
     def _bucket(self, extra=0):
         if self._grad_bucket is None or self._grad_bucket.extra != extra:
@@ -75,12 +140,20 @@ class FusedStepMixin:
 
 
 class RankNetLoss(FusedStepMixin):
+    _direct_entry = ("ptr_ranknet_fwd_bwd", lambda self, kw: [C.c_float(float(self.sigma))])
+
     def custom_loss_function(self, batch_preds, batch_std_labels, **kwargs):
         """ptranking/ltr_adhoc/pairwise/ranknet.py:25-42"""
         return self._fused_step(F_.ranknet_loss(batch_preds, batch_std_labels, sigma=self.sigma, lens=kwargs.get('lens')))
 
 
 class LambdaRankLoss(FusedStepMixin):
+    _direct_entry = ("ptr_lambdarank_fwd_bwd", lambda self, kw: [C.c_float(float(self.sigma))])
+
+    def _direct_check(self, kwargs):
+        assert 'label_type' in kwargs and is_multilabel(kwargs['label_type'])
+        assert 'presort' in kwargs and kwargs['presort'] is True  # aiming for direct usage of ideal ranking
+
     def custom_loss_function(self, batch_preds, batch_std_labels, **kwargs):
         """ptranking/ltr_adhoc/listwise/lambdarank.py:27-62"""
         assert 'label_type' in kwargs and is_multilabel(kwargs['label_type'])
@@ -89,6 +162,15 @@ class LambdaRankLoss(FusedStepMixin):
 
 
 class LambdaLossLoss(FusedStepMixin):
+    _direct_entry = ("ptr_lambdaloss_fwd_bwd",
+                     lambda self, kw: [int(self.k), C.c_float(float(self.sigma)), C.c_float(float(getattr(self, 'mu', 5.0))),
+                                       F_.LAMBDALOSS_TYPES[self.loss_type], int(bool('presort' in kw and kw['presort']))])
+
+    def _direct_check(self, kwargs):
+        assert is_multilabel(kwargs['label_type'])
+        if self.loss_type not in F_.LAMBDALOSS_TYPES:
+            raise NotImplementedError(f"LambdaLoss type {self.loss_type!r} (supported: {sorted(F_.LAMBDALOSS_TYPES)})")
+
     def custom_loss_function(self, batch_preds, batch_std_labels, **kwargs):
         """ptranking/ltr_adhoc/listwise/lambdaloss.py:73-138"""
         assert is_multilabel(kwargs['label_type'])
@@ -178,6 +260,8 @@ class MDPRankLoss(FusedStepMixin):
 
 
 class ListNetLoss(FusedStepMixin):
+    _direct_entry = ("ptr_listnet_fwd_bwd", lambda self, kw: [])
+
     def custom_loss_function(self, batch_preds, batch_std_labels, **kwargs):
         """ptranking/ltr_adhoc/listwise/listnet.py:22-45"""
         return self._fused_step(F_.listnet_loss(batch_preds, batch_std_labels, lens=kwargs.get('lens')))
@@ -244,6 +328,10 @@ class ListMLELoss(FusedStepMixin):
         lens = kwargs.get('lens')
         perm = self._shuffle_ties(batch_std_labels, lens)   # shuffle per epoch rather than using the same order for a query
         return self._fused_step(F_.listmle_loss(batch_preds, perm, lens=lens))
+
+
+for _cls in (RankNetLoss, LambdaRankLoss, LambdaLossLoss, ListNetLoss):
+    _cls._direct_owner = _cls
 
 
 def make_ranker_classes(base=PointScorerRanker):

@@ -151,6 +151,21 @@ class FlatAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
 
+    def _step_param(self, p, group):
+        if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()):
+            raise RuntimeError("FlatAdam needs contiguous CUDA float32 parameters / gradients")
+        st = self.state[p]
+        if not st:
+            st["step"] = 0
+            st["exp_avg"] = torch.zeros_like(p)
+            st["exp_avg_sq"] = torch.zeros_like(p)
+        st["step"] += 1
+        b1, b2 = group["betas"]
+        with torch.cuda.device(p.device):
+            _lib.call("ptr_adam_step", _lib.ptr(p), _lib.ptr(p.grad), _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]),
+                      C.c_int64(p.numel()), C.c_float(group["lr"]), C.c_float(b1), C.c_float(b2), C.c_float(group["eps"]),
+                      C.c_float(group["weight_decay"]), int(st["step"]), _lib.current_stream(p.device))
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -158,23 +173,16 @@ class FlatAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         for group in self.param_groups:
-            b1, b2 = group["betas"]
             for p in group["params"]:
-                if p.grad is None:
-                    continue
-                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()):
-                    raise RuntimeError("FlatAdam needs contiguous CUDA float32 parameters / gradients")
-                st = self.state[p]
-                if not st:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p)
-                    st["exp_avg_sq"] = torch.zeros_like(p)
-                st["step"] += 1
-                with torch.cuda.device(p.device):
-                    _lib.call("ptr_adam_step", _lib.ptr(p), _lib.ptr(p.grad), _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]),
-                              C.c_int64(p.numel()), C.c_float(group["lr"]), C.c_float(b1), C.c_float(b2), C.c_float(group["eps"]),
-                              C.c_float(group["weight_decay"]), int(st["step"]), _lib.current_stream(p.device))
+                if p.grad is not None:
+                    self._step_param(p, group)
         return loss
+
+    def step_flat(self, p):
+        """The update of `step()` for one parameter without torch.optim's per-call wrappers (profiler hooks, no_grad scope) —
+        the direct train step of rankers.FusedStepMixin.  Keeps `state` and the lr-scheduler's bookkeeping consistent."""
+        self._step_param(p, self.param_groups[0])
+        self._opt_called = True           # what torch.optim.lr_scheduler's wrapper of step() records
 
 
 class FusedScorerMixin:

@@ -187,3 +187,53 @@ def test_need_per_q_lists_hold_the_per_query_values():
             tot += got.sum(0)
             nq += len(ids)
         G.assert_close(avgs[mi].numpy(), (tot / nq).numpy(), f"{m} average = mean of the per-query values")
+
+
+@pytest.mark.parametrize("name,paras", [("RankNet", dict(sigma=1.0)), ("LambdaRank", dict(sigma=1.5)),
+                                        ("LambdaLoss", dict(k=5, sigma=1.0, mu=5.0, loss_type="NDCG_Loss2++")), ("ListNet", None)])
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_direct_train_step_is_bit_identical_to_the_autograd_path(name, paras, dropout):
+    """rankers.FusedStepMixin._direct_train_op issues the same kernels with the same arguments in the same order as
+    forward -> custom_loss_function (autograd): parameters, optimiser state and losses must agree bit for bit."""
+    import ptranking_amd as pa
+    sf = copy.deepcopy(SF)
+    sf["pointsf"].update(num_features=136, dropout=dropout)
+
+    def make(direct):
+        torch.manual_seed(11)
+        cls = getattr(pa, name)
+        r = cls(sf_para_dict=copy.deepcopy(sf), gpu=True, device="cuda:0") if paras is None else \
+            cls(sf_para_dict=copy.deepcopy(sf), model_para_dict=dict(paras), gpu=True, device="cuda:0")
+        r.init()
+        r.point_sf.dropout = dropout
+        r.train_mode()
+        r.use_direct_step = direct
+        return r
+
+    a, b = make(True), make(False)
+    X, Y = make_data(5, 9, 70, 136)
+    X, Y = X.cuda(), Y.cuda()
+    lens = torch.tensor([70, 3, 70, 1, 55, 70, 64, 65, 2], dtype=torch.int32, device="cuda")
+    for step, kw in enumerate([{}, {}, {"lens": lens}, {}]):
+        out = []
+        for r in (a, b):
+            torch.manual_seed(100 + step)                       # the dropout seed is drawn from torch's CPU generator
+            out.append(r.train_op(X, Y, epoch_k=1 if step else 10, presort=True, label_type=pa.LABEL_TYPE.MultiLabel, **kw))
+        (la, sa), (lb, sb) = out
+        assert sa == sb and torch.equal(la.reshape(()), lb.reshape(())), (step, la, lb)
+        assert torch.equal(a.point_sf.flat, b.point_sf.flat), step
+    sta, stb = a.optimizer.state[a.point_sf.flat], b.optimizer.state[b.point_sf.flat]
+    assert sta["step"] == stb["step"] == 4 and torch.equal(sta["exp_avg_sq"], stb["exp_avg_sq"])
+    assert "_direct_buffers" in a.__dict__ and "_direct_buffers" not in b.__dict__
+    a.scheduler.step()                                           # no "scheduler before optimizer" warning path
+
+    class Custom(type(a)):                                       # a plugin that overrides the loss keeps the autograd path
+        def custom_loss_function(self, batch_preds, batch_std_labels, **kwargs):
+            self.seen = True
+            return super().custom_loss_function(batch_preds, batch_std_labels, **kwargs)
+
+    c = Custom(sf_para_dict=copy.deepcopy(sf), gpu=True, device="cuda:0") if paras is None else \
+        Custom(sf_para_dict=copy.deepcopy(sf), model_para_dict=dict(paras), gpu=True, device="cuda:0")
+    c.init(); c.train_mode()
+    c.train_op(X, Y, epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
+    assert getattr(c, "seen", False) and "_direct_buffers" not in c.__dict__
