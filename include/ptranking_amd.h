@@ -168,6 +168,35 @@ int ptr_adam_step(float *param, const float *grad, float *exp_avg, float *exp_av
 /* Test helper: the dropout keep-mask (1.0 / 0.0) of dropout site `site` for an [R][n_feat] activation. */
 int ptr_mlp_dropout_mask(int R, int n_feat, int site, float p_drop, uint64_t seed, float *out, void *stream);
 
+/* ---- linear layers of the scoring functions (hand-written fp32-MFMA kernels, csrc/linear.hip) -------------------------------
+ * Replace the library GEMMs behind the reference's nn.Linear modules: the stacked feed-forward nets of
+ * ptranking/base/utils.py:288-356 (pointsf with any activation / batch norm; the listsf head / tail stacks, ff_dims 128/256/512)
+ * and the Q|K|V / fc projections of ptranking/base/list_ranker.py:176-254.  Row-major operands with explicit leading dimensions
+ * (so packed buffers such as [R][3F] are read / written in place); W is nn.Linear's [N][K] weight.
+ *   ptr_linear_forward          Y[R][N] = epi(X[R][K] W^T + bias)   epi: PTR_LINEAR_NONE | _RELU | _RELU_DROPOUT (ReLU, then the
+ *                               NEXT layer's dropout from the counter-based generator (seed, site): the stored value is that
+ *                               layer's input and `a > 0` encodes "ReLU active and kept")
+ *   ptr_linear_backward_input   dX[R][K] = dY[R][N] W, optionally gated: dX *= [gate > 0] / (1 - p_drop)  (gate = the stored
+ *                               _RELU_DROPOUT output of the layer below, NULL = no gate)
+ *   ptr_linear_backward_weight  dW[N][K] = dY^T X, db[N] = column sums of dY (NULL = skip); ws = ptr_linear_backward_weight_ws_floats
+ *                               floats of scratch; deterministic (fixed-order reduction of row chunks)                          */
+#define PTR_LINEAR_NONE 0
+#define PTR_LINEAR_RELU 1
+#define PTR_LINEAR_RELU_DROPOUT 2
+#define PTR_LINEAR_GATE 3          /* internal: the epilogue of ptr_linear_backward_input */
+int ptr_linear_forward(const float *X, int ldx, const float *W, const float *bias, int R, int K, int N, int act, float p_drop,
+                       uint64_t seed, int site, float *Y, int ldy, void *stream);
+int ptr_linear_backward_input(const float *dY, int ldy, const float *W, int R, int K, int N, const float *gate, int ldg, float p_drop,
+                              float *dX, int ldx, void *stream);
+size_t ptr_linear_backward_weight_ws_floats(int R, int K, int N);
+int ptr_linear_backward_weight(const float *X, int ldx, const float *dY, int ldy, int R, int K, int N, float *ws, float *dW, float *db,
+                               void *stream);
+/* nn.Dropout in front of a stack's first Linear (utils.py:299): out = x * keep(seed, site, row, col) / (1 - p); the backward is the
+ * same call on the incoming gradient (the mask is recomputed).  C, ldx, ldo multiples of 4, 16-byte aligned pointers. */
+int ptr_dropout_apply(const float *x, int ldx, int R, int C, float p_drop, uint64_t seed, int site, float *out, int ldo, void *stream);
+/* out = dy * [y > 0]: backward of a trailing ReLU (the `apply_tl_af` activation of the listsf head stack, list_ranker.py:318). */
+int ptr_relu_gate(const float *dy, const float *y, int64_t n, float *out, void *stream);
+
 /* ---- listsf: the permutation-equivariant scorer's fused pieces (fp32 MFMA attention core, the reference's LayerNorm) ----
  * ptr_mhsa_forward replaces ptranking/base/list_ranker.py:216-240 (Q K^T / sqrt(d_h) -> softmax -> Dropout -> . V, heads = column
  * blocks of width F / n_heads of the [B][L][F] projections Q, K, V; the output O has the same layout, i.e. what

@@ -21,6 +21,7 @@ import torch.optim as optim
 from torch.optim.lr_scheduler import StepLR
 
 from . import dp
+from .linear import FusedLinear, ReluStack
 from . import functional as F_
 from .batching import unpack_batch
 
@@ -276,50 +277,9 @@ class _BatchNormPerQuery(nn.Module):
         return Y * self.weight + self.bias if self.affine else Y
 
 
-class _SplitKLinearFn(torch.autograd.Function):
-    """y = x W^T + b with a weight gradient that fills the GPU.  dW = dY^T X is a [out, in] result contracted over ALL documents
-    of the batch (K = B*L ~ 10^5..10^6): the library GEMM picks one macro-tile per 32x32 outputs and no split-K, i.e. ~25
-    workgroups on 256 CUs for a 136x136 layer (measured 680 us where 30 us suffice).  Here the rows are cut into chunks of
-    `CHUNK` documents, one batched library GEMM produces [S, out, in] partial sums and a fixed-order sum reduces them —
-    deterministic, and every CU has work."""
-
-    CHUNK = 1024
-
-    @staticmethod
-    def forward(ctx, x, weight, bias):
-        x2 = x.reshape(-1, x.shape[-1])
-        ctx.save_for_backward(x2, weight)
-        ctx.has_bias = bias is not None
-        # x @ W^T on a transposed COPY of the small weight: for these tall-skinny shapes the library's kernel for a transposed
-        # B operand runs at less than half the speed of the plain one (311 vs 137 us at 262144 x 136 x 136, rocprofv3)
-        wt = weight.t().contiguous()
-        y = torch.addmm(bias, x2, wt) if bias is not None else x2 @ wt
-        return y.view(*x.shape[:-1], weight.shape[0])
-
-    @staticmethod
-    def backward(ctx, dy):
-        x2, weight = ctx.saved_tensors
-        dy2 = dy.reshape(-1, dy.shape[-1])
-        dx = (dy2 @ weight).view(*dy.shape[:-1], weight.shape[1]) if ctx.needs_input_grad[0] else None
-        R, ck = x2.shape[0], _SplitKLinearFn.CHUNK
-        S = R // ck
-        if S >= 8:
-            main = S * ck
-            part = torch.bmm(dy2[:main].view(S, ck, -1).transpose(1, 2), x2[:main].view(S, ck, -1))       # [S, out, in]
-            dw = part.sum(dim=0)
-            if main < R:
-                dw = dw + dy2[main:].t() @ x2[main:]
-        else:
-            dw = dy2.t() @ x2
-        db = dy2.sum(dim=0) if ctx.has_bias else None
-        return dx, dw, db
-
-
-class SplitKLinear(nn.Linear):
-    """nn.Linear (same parameters, initialisation and state_dict) whose backward computes dW with the split-K scheme above."""
-
-    def forward(self, x):
-        return _SplitKLinearFn.apply(x, self.weight, self.bias)
+# nn.Linear on the hand-written fp32-MFMA kernels (csrc/linear.hip): forward, backward-input and a split-row backward-weight with a
+# fixed-order reduction.  (Round 1 ran library GEMMs here, with a split-K wrapper around the library's 25-workgroup dW kernel.)
+SplitKLinear = FusedLinear
 
 
 def build_stacked_ffnet(ff_dims, AF=None, TL_AF=None, apply_tl_af=False, dropout=0.1, BN=True, bn_type=None, bn_affine=False,
@@ -336,7 +296,12 @@ def build_stacked_ffnet(ff_dims, AF=None, TL_AF=None, apply_tl_af=False, dropout
             return _BatchNormPerQuery(dim, momentum=0.1, affine=bn_affine, device=device)
         raise NotImplementedError(f"bn_type={bn_type!r}")
 
-    net = nn.Sequential()
+    # AF='R' without batch norm (the listsf stacks, the pointsf configurations the single-kernel scorer does not take): the whole
+    # stack runs as one fused autograd node — ReLU / dropout in the producing kernel's epilogue (ptranking_amd/linear.py)
+    fuse_relu = AF == 'R' and not BN and (not apply_tl_af or TL_AF == 'R')
+    net = ReluStack() if fuse_relu else nn.Sequential()
+    if fuse_relu:
+        net.tail_relu = bool(apply_tl_af)
     n = len(ff_dims)
     for i in range(1, n - 1):
         net.add_module(f'dr_{i}', nn.Dropout(dropout))

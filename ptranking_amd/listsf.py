@@ -22,7 +22,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .host import SplitKLinear, _SplitKLinearFn, build_stacked_ffnet
+from .host import SplitKLinear, build_stacked_ffnet
+from .linear import linear
 
 MAX_HEAD_DIM = 128        # PTR_MHSA_MAX_HEAD_DIM
 Encoder_Type = ['DASALC', 'AllRank', 'AttnDIN']   # list_ranker.py:13
@@ -209,7 +210,7 @@ class MultiheadAttention(nn.Module):
         # column blocks the attention kernels read in place (the concatenation of three F x F matrices is negligible)
         w = torch.cat([self.w_q.weight, self.w_k.weight, self.w_v.weight], dim=0)
         b = torch.cat([self.w_q.bias, self.w_k.bias, self.w_v.bias], dim=0)
-        qkv = _SplitKLinearFn.apply(batch_rankings, w, b)
+        qkv = linear(batch_rankings, w, b)
         p = self.do_dropout.p if self.training else 0.0
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0      # CPU generator: no device sync
         x = mhsa_core_packed(qkv, self.n_heads, p_drop=p, seed=seed, site=self.site, lens=lens)

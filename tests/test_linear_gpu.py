@@ -1,0 +1,130 @@
+"""GPU: the hand-written linear-layer kernels (csrc/linear.hip) and the fused (Dropout -> Linear -> ReLU)* stack against plain
+torch fp32 modules evaluated on the CPU (the reference's arithmetic), incl. odd shapes, strided inputs and the kernel's own dropout
+masks fed to the torch side."""
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, tol=2e-5, what=""):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, f"{what}: max|diff|={err:.3e} > {tol * scale:.3e}"
+
+
+@pytest.mark.parametrize("R,K,N", [(1000, 136, 128), (777, 128, 256), (515, 256, 512), (300, 512, 136), (2049, 136, 408), (640, 136, 136),
+                                   (333, 512, 1), (100, 10, 100), (65, 100, 1), (4096, 46, 100), (50, 7, 5), (1, 136, 128)])
+@pytest.mark.parametrize("bias", [True, False])
+def test_linear_forward_backward_match_torch_cpu(R, K, N, bias):
+    from ptranking_amd.linear import linear
+    torch.manual_seed(R + K + N)
+    x = torch.randn(R, K)
+    w = torch.randn(N, K) / K ** 0.5
+    b = torch.randn(N) if bias else None
+    g = torch.randn(R, N)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    yr = torch.nn.functional.linear(xr, wr, br)
+    yr.backward(g)
+    xg, wg = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    bg = b.cuda().requires_grad_(True) if bias else None
+    y = linear(xg, wg, bg)
+    y.backward(g.cuda())
+    close(y, yr, what="y")
+    close(xg.grad, xr.grad, what="dx")
+    close(wg.grad, wr.grad, tol=5e-5, what="dw")
+    if bias:
+        close(bg.grad, br.grad, tol=5e-5, what="db")
+
+
+def test_linear_reads_strided_rows_in_place_and_is_bit_stable():
+    from ptranking_amd.linear import linear
+    torch.manual_seed(0)
+    big = torch.randn(700, 408, device="cuda")
+    x = big[:, 136:272]                              # a column block of a packed [R, 3F] buffer (row stride 408)
+    w = torch.randn(64, 136, device="cuda", requires_grad=True)
+    y = linear(x, w)
+    close(y, x.contiguous().cpu() @ w.detach().cpu().t(), what="strided")
+    y.sum().backward()
+    g1 = w.grad.clone()
+    w.grad = None
+    linear(x, w).sum().backward()
+    assert torch.equal(g1, w.grad)
+    x3 = torch.randn(5, 40, 136, device="cuda", requires_grad=True)      # [B, L, K] inputs keep their leading shape
+    y3 = linear(x3, w)
+    assert y3.shape == (5, 40, 64)
+    y3.sum().backward()
+    assert x3.grad.shape == x3.shape
+
+
+def _ref_stack(dims, tail_relu, masks, p, params):
+    """torch-CPU restatement of the stack with explicit keep masks (what nn.Dropout does: x * mask / (1 - p))."""
+    def f(x):
+        n = len(dims) - 1
+        a = x * masks[0] / (1 - p) if masks[0] is not None else x
+        for i in range(n - 1):
+            a = torch.relu(torch.nn.functional.linear(a, params[2 * i], params[2 * i + 1]))
+            if i < n - 2 and masks[i + 1] is not None:
+                a = a * masks[i + 1] / (1 - p)
+        out = torch.nn.functional.linear(a, params[-2], params[-1])
+        return torch.relu(out) if tail_relu else out
+    return f
+
+
+@pytest.mark.parametrize("dims,tail_relu", [([136, 128, 256, 512, 136], True), ([136, 128, 256, 512, 1], False), ([24, 100, 100, 100, 1], False),
+                                            ([136, 64, 1], False), ([40, 8], False)])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_relu_stack_matches_torch_cpu_with_the_kernels_own_masks(dims, tail_relu, p):
+    from ptranking_amd.host import build_stacked_ffnet
+    from ptranking_amd.linear import ReluStack
+    from ptranking_amd import _lib
+    import ctypes as C
+    torch.manual_seed(sum(dims))
+    net = build_stacked_ffnet(dims, AF='R', TL_AF='R', apply_tl_af=tail_relu, dropout=p, BN=False).cuda()
+    assert isinstance(net, ReluStack)
+    net.train()
+    R = 777
+    x = torch.randn(3, R // 3, dims[0], device="cuda", requires_grad=True)
+    out = net(x)
+    assert out.shape == (3, R // 3, dims[-1])
+    g = torch.randn_like(out)
+    out.backward(g)
+    seed = net.last_seed
+    n = len(dims) - 1
+
+    def mask(site, width):                       # keep mask of dropout site `site` = ptr_dropout_apply on ones * (1 - p)
+        if p == 0.0 or n == 1:
+            return None
+        ones = torch.ones(R, width, device="cuda")
+        m = torch.empty_like(ones)
+        if width % 4 == 0:
+            _lib.call("ptr_dropout_apply", _lib.ptr(ones), width, R, width, C.c_float(p), C.c_uint64(seed), site, _lib.ptr(m), width,
+                      _lib.current_stream(ones.device))
+            return (m > 0).float().cpu()
+        return None
+    masks = [mask(0, dims[0])] + [mask(i + 1, dims[i + 1]) for i in range(n - 2)] + [None]
+    params = []
+    for m_ in net:
+        if isinstance(m_, nn.Linear):
+            params += [m_.weight.detach().cpu().clone().requires_grad_(True), m_.bias.detach().cpu().clone().requires_grad_(True)]
+    xr = x.detach().cpu().reshape(R, dims[0]).clone().requires_grad_(True)
+    ref = _ref_stack(dims, tail_relu, masks, p, params)(xr)
+    ref.backward(g.cpu().reshape(R, dims[-1]))
+    close(out.reshape(R, -1), ref, what="out")
+    close(x.grad.reshape(R, -1), xr.grad, tol=5e-5, what="dx")
+    lins = [m_ for m_ in net if isinstance(m_, nn.Linear)]
+    for i, m_ in enumerate(lins):
+        close(m_.weight.grad, params[2 * i].grad, tol=5e-5, what=f"dW{i}")
+        close(m_.bias.grad, params[2 * i + 1].grad, tol=5e-5, what=f"db{i}")
+    if p > 0 and n > 1:
+        keep = masks[0].mean().item()
+        assert abs(keep - (1 - p)) < 0.01
+    # eval mode: no dropout, deterministic
+    net.eval()
+    with torch.no_grad():
+        a, b = net(x), net(x)
+    assert torch.equal(a, b)
+    assert list(net.state_dict()) == [f"ff_{i + 2}.{k}" for i in range(n) for k in ("weight", "bias")]
