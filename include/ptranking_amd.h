@@ -197,6 +197,31 @@ int ptr_dropout_apply(const float *x, int ldx, int R, int C, float p_drop, uint6
 /* out = dy * [y > 0]: backward of a trailing ReLU (the `apply_tl_af` activation of the listsf head stack, list_ranker.py:318). */
 int ptr_relu_gate(const float *dy, const float *y, int64_t n, float *out, void *stream);
 
+/* ---- batch normalisation + activation + dropout of the stacked feed-forward nets (csrc/bnact.hip) --------------------------
+ * One hidden layer of get_stacked_FFNet (ptranking/base/utils.py:296-315) is Dropout -> Linear -> [LTRBatchNorm] -> AF; the default
+ * pointsf (ptranking/ltr_adhoc/eval/parameter.py:145-146) is 5 x [.. -> BN(affine) -> GELU] -> Linear -> BN -> Sigmoid.  Around
+ * ptr_linear_*:  ptr_bn_stats = LTRBatchNorm's batch statistics (utils.py:201-223: BatchNorm1d without running statistics — batch
+ * statistics in training and evaluation, biased variance, two-pass), ptr_bnact_forward = dropout_next(AF(gamma * xhat + beta)),
+ * ptr_bnact_backward = the backward of all three (dropout mask and activation derivative recomputed from the stored
+ * pre-normalisation z; BatchNorm's two column sums reduced in a fixed order), also yielding dgamma / dbeta.
+ * Activations = the working entries of get_AF (utils.py:100-143).  mean == NULL: no batch norm; gamma / beta NULL: no affine. */
+#define PTR_AF_NONE 0
+#define PTR_AF_RELU 1      /* 'R'  */
+#define PTR_AF_LEAKY 2     /* 'LR' */
+#define PTR_AF_ELU 3       /* 'E' and 'CE' (alpha = 1) */
+#define PTR_AF_SELU 4      /* 'SE' */
+#define PTR_AF_GELU 5      /* 'GE' (erf form) */
+#define PTR_AF_SIGMOID 6   /* 'S'  */
+#define PTR_AF_TANH 7      /* 'T'  */
+size_t ptr_bn_ws_floats(int R, int N);
+int ptr_bn_stats(const float *z, int ld, int R, int N, float eps, float *ws, float *mean, float *rstd, void *stream);
+int ptr_bnact_forward(const float *z, int ld, int R, int N, const float *mean, const float *rstd, const float *gamma, const float *beta,
+                      int af, float p_drop, uint64_t seed, int site, float *out, void *stream);
+/* ws: ptr_bn_ws_floats(R, N) + 2 * N floats (only read / written with batch norm) */
+int ptr_bnact_backward(const float *z, const float *da, int ld, int R, int N, const float *mean, const float *rstd, const float *gamma,
+                       const float *beta, int af, float p_drop, uint64_t seed, int site, float *ws, float *dz, float *dgamma,
+                       float *dbeta, void *stream);
+
 /* ---- listsf: the permutation-equivariant scorer's fused pieces (fp32 MFMA attention core, the reference's LayerNorm) ----
  * ptr_mhsa_forward replaces ptranking/base/list_ranker.py:216-240 (Q K^T / sqrt(d_h) -> softmax -> Dropout -> . V, heads = column
  * blocks of width F / n_heads of the [B][L][F] projections Q, K, V; the output O has the same layout, i.e. what

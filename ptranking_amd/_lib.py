@@ -47,6 +47,10 @@ SIGNATURES = {
     "ptr_linear_backward_input": [_vp, _i, _vp, _i, _i, _i, _vp, _i, _f, _vp, _i, _vp],
     "ptr_linear_backward_weight_ws_floats": [_i, _i, _i],
     "ptr_linear_backward_weight": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "ptr_bn_ws_floats": [_i, _i],
+    "ptr_bn_stats": [_vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
+    "ptr_bnact_forward": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _u64, _i, _vp, _vp],
+    "ptr_bnact_backward": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _u64, _i, _vp, _vp, _vp, _vp, _vp],
     "ptr_dropout_apply": [_vp, _i, _i, _i, _f, _u64, _i, _vp, _i, _vp],
     "ptr_relu_gate": [_vp, _vp, C.c_int64, _vp, _vp],
     "ptr_mhsa_forward": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _u64, _i, _vp, _vp, _vp],
@@ -59,7 +63,7 @@ SIGNATURES = {
     "ptr_letor_load": [C.c_char_p, _i, _f, C.c_int64, C.c_int32, C.c_int64, _vp, _i, _vp, _vp, _vp],
 }
 _RESTYPES = {"ptr_last_error": C.c_char_p, "ptr_mlp_num_params": C.c_size_t, "ptr_mlp_backward_ws_floats": C.c_size_t,
-             "ptr_mlp_backward_dz_floats": C.c_size_t, "ptr_linear_backward_weight_ws_floats": C.c_size_t,
+             "ptr_mlp_backward_dz_floats": C.c_size_t, "ptr_linear_backward_weight_ws_floats": C.c_size_t, "ptr_bn_ws_floats": C.c_size_t,
              "ptr_layernorm_backward_ws_floats": C.c_size_t}
 OPTIONAL = set()
 

@@ -21,7 +21,7 @@ import torch.optim as optim
 from torch.optim.lr_scheduler import StepLR
 
 from . import dp
-from .linear import FusedLinear, ReluStack
+from .linear import FusedLinear, FusedStack
 from . import functional as F_
 from .batching import unpack_batch
 
@@ -296,12 +296,9 @@ def build_stacked_ffnet(ff_dims, AF=None, TL_AF=None, apply_tl_af=False, dropout
             return _BatchNormPerQuery(dim, momentum=0.1, affine=bn_affine, device=device)
         raise NotImplementedError(f"bn_type={bn_type!r}")
 
-    # AF='R' without batch norm (the listsf stacks, the pointsf configurations the single-kernel scorer does not take): the whole
-    # stack runs as one fused autograd node — ReLU / dropout in the producing kernel's epilogue (ptranking_amd/linear.py)
-    fuse_relu = AF == 'R' and not BN and (not apply_tl_af or TL_AF == 'R')
-    net = ReluStack() if fuse_relu else nn.Sequential()
-    if fuse_relu:
-        net.tail_relu = bool(apply_tl_af)
+    # On the GPU the whole stack runs as one autograd node on the hand-written kernels (ptranking_amd/linear.py: FusedStack): GEMM
+    # epilogues for ReLU / dropout, layer-wise statistics for bn_type='BN', every working activation of get_AF
+    net = FusedStack()
     n = len(ff_dims)
     for i in range(1, n - 1):
         net.add_module(f'dr_{i}', nn.Dropout(dropout))

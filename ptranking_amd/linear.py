@@ -158,21 +158,208 @@ class _ReluStackFn(torch.autograd.Function):
         return (None, None, None, None, *grads)
 
 
-class ReluStack(nn.Sequential):
-    """The Sequential get_stacked_FFNet builds for AF='R', BN=False (module names and state_dict as the reference's), evaluated as
-    one fused autograd node on the GPU.  `tail_relu`: apply_tl_af with TL_AF='R' (the listsf head stack, list_ranker.py:318)."""
+AF_CODE = {nn.ReLU: 1, nn.LeakyReLU: 2, nn.ELU: 3, nn.CELU: 3, nn.SELU: 4, nn.GELU: 5, nn.Sigmoid: 6, nn.Tanh: 7}   # PTR_AF_*
+BN_EPS = 1e-5            # nn.BatchNorm1d's default, what LTRBatchNorm builds (utils.py:214)
 
-    tail_relu = False
+
+def _af_code(m):
+    code = AF_CODE.get(type(m))
+    if code is None:
+        return None
+    if isinstance(m, nn.LeakyReLU) and m.negative_slope != 0.01:
+        return None
+    if isinstance(m, (nn.ELU, nn.CELU)) and m.alpha != 1.0:
+        return None
+    if isinstance(m, nn.GELU) and getattr(m, "approximate", "none") != "none":
+        return None
+    return code
+
+
+def _bn_stats(z):
+    R, N = z.shape
+    dev = z.device
+    ws = torch.empty(_lib.query("ptr_bn_ws_floats", R, N), device=dev, dtype=torch.float32)
+    mean = torch.empty(N, device=dev, dtype=torch.float32)
+    rstd = torch.empty(N, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _lib.call("ptr_bn_stats", _lib.ptr(z), N, R, N, C.c_float(BN_EPS), _lib.ptr(ws), _lib.ptr(mean), _lib.ptr(rstd), _lib.current_stream(dev))
+    return mean, rstd
+
+
+def _bnact_fwd(z, mean, rstd, gamma, beta, af, p, seed, site):
+    R, N = z.shape
+    out = torch.empty_like(z)
+    with torch.cuda.device(z.device):
+        _lib.call("ptr_bnact_forward", _lib.ptr(z), N, R, N, _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(beta), af, C.c_float(p),
+                  C.c_uint64(seed), site, _lib.ptr(out), _lib.current_stream(z.device))
+    return out
+
+
+def _bnact_bwd(z, da, mean, rstd, gamma, beta, af, p, seed, site):
+    R, N = z.shape
+    dev = z.device
+    has_bn = mean is not None
+    ws = torch.empty(_lib.query("ptr_bn_ws_floats", R, N) + 2 * N, device=dev, dtype=torch.float32) if has_bn else None
+    dz = torch.empty_like(z)
+    dg = torch.empty(N, device=dev, dtype=torch.float32) if (has_bn and gamma is not None) else None
+    db = torch.empty(N, device=dev, dtype=torch.float32) if (has_bn and beta is not None) else None
+    with torch.cuda.device(dev):
+        _lib.call("ptr_bnact_backward", _lib.ptr(z), _lib.ptr(da), N, R, N, _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(beta), af,
+                  C.c_float(p), C.c_uint64(seed), site, _lib.ptr(ws), _lib.ptr(dz), _lib.ptr(dg), _lib.ptr(db), _lib.current_stream(dev))
+    return dz, dg, db
+
+
+class _StackFn(torch.autograd.Function):
+    """The general stack of get_stacked_FFNet (utils.py:288-356): [Dropout -> Linear -> [BN] -> AF]* -> Linear [-> [BN] -> TL_AF], layer by
+    layer on our kernels: linear -> column statistics -> (normalise, activate, next layer's dropout).  Only the pre-normalisation z
+    and the layer inputs are kept for backward.  spec = (n_linear, [af codes of the hidden layers], tail af or 0, has_bn)."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed, spec, *params):
+        n, afs, tail_af, has_bn = spec
+        per = 4 if has_bn else 2
+        x2, ldx = _rows(x)
+        dev = x2.device
+        R, K0 = x2.shape
+        if n > 1 and p > 0.0:
+            if K0 % 4 or ldx % 4:
+                raise NotImplementedError("input width must be a multiple of 4 for the fused dropout")
+            a = torch.empty((R, K0), device=dev, dtype=torch.float32)
+            with torch.cuda.device(dev):
+                _lib.call("ptr_dropout_apply", _lib.ptr(x2), ldx, R, K0, C.c_float(p), C.c_uint64(seed), 0, _lib.ptr(a), K0, _lib.current_stream(dev))
+            ins, lda = [a], K0
+        else:
+            ins, lda = [x2], ldx
+        zs, stats = [], []
+        for i in range(n):
+            W, b = params[per * i], params[per * i + 1]
+            gamma, beta = (params[per * i + 2], params[per * i + 3]) if has_bn else (None, None)
+            z = _fwd(ins[-1], lda if i == 0 else ins[-1].shape[1], W, b)
+            hidden = i < n - 1
+            af = afs[i] if hidden else tail_af
+            if not hidden and af == 0:
+                out = z
+                zs.append(None); stats.append((None, None))
+                break
+            mean, rstd = _bn_stats(z) if has_bn else (None, None)
+            pd = p if (hidden and i < n - 2) else 0.0          # the dropout in front of the NEXT hidden Linear
+            a = _bnact_fwd(z, mean, rstd, gamma, beta, af, pd, seed, i + 1)
+            zs.append(z); stats.append((mean, rstd))
+            if hidden:
+                ins.append(a)
+            else:
+                out = a
+        flat_stats = [t for ms in stats for t in ms]
+        ctx.save_for_backward(*ins, *zs, *flat_stats, *params)
+        ctx.meta = (n, p, seed, spec, lda)
+        return out.view(*x.shape[:-1], out.shape[1])
+
+    @staticmethod
+    def backward(ctx, dout):
+        n, p, seed, spec, lda = ctx.meta
+        _, afs, tail_af, has_bn = spec
+        per = 4 if has_bn else 2
+        sv = ctx.saved_tensors
+        ins, zs, fs, params = sv[:n], sv[n:2 * n], sv[2 * n:4 * n], sv[4 * n:]
+        dev = dout.device
+        d = dout.reshape(-1, dout.shape[-1]).contiguous()
+        grads = [None] * len(params)
+        for i in range(n - 1, -1, -1):
+            W = params[per * i]
+            gamma, beta = (params[per * i + 2], params[per * i + 3]) if has_bn else (None, None)
+            hidden = i < n - 1
+            af = afs[i] if hidden else tail_af
+            if hidden or af != 0:
+                pd = p if (hidden and i < n - 2) else 0.0
+                d, dg, dbt = _bnact_bwd(zs[i], d, fs[2 * i], fs[2 * i + 1], gamma, beta, af, pd, seed, i + 1)
+                if has_bn:
+                    grads[per * i + 2], grads[per * i + 3] = dg, dbt
+            a_in = ins[i]
+            dw, db = _bwd_weight(a_in, lda if i == 0 else a_in.shape[1], d, params[per * i + 1] is not None)
+            grads[per * i], grads[per * i + 1] = dw, db
+            if i > 0:
+                d = _bwd_input(d, W)
+            elif ctx.needs_input_grad[0]:
+                dx = _bwd_input(d, W)
+                if n > 1 and p > 0.0:
+                    dxd = torch.empty_like(dx)
+                    with torch.cuda.device(dev):
+                        _lib.call("ptr_dropout_apply", _lib.ptr(dx), dx.shape[1], dx.shape[0], dx.shape[1], C.c_float(p), C.c_uint64(seed), 0,
+                                  _lib.ptr(dxd), dx.shape[1], _lib.current_stream(dev))
+                    dx = dxd
+                return (dx.view(*dout.shape[:-1], W.shape[1]), None, None, None, *grads)
+        return (None, None, None, None, *grads)
+
+
+class FusedStack(nn.Sequential):
+    """The Sequential get_stacked_FFNet builds (module names and state_dict as the reference's: dr_i / ff_{i+1} / bn_{i+1} / act_{i+1}),
+    evaluated on the GPU as ONE autograd node on the hand-written kernels:
+      * AF='R' without batch norm: ReLU and the next layer's dropout in the producing GEMM's epilogue (`_ReluStackFn`);
+      * any other working activation of get_AF and / or bn_type='BN' (the reference's DEFAULT pointsf: 5 x [BN(affine) -> GELU],
+        Sigmoid tail): layer-wise linear -> statistics -> normalise / activate / dropout (`_StackFn`).
+    A structure it does not recognise (bn_type='BN2', RReLU, ...) runs module by module (FusedLinear GEMMs + torch elementwise)."""
+
+    tail_relu = False        # kept for the pure-ReLU fast path
+    _plan = None
+
+    def _make_plan(self):
+        mods = list(self)
+        lins, afs, bns, drops = [], [], [], []
+        i = 0
+        cur = None
+        for m in mods:
+            if isinstance(m, nn.Dropout):
+                drops.append(m)
+            elif isinstance(m, nn.Linear):
+                cur = {"lin": m, "bn": None, "af": 0}
+                lins.append(cur)
+            elif type(m).__name__ in ("_BatchNormOverDocs", "LTRBatchNorm"):
+                if cur is None or cur["bn"] is not None or cur["af"] != 0:
+                    return None
+                cur["bn"] = m.bn
+            elif _af_code(m) is not None:
+                if cur is None or cur["af"] != 0:
+                    return None
+                cur["af"] = _af_code(m)
+            else:
+                return None
+        if not lins or any(l["af"] == 0 for l in lins[:-1]):
+            return None
+        has_bn = any(l["bn"] is not None for l in lins)
+        if has_bn and (any(l["bn"] is None for l in lins[:-1]) or (lins[-1]["af"] != 0) != (lins[-1]["bn"] is not None)):
+            return None
+        if has_bn and any(l["bn"] is not None and (l["bn"].track_running_stats or l["bn"].eps != BN_EPS) for l in lins):
+            return None
+        if len(drops) not in (0, len(lins) - 1) or len({d.p for d in drops}) > 1:
+            return None
+        relu_only = not has_bn and all(l["af"] == 1 for l in lins[:-1]) and lins[-1]["af"] in (0, 1)
+        return dict(lins=lins, has_bn=has_bn, relu_only=relu_only, p=drops[0].p if drops else 0.0)
 
     def forward(self, x):
         if not x.is_cuda:
             return super().forward(x)
-        lins = [m for m in self if isinstance(m, nn.Linear)]
-        drops = [m for m in self if isinstance(m, nn.Dropout)]
-        p = drops[0].p if (drops and self.training) else 0.0
+        if self._plan is None:
+            self._plan = self._make_plan() or False
+        plan = self._plan
+        if plan is False:
+            return super().forward(x)
+        lins = plan["lins"]
+        p = plan["p"] if self.training else 0.0
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0      # CPU generator: no device sync
         self.last_seed = seed
+        if plan["relu_only"]:
+            params = []
+            for l in lins:
+                params += [l["lin"].weight, l["lin"].bias]
+            return _ReluStackFn.apply(x, float(p), seed, lins[-1]["af"] == 1, *params)
         params = []
-        for m in lins:
-            params += [m.weight, m.bias]
-        return _ReluStackFn.apply(x, float(p), seed, bool(self.tail_relu), *params)
+        for l in lins:
+            params += [l["lin"].weight, l["lin"].bias]
+            if plan["has_bn"]:
+                bn = l["bn"]
+                params += [bn.weight if bn is not None else None, bn.bias if bn is not None else None]
+        spec = (len(lins), tuple(l["af"] for l in lins[:-1]), lins[-1]["af"], plan["has_bn"])
+        return _StackFn.apply(x, float(p), seed, spec, *params)
+
+
+ReluStack = FusedStack

@@ -20,17 +20,35 @@ HIDDEN = 100   # ptranking/base/point_ranker.py:30
 ACT_LD = 112   # PTR_MLP_ACT_LD: leading dimension of the stored activations / dZ scratch
 
 
-def fusable(num_features=None, h_dim=100, out_dim=1, num_layers=3, AF='R', TL_AF='S', apply_tl_af=False, BN=True, bn_type=None,
-            bn_affine=False, dropout=0.1, **_):
-    """True when the pointsf configuration is the one the fused kernels implement."""
-    if not (AF == 'R' and not BN and not apply_tl_af and h_dim == HIDDEN and out_dim == 1 and 1 <= num_layers <= 8):
-        return False
-    hidden = (num_layers - 1) * 112 * 100 + num_layers * 112 + 112 + 16
-    w1 = 112 * ((num_features + 3) // 4 * 4 + 4)
-    if (w1 + hidden) * 4 <= 160 * 1024:
-        return True                      # all weights in LDS
-    # large F (Yahoo: 700): W1 streams from L2 — needs 16-byte aligned rows and at most 48 in-feature tiles
-    return hidden * 4 <= 160 * 1024 and num_features % 4 == 0 and (num_features + 15) // 16 <= 48
+_STACK_AF = {'R', 'LR', 'E', 'SE', 'CE', 'GE', 'S', 'T'}      # the working entries of get_AF (utils.py:100-143) minus the random RReLU
+
+
+def fused_kind(num_features=None, h_dim=100, out_dim=1, num_layers=3, AF='R', TL_AF='S', apply_tl_af=False, BN=True, bn_type=None,
+               bn_affine=False, dropout=0.1, **_):
+    """Which hand-written path serves a pointsf configuration:
+      'single'  the single-kernel scorer (forward = one kernel, backward = one kernel + reduction): AF='R', no batch norm, no tail
+                activation — the benchmark configuration;
+      'stack'   the layer-wise fused stack (ptranking_amd/linear.py FusedStack: hand-written GEMMs + batch-norm / activation / dropout
+                kernels): every other working activation, bn_type='BN', tail activation — incl. the reference's DEFAULT pointsf
+                (5 layers, GELU, BN affine, Sigmoid tail; ptranking/ltr_adhoc/eval/parameter.py:145-146);
+      None      not covered (bn_type='BN2', RReLU): torch modules (their Linear layers still run the hand-written GEMMs)."""
+    if AF == 'R' and not BN and not apply_tl_af and h_dim == HIDDEN and out_dim == 1 and 1 <= num_layers <= 8:
+        hidden = (num_layers - 1) * 112 * 100 + num_layers * 112 + 112 + 16
+        w1 = 112 * ((num_features + 3) // 4 * 4 + 4)
+        if (w1 + hidden) * 4 <= 160 * 1024:
+            return 'single'                  # all weights in LDS
+        # large F (Yahoo: 700): W1 streams from L2 — needs 16-byte aligned rows and at most 48 in-feature tiles
+        if hidden * 4 <= 160 * 1024 and num_features % 4 == 0 and (num_features + 15) // 16 <= 48:
+            return 'single'
+    if AF in _STACK_AF and (not apply_tl_af or TL_AF in _STACK_AF) and (not BN or bn_type == 'BN') and \
+            (dropout == 0.0 or num_features % 4 == 0 or num_layers == 0):
+        return 'stack'
+    return None
+
+
+def fusable(**kw):
+    """True when a hand-written path (single-kernel scorer or fused stack) implements the pointsf configuration."""
+    return fused_kind(**kw) is not None
 
 
 class _ScorerFn(torch.autograd.Function):
@@ -193,8 +211,13 @@ class FusedScorerMixin:
 
     def ini_pointsf(self, **kw):
         on_gpu = bool(getattr(self, "gpu", False)) and torch.cuda.is_available()
-        if self.use_fused_scorer and on_gpu and fusable(**kw):
+        kind = fused_kind(**kw) if (self.use_fused_scorer and on_gpu) else None
+        if kind == 'single':
             return FusedPointScorer(kw["num_features"], num_layers=kw.get("num_layers", 3), dropout=kw.get("dropout", 0.1))
+        if kind == 'stack':
+            from .host import build_pointsf          # our modules with the reference's names / initialisation (FusedStack)
+            allowed = ("num_features", "h_dim", "out_dim", "num_layers", "AF", "TL_AF", "apply_tl_af", "BN", "bn_type", "bn_affine", "dropout")
+            return build_pointsf(**{k: v for k, v in kw.items() if k in allowed})
         return super().ini_pointsf(**kw)
 
     def config_optimizer(self):

@@ -139,7 +139,7 @@ def test_state_dict_is_interchangeable_with_the_reference_layout(tmp_path):
     assert abs(w.std().item() - (2.0 / 200) ** 0.5) < 0.01
 
 
-def test_ranker_uses_the_fused_scorer_and_falls_back_for_other_configs():
+def test_ranker_uses_the_fused_scorer_and_the_fused_stack_for_other_configs():
     import ptranking_amd as pa
     from ptranking_amd.scorer import FusedPointScorer, FlatAdam
     sf = {"sf_id": "pointsf", "opt": "Adam", "lr": 1e-3,
@@ -158,6 +158,7 @@ def test_ranker_uses_the_fused_scorer_and_falls_back_for_other_configs():
            "pointsf": dict(num_features=136, num_layers=3, AF="GE", TL_AF="S", apply_tl_af=False, BN=False, bn_type=None, bn_affine=False)}
     r2 = pa.LambdaRank(sf_para_dict=sf2, model_para_dict={"sigma": 1.0}, gpu=True, device="cuda:0")
     r2.init()
-    assert isinstance(r2.point_sf, torch.nn.Sequential) and isinstance(r2.optimizer, torch.optim.Adam)
+    from ptranking_amd.linear import FusedStack
+    assert isinstance(r2.point_sf, FusedStack) and isinstance(r2.optimizer, torch.optim.Adam)   # GELU: the layer-wise fused stack
     loss2, _ = r2.train_op(X, Y, epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
     assert torch.isfinite(loss2)

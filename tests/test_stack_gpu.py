@@ -1,0 +1,112 @@
+"""GPU: the layer-wise fused stack (hand-written GEMMs + batch-norm / activation / dropout kernels) on the reference's DEFAULT
+pointsf configuration — 5 layers, GELU, LTRBatchNorm 'BN' affine, Sigmoid tail (ptranking/ltr_adhoc/eval/parameter.py:145-146) — and
+on the other activations of get_AF, against the same modules evaluated by torch on the CPU (fp32), incl. the kernels' own dropout
+masks fed to the torch side."""
+import copy
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+DEFAULT = dict(num_layers=5, AF='GE', TL_AF='S', apply_tl_af=True, BN=True, bn_type='BN', bn_affine=True)
+
+
+def close(a, b, tol=3e-5, what=""):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, f"{what}: max|diff|={err:.3e} > {tol * scale:.3e}"
+
+
+def _mask(R, width, p, seed, site):
+    from ptranking_amd import _lib
+    ones = torch.ones(R, width, device="cuda")
+    m = torch.empty_like(ones)
+    _lib.call("ptr_dropout_apply", _lib.ptr(ones), width, R, width, C.c_float(p), C.c_uint64(seed), site, _lib.ptr(m), width,
+              _lib.current_stream(ones.device))
+    return (m > 0).float().cpu()
+
+
+def _cpu_forward_with_masks(net_cpu, x, p, seed, R):
+    """nn.Sequential.forward on the CPU with every nn.Dropout replaced by the kernel's keep mask of that site."""
+    site = 0
+    for m in net_cpu:
+        if isinstance(m, nn.Dropout):
+            if p > 0:
+                x = x * _mask(R, x.shape[-1], p, seed, site) / (1 - p)
+            site += 1
+        else:
+            x = m(x)
+    return x
+
+
+@pytest.mark.parametrize("cfg", [DEFAULT,
+                                 dict(num_layers=3, AF='GE', TL_AF='S', apply_tl_af=False, BN=False, bn_type=None, bn_affine=False),
+                                 dict(num_layers=2, AF='T', TL_AF='T', apply_tl_af=True, BN=True, bn_type='BN', bn_affine=False),
+                                 dict(num_layers=3, AF='SE', TL_AF='S', apply_tl_af=True, BN=False, bn_type=None, bn_affine=False),
+                                 dict(num_layers=2, AF='LR', TL_AF='E', apply_tl_af=True, BN=True, bn_type='BN', bn_affine=True),
+                                 dict(num_layers=4, AF='CE', TL_AF='S', apply_tl_af=False, BN=True, bn_type='BN', bn_affine=True),
+                                 dict(num_layers=3, AF='S', TL_AF='R', apply_tl_af=True, BN=False, bn_type=None, bn_affine=False)])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_fused_stack_matches_torch_cpu_modules(cfg, p):
+    from ptranking_amd.host import build_pointsf
+    from ptranking_amd.linear import FusedStack
+    from ptranking_amd.scorer import fused_kind
+    assert fused_kind(num_features=136, dropout=p, **cfg) == 'stack'
+    torch.manual_seed(3 + cfg["num_layers"])
+    net = build_pointsf(num_features=136, dropout=p, **cfg)
+    assert isinstance(net, FusedStack)
+    with torch.no_grad():                                   # non-trivial affine parameters / biases
+        for n_, prm in net.named_parameters():
+            if "bn" in n_:
+                prm.add_(0.3 * torch.randn_like(prm))
+    ref = copy.deepcopy(net)                                # CPU tensors -> FusedStack.forward = the plain torch modules
+    net = net.cuda()
+    net.train(); ref.train()
+    B, L = 6, 129
+    R = B * L
+    x = torch.randn(B, L, 136)
+    xg = x.cuda().requires_grad_(True)
+    out = net(xg)
+    assert net._plan and not net._plan["relu_only"]
+    g = torch.randn_like(out)
+    out.backward(g)
+    xr = x.clone().reshape(R, 136).requires_grad_(True)
+    outr = _cpu_forward_with_masks(ref, xr, p, net.last_seed, R)
+    outr.backward(g.cpu().reshape(R, -1))
+    close(out.reshape(R, -1), outr, what="out")
+    close(xg.grad.reshape(R, -1), xr.grad, tol=1e-4, what="dx")
+    got = dict(net.named_parameters())
+    for n_, prm in ref.named_parameters():
+        close(got[n_].grad, prm.grad, tol=1e-4, what=n_)
+    assert list(net.state_dict()) == list(ref.state_dict())
+    # LTRBatchNorm has no running statistics: evaluation uses the batch statistics too (utils.py:214); no dropout in eval
+    net.eval(); ref.eval()
+    with torch.no_grad():
+        close(net(xg).reshape(R, -1), ref(x.reshape(R, 136)), what="eval")
+        assert torch.equal(net(xg), net(xg))
+
+
+def test_default_pointsf_ranker_trains_on_the_fused_stack():
+    import ptranking_amd as pa
+    from ptranking_amd.linear import FusedStack
+    sf = {"sf_id": "pointsf", "opt": "Adam", "lr": 1e-3, "pointsf": dict(num_features=136, **DEFAULT)}
+    r = pa.LambdaRank(sf_para_dict=sf, model_para_dict={"sigma": 1.0}, gpu=True, device="cuda:0")
+    r.init()
+    assert isinstance(r.point_sf, FusedStack) and pa.scorer.fusable(num_features=136, **DEFAULT)
+    r.train_mode()
+    X = torch.randn(16, 64, 136, device="cuda")
+    Y = torch.sort(torch.randint(0, 5, (16, 64), device="cuda").float(), dim=1, descending=True)[0]
+    Y[:, 0] = 2.0
+    before = [p_.detach().clone() for p_ in r.point_sf.parameters()]
+    losses = []
+    for _ in range(3):
+        loss, stop = r.train_op(X, Y, epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
+        losses.append(float(loss))
+    assert all(torch.isfinite(torch.tensor(losses))) and not stop
+    assert any(not torch.equal(a, b) for a, b in zip(before, r.point_sf.parameters()))
+    m = r.adhoc_performance_at_ks(test_data=[(list(range(16)), X, Y)], ks=[1, 5, 10], label_type=pa.LABEL_TYPE.MultiLabel, presort=True)
+    assert all(torch.isfinite(t).all() for t in m)
