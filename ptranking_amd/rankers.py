@@ -69,6 +69,9 @@ class FusedStepMixin:
                 or not (Y.is_cuda and Y.dtype == torch.float32 and Y.is_contiguous() and Y.shape == X.shape[:2])
                 or X.size(2) != sf.num_features or len(self.optimizer.param_groups) != 1):
             return None
+        od = self.optimizer.__dict__       # an optimiser whose step / zero_grad were replaced on the instance (gradient accumulation hacks,
+        if 'zero_grad' in od or ('step' in od and not getattr(od['step'], '_wrapped_by_lr_sched', False)):   # hooks) keeps its semantics:
+            return None                    # autograd path (torch's lr schedulers wrap step() themselves — that wrapper is fine)
         self._direct_check(kwargs)
         lens = kwargs.get('lens')
         if lens is not None and not (lens.is_cuda and lens.dtype == torch.int32 and lens.is_contiguous()):
