@@ -418,11 +418,17 @@ static int launch_linear(const float *X, int ldx, const float *W, const float *b
     return PTR_ERR_UNSUPPORTED;
 }
 
-// backward-weight tiling: outputs per block 16*MTO (MTO in {2, 4, 8}), inputs per block 64*NTW (NTW in {1, 2, 4})
+// backward-weight tiling: a block covers 16*MTO outputs x 64*NTW inputs (wave w owns the input tiles w, w+4, ...).  Both are chosen to
+// minimise padding: K = 136 is 9 input tiles -> ONE block of NTW = 3 (a fixed 128-column block needed two, the second 94 % empty:
+// 27 TFLOP/s measured); N = 136 is 9 output tiles -> two blocks of MTO = 5.  MTO * NTW <= 24 accumulator tiles (96 registers) per wave.
 static void bw_tiling(int K, int N, int &MTO, int &NTW) {
-    MTO = N <= 32 ? 2 : N <= 64 ? 4 : 8;
-    NTW = K <= 64 ? 1 : K <= 128 ? 2 : 4;
-    if (MTO == 8 && NTW == 4) NTW = 2;             // 8 x 4 x 4 accumulators per wave would leave no room for the slabs' registers
+    const int n_out = (N + 15) / 16, n_in = (K + 15) / 16;
+    const int nbn = (n_out + 7) / 8;
+    MTO = (n_out + nbn - 1) / nbn;
+    int ntw_max = 24 / MTO;
+    if (ntw_max > 4) ntw_max = 4;
+    const int nbk = (n_in + 4 * ntw_max - 1) / (4 * ntw_max);
+    NTW = (n_in + 4 * nbk - 1) / (4 * nbk);
 }
 static int bw_chunks(int R, int K, int N) {
     int MTO, NTW;
@@ -474,7 +480,10 @@ extern "C" int ptr_linear_backward_weight(const float *X, int ldx, const float *
     bw_tiling(K, N, MTO, NTW);
     const int nnb = (N + 16 * MTO - 1) / (16 * MTO), nkb = (K + 64 * NTW - 1) / (64 * NTW);
     const int chunks = bw_chunks(R, K, N);
-    constexpr int RB = 16;
+#ifndef LIN_BW_RB
+#define LIN_BW_RB 16
+#endif
+    constexpr int RB = LIN_BW_RB;
     auto go = [&](auto kern, int mto, int ntw) -> int {
         const size_t lds = (size_t)(2 * RB * (16 * mto + 16) + 2 * RB * (64 * ntw + 16)) * sizeof(float);
         if (int e = allow_lds(kern, lds)) return e;
@@ -482,9 +491,12 @@ extern "C" int ptr_linear_backward_weight(const float *X, int ldx, const float *
         return check_hip(hipGetLastError(), who);
     };
     int e = PTR_ERR_UNSUPPORTED;
-    if (MTO == 2) e = NTW == 1 ? go(linear_bwd_w_kernel<2, 1, RB>, 2, 1) : NTW == 2 ? go(linear_bwd_w_kernel<2, 2, RB>, 2, 2) : go(linear_bwd_w_kernel<2, 4, RB>, 2, 4);
-    else if (MTO == 4) e = NTW == 1 ? go(linear_bwd_w_kernel<4, 1, RB>, 4, 1) : NTW == 2 ? go(linear_bwd_w_kernel<4, 2, RB>, 4, 2) : go(linear_bwd_w_kernel<4, 4, RB>, 4, 4);
-    else e = NTW == 1 ? go(linear_bwd_w_kernel<8, 1, RB>, 8, 1) : go(linear_bwd_w_kernel<8, 2, RB>, 8, 2);
+#define BW_CASE(M, T) if (MTO == M && NTW == T) e = go(linear_bwd_w_kernel<M, T, RB>, M, T);
+#define BW_ROW(M) BW_CASE(M, 1) BW_CASE(M, 2) BW_CASE(M, 3) BW_CASE(M, 4)
+    BW_ROW(1) BW_ROW(2) BW_ROW(3) BW_ROW(4) BW_ROW(5) BW_ROW(6)
+    BW_CASE(7, 1) BW_CASE(7, 2) BW_CASE(7, 3) BW_CASE(8, 1) BW_CASE(8, 2) BW_CASE(8, 3)
+#undef BW_ROW
+#undef BW_CASE
     if (e) return e;
     hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ws, chunks, n, n, dW, nw, db);
     return check_hip(hipGetLastError(), who);
