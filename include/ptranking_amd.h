@@ -213,14 +213,16 @@ int ptr_relu_gate(const float *dy, const float *y, int64_t n, float *out, void *
 #define PTR_AF_GELU 5      /* 'GE' (erf form) */
 #define PTR_AF_SIGMOID 6   /* 'S'  */
 #define PTR_AF_TANH 7      /* 'T'  */
-size_t ptr_bn_ws_floats(int R, int N);
-int ptr_bn_stats(const float *z, int ld, int R, int N, float eps, float *ws, float *mean, float *rstd, void *stream);
-int ptr_bnact_forward(const float *z, int ld, int R, int N, const float *mean, const float *rstd, const float *gamma, const float *beta,
-                      int af, float p_drop, uint64_t seed, int site, float *out, void *stream);
-/* ws: ptr_bn_ws_floats(R, N) + 2 * N floats (only read / written with batch norm) */
-int ptr_bnact_backward(const float *z, const float *da, int ld, int R, int N, const float *mean, const float *rstd, const float *gamma,
-                       const float *beta, int af, float p_drop, uint64_t seed, int site, float *ws, float *dz, float *dgamma,
-                       float *dbeta, void *stream);
+/* group_rows: 0 = statistics over all R rows (LTRBatchNorm 'BN'); L > 0 = per group of L consecutive rows, i.e. per query (LTRBatchNorm2
+ * 'BN2', utils.py:227-286; R % L == 0) — mean / rstd then are [R / L][N]. */
+size_t ptr_bn_ws_floats(int R, int N, int group_rows);
+int ptr_bn_stats(const float *z, int ld, int R, int N, int group_rows, float eps, float *ws, float *mean, float *rstd, void *stream);
+int ptr_bnact_forward(const float *z, int ld, int R, int N, int group_rows, const float *mean, const float *rstd, const float *gamma,
+                      const float *beta, int af, float p_drop, uint64_t seed, int site, float *out, void *stream);
+/* ws: ptr_bn_ws_floats(R, N, group_rows) + 2 * N floats (only read / written with batch norm); dgamma / dbeta: sums over ALL rows */
+int ptr_bnact_backward(const float *z, const float *da, int ld, int R, int N, int group_rows, const float *mean, const float *rstd,
+                       const float *gamma, const float *beta, int af, float p_drop, uint64_t seed, int site, float *ws, float *dz,
+                       float *dgamma, float *dbeta, void *stream);
 
 /* ---- listsf: the permutation-equivariant scorer's fused pieces (fp32 MFMA attention core, the reference's LayerNorm) ----
  * ptr_mhsa_forward replaces ptranking/base/list_ranker.py:216-240 (Q K^T / sqrt(d_h) -> softmax -> Dropout -> . V, heads = column

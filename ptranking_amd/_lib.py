@@ -47,10 +47,10 @@ SIGNATURES = {
     "ptr_linear_backward_input": [_vp, _i, _vp, _i, _i, _i, _vp, _i, _f, _vp, _i, _vp],
     "ptr_linear_backward_weight_ws_floats": [_i, _i, _i],
     "ptr_linear_backward_weight": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
-    "ptr_bn_ws_floats": [_i, _i],
-    "ptr_bn_stats": [_vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
-    "ptr_bnact_forward": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _u64, _i, _vp, _vp],
-    "ptr_bnact_backward": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _u64, _i, _vp, _vp, _vp, _vp, _vp],
+    "ptr_bn_ws_floats": [_i, _i, _i],
+    "ptr_bn_stats": [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
+    "ptr_bnact_forward": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _u64, _i, _vp, _vp],
+    "ptr_bnact_backward": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _u64, _i, _vp, _vp, _vp, _vp, _vp],
     "ptr_dropout_apply": [_vp, _i, _i, _i, _f, _u64, _i, _vp, _i, _vp],
     "ptr_relu_gate": [_vp, _vp, C.c_int64, _vp, _vp],
     "ptr_mhsa_forward": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _u64, _i, _vp, _vp, _vp],

@@ -42,6 +42,7 @@ __device__ __forceinline__ float af_bwd(int af, float y) {
 }
 
 struct BnActArgs {
+    int group;                   // rows per statistics group: 0 = one group (LTRBatchNorm, the whole batch), L = per query (LTRBatchNorm2)
     int R, N, ld;                // z / a / da are [R][N] with leading dimension ld
     int af;
     int has_bn;
@@ -70,8 +71,9 @@ colsum2_kernel(const float *__restrict__ z, const float *__restrict__ da, const 
     const int cols_per_pass = N < 256 ? N : 256;
     const int rsub = 256 / cols_per_pass;                    // row lanes per pass
     const int c_in = tid % cols_per_pass, rl = tid / cols_per_pass;
-    const int chunk = (R + gridDim.x - 1) / gridDim.x;
+    const int chunk = a.group > 0 ? a.group : (R + gridDim.x - 1) / gridDim.x;     // grouped: one workgroup per group (query)
     const int r_begin = blockIdx.x * chunk, r_end = min(R, r_begin + chunk);
+    const size_t so = a.group > 0 ? (size_t)blockIdx.x * N : 0;                  // offset of this group's statistics
     const uint32_t thr = drop_thr(a.p_drop);
     const float inv_keep = a.p_drop > 0.0f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
     for (int c0 = 0; c0 < N; c0 += cols_per_pass) {
@@ -79,8 +81,8 @@ colsum2_kernel(const float *__restrict__ z, const float *__restrict__ da, const 
         float s1 = 0.0f, s2 = 0.0f;
         if (c < N && rl < rsub) {
             float mu = 0.f, rs = 1.f, ga = 1.f, be = 0.f;
-            if (MODE == 1 && a.has_bn) { mu = mean[c]; rs = rstd[c]; ga = gamma ? gamma[c] : 1.0f; be = beta ? beta[c] : 0.0f; }
-            if (MODE == 2) mu = mean[c];
+            if (MODE == 1 && a.has_bn) { mu = mean[so + c]; rs = rstd[so + c]; ga = gamma ? gamma[c] : 1.0f; be = beta ? beta[c] : 0.0f; }
+            if (MODE == 2) mu = mean[so + c];
             for (int r = r_begin + rl; r < r_end; r += rsub) {
                 const float zv = z[(size_t)r * a.ld + c];
                 if (MODE == 0) {
@@ -128,6 +130,18 @@ colsum2_reduce_kernel(const float *__restrict__ partial, int nblk, int N, int R,
     }
 }
 
+// grouped statistics: the per-group partial IS the group's sum.  FINISH 1: mean = sum / L; FINISH 2: rstd = 1 / sqrt(sum / L + eps)
+template <int FINISH>
+__global__ void __launch_bounds__(256)
+group_finish_kernel(const float *__restrict__ partial, size_t G, int N, int L, float eps, float *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= G * N) return;
+    const size_t gidx = i / N;
+    const int c = (int)(i - gidx * N);
+    const float sv = partial[(gidx * 2 + 0) * N + c];
+    out[i] = FINISH == 1 ? sv / (float)L : 1.0f / sqrtf(sv / (float)L + eps);
+}
+
 // a_out = dropout(AF(BN(z)))
 __global__ void __launch_bounds__(256)
 bnact_fwd_kernel(const float *__restrict__ z, const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ gamma,
@@ -136,7 +150,8 @@ bnact_fwd_kernel(const float *__restrict__ z, const float *__restrict__ mean, co
     if (i >= (size_t)a.R * a.N) return;
     const int r = (int)(i / a.N), c = (int)(i - (size_t)r * a.N);
     float y = z[(size_t)r * a.ld + c];
-    if (a.has_bn) y = fmaf(gamma ? gamma[c] : 1.0f, (y - mean[c]) * rstd[c], beta ? beta[c] : 0.0f);
+    const size_t so = a.group > 0 ? (size_t)(r / a.group) * a.N : 0;
+    if (a.has_bn) y = fmaf(gamma ? gamma[c] : 1.0f, (y - mean[so + c]) * rstd[so + c], beta ? beta[c] : 0.0f);
     const float h = af_fwd(a.af, y);
     out[(size_t)r * a.ld + c] = h * drop_factor(a, r, c, drop_thr(a.p_drop), a.p_drop > 0.0f ? 1.0f / (1.0f - a.p_drop) : 1.0f);
 }
@@ -152,12 +167,14 @@ bnact_bwd_kernel(const float *__restrict__ z, const float *__restrict__ da, cons
     const float zv = z[(size_t)r * a.ld + c];
     const float thr_keep = drop_factor(a, r, c, drop_thr(a.p_drop), a.p_drop > 0.0f ? 1.0f / (1.0f - a.p_drop) : 1.0f);
     if (a.has_bn) {
-        const float ga = gamma ? gamma[c] : 1.0f, rs = rstd[c];
-        const float xh = (zv - mean[c]) * rs;
+        // grouped: sum_dy / sum_dyx are the per-group partials [G][2][N] of colsum2_kernel<1> (sum_dyx = sum_dy + N), mean over L rows
+        const size_t so = a.group > 0 ? (size_t)(r / a.group) * a.N : 0, ss = a.group > 0 ? 2 * so : 0;
+        const float ga = gamma ? gamma[c] : 1.0f, rs = rstd[so + c];
+        const float xh = (zv - mean[so + c]) * rs;
         const float y = fmaf(ga, xh, beta ? beta[c] : 0.0f);
         const float dy = da[(size_t)r * a.ld + c] * thr_keep * af_bwd(a.af, y);
-        const float invR = 1.0f / (float)a.R;
-        dz[(size_t)r * a.ld + c] = (ga * rs) * (dy - sum_dy[c] * invR - xh * (sum_dyx[c] * invR));
+        const float invR = 1.0f / (float)(a.group > 0 ? a.group : a.R);
+        dz[(size_t)r * a.ld + c] = (ga * rs) * (dy - sum_dy[ss + c] * invR - xh * (sum_dyx[ss + c] * invR));
     } else {
         dz[(size_t)r * a.ld + c] = da[(size_t)r * a.ld + c] * thr_keep * af_bwd(a.af, zv);
     }
@@ -177,39 +194,56 @@ static int check_bnact(const char *who, int R, int N, int ld, int af, float p) {
 
 }  // namespace ptr
 
-extern "C" size_t ptr_bn_ws_floats(int R, int N) { return (size_t)ptr::bn_blocks(R) * 2 * (size_t)N; }
+// group_rows: 0 = statistics over all R rows (LTRBatchNorm); L > 0 = per group of L consecutive rows (per query, LTRBatchNorm2; R % L == 0)
+extern "C" size_t ptr_bn_ws_floats(int R, int N, int group_rows) {
+    const size_t blocks = group_rows > 0 ? (size_t)(R / group_rows) : (size_t)ptr::bn_blocks(R);
+    return blocks * 2 * (size_t)N;
+}
 
-// mean[N], rstd[N] of the columns of z over all R rows (biased variance, rstd = 1 / sqrt(var + eps))
-extern "C" int ptr_bn_stats(const float *z, int ld, int R, int N, float eps, float *ws, float *mean, float *rstd, void *stream) {
+// mean / rstd ([N], or [R / group_rows][N]) of the columns of z (biased variance, rstd = 1 / sqrt(var + eps), two-pass)
+extern "C" int ptr_bn_stats(const float *z, int ld, int R, int N, int group_rows, float eps, float *ws, float *mean, float *rstd, void *stream) {
     using namespace ptr;
     const char *who = "ptr_bn_stats";
     if (int rc = check_bnact(who, R, N, ld, 0, 0.0f)) return rc;
     if (R == 0 || !z || !ws || !mean || !rstd) { set_error("%s: NULL pointer / empty batch", who); return PTR_ERR_INVALID_ARG; }
-    BnActArgs a{R, N, ld, 0, 0, 0.0f, 0, 0, 0};
+    if (group_rows < 0 || (group_rows > 0 && R % group_rows)) { set_error("%s: R=%d is not a multiple of group_rows=%d", who, R, group_rows); return PTR_ERR_INVALID_ARG; }
+    hipStream_t st = as_stream(stream);
+    BnActArgs a{group_rows, R, N, ld, 0, 0, 0.0f, 0, 0, 0};
+    if (group_rows > 0) {
+        const int G = R / group_rows;
+        const unsigned fin = (unsigned)(((size_t)G * N + 255) / 256);
+        hipLaunchKernelGGL(colsum2_kernel<0>, dim3(G), dim3(256), 0, st, z, nullptr, nullptr, nullptr, nullptr, nullptr, a, ws);
+        hipLaunchKernelGGL(group_finish_kernel<1>, dim3(fin), dim3(256), 0, st, ws, (size_t)G, N, group_rows, eps, mean);
+        hipLaunchKernelGGL(colsum2_kernel<2>, dim3(G), dim3(256), 0, st, z, nullptr, mean, nullptr, nullptr, nullptr, a, ws);
+        hipLaunchKernelGGL(group_finish_kernel<2>, dim3(fin), dim3(256), 0, st, ws, (size_t)G, N, group_rows, eps, rstd);
+        return check_hip(hipGetLastError(), who);
+    }
     const int nb = bn_blocks(R);
-    hipLaunchKernelGGL(colsum2_kernel<0>, dim3(nb), dim3(256), 0, as_stream(stream), z, nullptr, nullptr, nullptr, nullptr, nullptr, a, ws);
-    hipLaunchKernelGGL(colsum2_reduce_kernel<1>, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), ws, nb, N, R, eps, mean, nullptr);
-    hipLaunchKernelGGL(colsum2_kernel<2>, dim3(nb), dim3(256), 0, as_stream(stream), z, nullptr, mean, nullptr, nullptr, nullptr, a, ws);
-    hipLaunchKernelGGL(colsum2_reduce_kernel<2>, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), ws, nb, N, R, eps, rstd, nullptr);
+    hipLaunchKernelGGL(colsum2_kernel<0>, dim3(nb), dim3(256), 0, st, z, nullptr, nullptr, nullptr, nullptr, nullptr, a, ws);
+    hipLaunchKernelGGL(colsum2_reduce_kernel<1>, dim3((N + 255) / 256), dim3(256), 0, st, ws, nb, N, R, eps, mean, nullptr);
+    hipLaunchKernelGGL(colsum2_kernel<2>, dim3(nb), dim3(256), 0, st, z, nullptr, mean, nullptr, nullptr, nullptr, a, ws);
+    hipLaunchKernelGGL(colsum2_reduce_kernel<2>, dim3((N + 255) / 256), dim3(256), 0, st, ws, nb, N, R, eps, rstd, nullptr);
     return check_hip(hipGetLastError(), who);
 }
 
 // out = dropout(AF(gamma * (z - mean) * rstd + beta))   (mean == NULL: no batch norm; gamma / beta NULL: no affine)
-extern "C" int ptr_bnact_forward(const float *z, int ld, int R, int N, const float *mean, const float *rstd, const float *gamma,
+extern "C" int ptr_bnact_forward(const float *z, int ld, int R, int N, int group_rows, const float *mean, const float *rstd, const float *gamma,
                                  const float *beta, int af, float p_drop, uint64_t seed, int site, float *out, void *stream) {
     using namespace ptr;
     const char *who = "ptr_bnact_forward";
     if (int rc = check_bnact(who, R, N, ld, af, p_drop)) return rc;
     if (R == 0) return 0;
     if (!z || !out || (mean && !rstd)) { set_error("%s: NULL pointer", who); return PTR_ERR_INVALID_ARG; }
-    BnActArgs a{R, N, ld, af, mean ? 1 : 0, p_drop, (uint32_t)seed, (uint32_t)(seed >> 32), site};
+    if (group_rows < 0 || (group_rows > 0 && R % group_rows)) { set_error("%s: R=%d is not a multiple of group_rows=%d", who, R, group_rows); return PTR_ERR_INVALID_ARG; }
+    BnActArgs a{mean ? group_rows : 0, R, N, ld, af, mean ? 1 : 0, p_drop, (uint32_t)seed, (uint32_t)(seed >> 32), site};
     const size_t n = (size_t)R * N;
     hipLaunchKernelGGL(bnact_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), z, mean, rstd, gamma, beta, a, out);
     return check_hip(hipGetLastError(), who);
 }
 
-// da -> dz (and, with batch norm, dgamma[N] = sum dy * xhat, dbeta[N] = sum dy; either may be NULL).  ws: ptr_bn_ws_floats + 2 * N floats.
-extern "C" int ptr_bnact_backward(const float *z, const float *da, int ld, int R, int N, const float *mean, const float *rstd,
+// da -> dz (and, with batch norm, dgamma[N] = sum dy * xhat, dbeta[N] = sum dy over ALL rows; either may be NULL).
+// ws: ptr_bn_ws_floats(R, N, group_rows) + 2 * N floats.
+extern "C" int ptr_bnact_backward(const float *z, const float *da, int ld, int R, int N, int group_rows, const float *mean, const float *rstd,
                                   const float *gamma, const float *beta, int af, float p_drop, uint64_t seed, int site, float *ws,
                                   float *dz, float *dgamma, float *dbeta, void *stream) {
     using namespace ptr;
@@ -217,17 +251,19 @@ extern "C" int ptr_bnact_backward(const float *z, const float *da, int ld, int R
     if (int rc = check_bnact(who, R, N, ld, af, p_drop)) return rc;
     if (R == 0) return 0;
     if (!z || !da || !dz || (mean && (!rstd || !ws))) { set_error("%s: NULL pointer", who); return PTR_ERR_INVALID_ARG; }
+    if (group_rows < 0 || (group_rows > 0 && R % group_rows)) { set_error("%s: R=%d is not a multiple of group_rows=%d", who, R, group_rows); return PTR_ERR_INVALID_ARG; }
     hipStream_t st = as_stream(stream);
-    BnActArgs a{R, N, ld, af, mean ? 1 : 0, p_drop, (uint32_t)seed, (uint32_t)(seed >> 32), site};
-    float *sum_dy = nullptr, *sum_dyx = nullptr;
+    BnActArgs a{mean ? group_rows : 0, R, N, ld, af, mean ? 1 : 0, p_drop, (uint32_t)seed, (uint32_t)(seed >> 32), site};
+    const float *sum_dy = nullptr, *sum_dyx = nullptr;
     if (mean) {
-        const int nb = bn_blocks(R);
-        sum_dy = ws + (size_t)nb * 2 * N;
-        sum_dyx = sum_dy + N;
+        const int nb = a.group > 0 ? R / a.group : bn_blocks(R);
+        float *tot_dy = ws + (size_t)nb * 2 * N, *tot_dyx = tot_dy + N;
         hipLaunchKernelGGL(colsum2_kernel<1>, dim3(nb), dim3(256), 0, st, z, da, mean, rstd, gamma, beta, a, ws);
-        hipLaunchKernelGGL(colsum2_reduce_kernel<0>, dim3((N + 255) / 256), dim3(256), 0, st, ws, nb, N, R, 0.0f, sum_dy, sum_dyx);
-        if (dbeta) { if (int e = check_hip(hipMemcpyAsync(dbeta, sum_dy, N * sizeof(float), hipMemcpyDeviceToDevice, st), who)) return e; }
-        if (dgamma) { if (int e = check_hip(hipMemcpyAsync(dgamma, sum_dyx, N * sizeof(float), hipMemcpyDeviceToDevice, st), who)) return e; }
+        hipLaunchKernelGGL(colsum2_reduce_kernel<0>, dim3((N + 255) / 256), dim3(256), 0, st, ws, nb, N, R, 0.0f, tot_dy, tot_dyx);
+        if (dbeta) { if (int e = check_hip(hipMemcpyAsync(dbeta, tot_dy, N * sizeof(float), hipMemcpyDeviceToDevice, st), who)) return e; }
+        if (dgamma) { if (int e = check_hip(hipMemcpyAsync(dgamma, tot_dyx, N * sizeof(float), hipMemcpyDeviceToDevice, st), who)) return e; }
+        sum_dy = a.group > 0 ? ws : tot_dy;                 // grouped: the per-group partials themselves
+        sum_dyx = a.group > 0 ? ws + N : tot_dyx;
     }
     const size_t n = (size_t)R * N;
     hipLaunchKernelGGL(bnact_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, z, da, mean, rstd, gamma, beta, sum_dy, sum_dyx, a, dz);

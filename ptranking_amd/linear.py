@@ -175,89 +175,107 @@ def _af_code(m):
     return code
 
 
-def _bn_stats(z):
+def _bn_stats(z, group=0):
     R, N = z.shape
     dev = z.device
-    ws = torch.empty(_lib.query("ptr_bn_ws_floats", R, N), device=dev, dtype=torch.float32)
-    mean = torch.empty(N, device=dev, dtype=torch.float32)
-    rstd = torch.empty(N, device=dev, dtype=torch.float32)
+    G = R // group if group else 1
+    ws = torch.empty(_lib.query("ptr_bn_ws_floats", R, N, group), device=dev, dtype=torch.float32)
+    mean = torch.empty(G * N, device=dev, dtype=torch.float32)
+    rstd = torch.empty(G * N, device=dev, dtype=torch.float32)
     with torch.cuda.device(dev):
-        _lib.call("ptr_bn_stats", _lib.ptr(z), N, R, N, C.c_float(BN_EPS), _lib.ptr(ws), _lib.ptr(mean), _lib.ptr(rstd), _lib.current_stream(dev))
+        _lib.call("ptr_bn_stats", _lib.ptr(z), N, R, N, group, C.c_float(BN_EPS), _lib.ptr(ws), _lib.ptr(mean), _lib.ptr(rstd), _lib.current_stream(dev))
     return mean, rstd
 
 
-def _bnact_fwd(z, mean, rstd, gamma, beta, af, p, seed, site):
+def _bnact_fwd(z, group, mean, rstd, gamma, beta, af, p, seed, site):
     R, N = z.shape
     out = torch.empty_like(z)
     with torch.cuda.device(z.device):
-        _lib.call("ptr_bnact_forward", _lib.ptr(z), N, R, N, _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(beta), af, C.c_float(p),
+        _lib.call("ptr_bnact_forward", _lib.ptr(z), N, R, N, group, _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(beta), af, C.c_float(p),
                   C.c_uint64(seed), site, _lib.ptr(out), _lib.current_stream(z.device))
     return out
 
 
-def _bnact_bwd(z, da, mean, rstd, gamma, beta, af, p, seed, site):
+def _bnact_bwd(z, da, group, mean, rstd, gamma, beta, af, p, seed, site):
     R, N = z.shape
     dev = z.device
     has_bn = mean is not None
-    ws = torch.empty(_lib.query("ptr_bn_ws_floats", R, N) + 2 * N, device=dev, dtype=torch.float32) if has_bn else None
+    ws = torch.empty(_lib.query("ptr_bn_ws_floats", R, N, group) + 2 * N, device=dev, dtype=torch.float32) if has_bn else None
     dz = torch.empty_like(z)
     dg = torch.empty(N, device=dev, dtype=torch.float32) if (has_bn and gamma is not None) else None
     db = torch.empty(N, device=dev, dtype=torch.float32) if (has_bn and beta is not None) else None
     with torch.cuda.device(dev):
-        _lib.call("ptr_bnact_backward", _lib.ptr(z), _lib.ptr(da), N, R, N, _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(beta), af,
+        _lib.call("ptr_bnact_backward", _lib.ptr(z), _lib.ptr(da), N, R, N, group, _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(beta), af,
                   C.c_float(p), C.c_uint64(seed), site, _lib.ptr(ws), _lib.ptr(dz), _lib.ptr(dg), _lib.ptr(db), _lib.current_stream(dev))
     return dz, dg, db
+
+
+def _stack_forward(x, p, seed, spec, params, fixed_stats=None, sink=None):
+    """Forward of the general stack.  spec = (n_linear, hidden af codes, tail af or 0, has_bn, group): group = 0 — statistics over the
+    whole batch ('BN'), L — per query ('BN2').  fixed_stats: per-layer (mean, rstd) to use instead of the batch statistics (BN2 under
+    torch.no_grad(): its moving statistics).  sink: list receiving (layer, mean, rstd) of the statistics computed here."""
+    n, afs, tail_af, has_bn, group = spec
+    per = 4 if has_bn else 2
+    x2, ldx = _rows(x)
+    dev = x2.device
+    R, K0 = x2.shape
+    if n > 1 and p > 0.0:
+        if K0 % 4 or ldx % 4:
+            raise NotImplementedError("input width must be a multiple of 4 for the fused dropout")
+        a = torch.empty((R, K0), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.call("ptr_dropout_apply", _lib.ptr(x2), ldx, R, K0, C.c_float(p), C.c_uint64(seed), 0, _lib.ptr(a), K0, _lib.current_stream(dev))
+        ins, lda = [a], K0
+    else:
+        ins, lda = [x2], ldx
+    zs, stats = [], []
+    out = None
+    for i in range(n):
+        W, b = params[per * i], params[per * i + 1]
+        gamma, beta = (params[per * i + 2], params[per * i + 3]) if has_bn else (None, None)
+        z = _fwd(ins[-1], lda if i == 0 else ins[-1].shape[1], W, b)
+        hidden = i < n - 1
+        af = afs[i] if hidden else tail_af
+        if not hidden and af == 0:
+            out = z
+            zs.append(None); stats.append((None, None))
+            break
+        gi = group
+        if not has_bn:
+            mean, rstd = None, None
+        elif fixed_stats is not None:
+            (mean, rstd), gi = fixed_stats[i], 0
+        else:
+            mean, rstd = _bn_stats(z, group)
+            if sink is not None:
+                sink.append((i, mean, rstd))
+        pd = p if (hidden and i < n - 2) else 0.0          # the dropout in front of the NEXT hidden Linear
+        a = _bnact_fwd(z, gi, mean, rstd, gamma, beta, af, pd, seed, i + 1)
+        zs.append(z); stats.append((mean, rstd))
+        if hidden:
+            ins.append(a)
+        else:
+            out = a
+    return out, ins, zs, stats, lda
 
 
 class _StackFn(torch.autograd.Function):
     """The general stack of get_stacked_FFNet (utils.py:288-356): [Dropout -> Linear -> [BN] -> AF]* -> Linear [-> [BN] -> TL_AF], layer by
     layer on our kernels: linear -> column statistics -> (normalise, activate, next layer's dropout).  Only the pre-normalisation z
-    and the layer inputs are kept for backward.  spec = (n_linear, [af codes of the hidden layers], tail af or 0, has_bn)."""
+    and the layer inputs are kept for backward."""
 
     @staticmethod
-    def forward(ctx, x, p, seed, spec, *params):
-        n, afs, tail_af, has_bn = spec
-        per = 4 if has_bn else 2
-        x2, ldx = _rows(x)
-        dev = x2.device
-        R, K0 = x2.shape
-        if n > 1 and p > 0.0:
-            if K0 % 4 or ldx % 4:
-                raise NotImplementedError("input width must be a multiple of 4 for the fused dropout")
-            a = torch.empty((R, K0), device=dev, dtype=torch.float32)
-            with torch.cuda.device(dev):
-                _lib.call("ptr_dropout_apply", _lib.ptr(x2), ldx, R, K0, C.c_float(p), C.c_uint64(seed), 0, _lib.ptr(a), K0, _lib.current_stream(dev))
-            ins, lda = [a], K0
-        else:
-            ins, lda = [x2], ldx
-        zs, stats = [], []
-        for i in range(n):
-            W, b = params[per * i], params[per * i + 1]
-            gamma, beta = (params[per * i + 2], params[per * i + 3]) if has_bn else (None, None)
-            z = _fwd(ins[-1], lda if i == 0 else ins[-1].shape[1], W, b)
-            hidden = i < n - 1
-            af = afs[i] if hidden else tail_af
-            if not hidden and af == 0:
-                out = z
-                zs.append(None); stats.append((None, None))
-                break
-            mean, rstd = _bn_stats(z) if has_bn else (None, None)
-            pd = p if (hidden and i < n - 2) else 0.0          # the dropout in front of the NEXT hidden Linear
-            a = _bnact_fwd(z, mean, rstd, gamma, beta, af, pd, seed, i + 1)
-            zs.append(z); stats.append((mean, rstd))
-            if hidden:
-                ins.append(a)
-            else:
-                out = a
+    def forward(ctx, x, p, seed, spec, sink, *params):
+        out, ins, zs, stats, lda = _stack_forward(x, p, seed, spec, params, sink=sink)
         flat_stats = [t for ms in stats for t in ms]
         ctx.save_for_backward(*ins, *zs, *flat_stats, *params)
-        ctx.meta = (n, p, seed, spec, lda)
+        ctx.meta = (spec[0], p, seed, spec, lda)
         return out.view(*x.shape[:-1], out.shape[1])
 
     @staticmethod
     def backward(ctx, dout):
         n, p, seed, spec, lda = ctx.meta
-        _, afs, tail_af, has_bn = spec
+        _, afs, tail_af, has_bn, group = spec
         per = 4 if has_bn else 2
         sv = ctx.saved_tensors
         ins, zs, fs, params = sv[:n], sv[n:2 * n], sv[2 * n:4 * n], sv[4 * n:]
@@ -271,7 +289,7 @@ class _StackFn(torch.autograd.Function):
             af = afs[i] if hidden else tail_af
             if hidden or af != 0:
                 pd = p if (hidden and i < n - 2) else 0.0
-                d, dg, dbt = _bnact_bwd(zs[i], d, fs[2 * i], fs[2 * i + 1], gamma, beta, af, pd, seed, i + 1)
+                d, dg, dbt = _bnact_bwd(zs[i], d, group, fs[2 * i], fs[2 * i + 1], gamma, beta, af, pd, seed, i + 1)
                 if has_bn:
                     grads[per * i + 2], grads[per * i + 3] = dg, dbt
             a_in = ins[i]
@@ -287,36 +305,40 @@ class _StackFn(torch.autograd.Function):
                         _lib.call("ptr_dropout_apply", _lib.ptr(dx), dx.shape[1], dx.shape[0], dx.shape[1], C.c_float(p), C.c_uint64(seed), 0,
                                   _lib.ptr(dxd), dx.shape[1], _lib.current_stream(dev))
                     dx = dxd
-                return (dx.view(*dout.shape[:-1], W.shape[1]), None, None, None, *grads)
-        return (None, None, None, None, *grads)
+                return (dx.view(*dout.shape[:-1], W.shape[1]), None, None, None, None, *grads)
+        return (None, None, None, None, None, *grads)
 
 
 class FusedStack(nn.Sequential):
     """The Sequential get_stacked_FFNet builds (module names and state_dict as the reference's: dr_i / ff_{i+1} / bn_{i+1} / act_{i+1}),
     evaluated on the GPU as ONE autograd node on the hand-written kernels:
       * AF='R' without batch norm: ReLU and the next layer's dropout in the producing GEMM's epilogue (`_ReluStackFn`);
-      * any other working activation of get_AF and / or bn_type='BN' (the reference's DEFAULT pointsf: 5 x [BN(affine) -> GELU],
-        Sigmoid tail): layer-wise linear -> statistics -> normalise / activate / dropout (`_StackFn`).
-    A structure it does not recognise (bn_type='BN2', RReLU, ...) runs module by module (FusedLinear GEMMs + torch elementwise)."""
+      * any other working activation of get_AF and / or batch norm — bn_type='BN' (statistics over all documents of the batch; the
+        reference's DEFAULT pointsf: 5 x [BN(affine) -> GELU], Sigmoid tail) or 'BN2' (per-query statistics, moving statistics under
+        torch.no_grad(), LTRBatchNorm2's quirks): layer-wise linear -> statistics -> normalise / activate / dropout (`_StackFn`).
+    A structure it does not recognise (RReLU, ...) runs module by module (FusedLinear GEMMs + torch elementwise)."""
 
     tail_relu = False        # kept for the pure-ReLU fast path
     _plan = None
 
     def _make_plan(self):
         mods = list(self)
-        lins, afs, bns, drops = [], [], [], []
-        i = 0
+        lins, drops = [], []
         cur = None
         for m in mods:
             if isinstance(m, nn.Dropout):
                 drops.append(m)
             elif isinstance(m, nn.Linear):
-                cur = {"lin": m, "bn": None, "af": 0}
+                cur = {"lin": m, "bn": None, "bn2": None, "af": 0}
                 lins.append(cur)
             elif type(m).__name__ in ("_BatchNormOverDocs", "LTRBatchNorm"):
-                if cur is None or cur["bn"] is not None or cur["af"] != 0:
+                if cur is None or cur["bn"] is not None or cur["bn2"] is not None or cur["af"] != 0:
                     return None
                 cur["bn"] = m.bn
+            elif type(m).__name__ in ("_BatchNormPerQuery", "LTRBatchNorm2"):
+                if cur is None or cur["bn"] is not None or cur["bn2"] is not None or cur["af"] != 0:
+                    return None
+                cur["bn2"] = m
             elif _af_code(m) is not None:
                 if cur is None or cur["af"] != 0:
                     return None
@@ -325,15 +347,22 @@ class FusedStack(nn.Sequential):
                 return None
         if not lins or any(l["af"] == 0 for l in lins[:-1]):
             return None
-        has_bn = any(l["bn"] is not None for l in lins)
-        if has_bn and (any(l["bn"] is None for l in lins[:-1]) or (lins[-1]["af"] != 0) != (lins[-1]["bn"] is not None)):
+        kinds = {("bn" if l["bn"] is not None else "bn2" if l["bn2"] is not None else None) for l in lins[:-1]}
+        if lins[-1]["af"] != 0:
+            kinds.add("bn" if lins[-1]["bn"] is not None else "bn2" if lins[-1]["bn2"] is not None else None)
+        elif lins[-1]["bn"] is not None or lins[-1]["bn2"] is not None:
             return None
-        if has_bn and any(l["bn"] is not None and (l["bn"].track_running_stats or l["bn"].eps != BN_EPS) for l in lins):
+        if len(lins) == 1 and lins[0]["af"] == 0:
+            kinds = {None}
+        if len(kinds) != 1:
+            return None                                 # batch norm on some layers only, or mixed kinds: not the reference's constructions
+        kind = kinds.pop()
+        if kind == "bn" and any(l["bn"] is not None and (l["bn"].track_running_stats or l["bn"].eps != BN_EPS) for l in lins):
             return None
         if len(drops) not in (0, len(lins) - 1) or len({d.p for d in drops}) > 1:
             return None
-        relu_only = not has_bn and all(l["af"] == 1 for l in lins[:-1]) and lins[-1]["af"] in (0, 1)
-        return dict(lins=lins, has_bn=has_bn, relu_only=relu_only, p=drops[0].p if drops else 0.0)
+        relu_only = kind is None and all(l["af"] == 1 for l in lins[:-1]) and lins[-1]["af"] in (0, 1)
+        return dict(lins=lins, kind=kind, relu_only=relu_only, p=drops[0].p if drops else 0.0)
 
     def forward(self, x):
         if not x.is_cuda:
@@ -341,7 +370,7 @@ class FusedStack(nn.Sequential):
         if self._plan is None:
             self._plan = self._make_plan() or False
         plan = self._plan
-        if plan is False:
+        if plan is False or (plan["kind"] == "bn2" and x.dim() != 3):
             return super().forward(x)
         lins = plan["lins"]
         p = plan["p"] if self.training else 0.0
@@ -352,14 +381,52 @@ class FusedStack(nn.Sequential):
             for l in lins:
                 params += [l["lin"].weight, l["lin"].bias]
             return _ReluStackFn.apply(x, float(p), seed, lins[-1]["af"] == 1, *params)
+        kind = plan["kind"]
         params = []
         for l in lins:
             params += [l["lin"].weight, l["lin"].bias]
-            if plan["has_bn"]:
+            if kind == "bn":
                 bn = l["bn"]
                 params += [bn.weight if bn is not None else None, bn.bias if bn is not None else None]
-        spec = (len(lins), tuple(l["af"] for l in lins[:-1]), lins[-1]["af"], plan["has_bn"])
-        return _StackFn.apply(x, float(p), seed, spec, *params)
+            elif kind == "bn2":
+                m = l["bn2"]                      # LTRBatchNorm2 (utils.py:266-284): y = (gamma * xhat + beta) [* weight + bias] — folded into one
+                if m is None:                     # effective scale / shift per feature by tiny autograd-tracked vector ops
+                    params += [None, None]
+                else:
+                    N = l["lin"].weight.shape[0]
+                    g, b = m.gamma.reshape(N), m.beta.reshape(N)
+                    if m.affine:
+                        g, b = g * m.weight.reshape(N), b * m.weight.reshape(N) + m.bias.reshape(N)
+                    params += [g, b]
+        has_bn = kind is not None
+        group = x.shape[-2] if kind == "bn2" else 0
+        spec = (len(lins), tuple(l["af"] for l in lins[:-1]), lins[-1]["af"], has_bn, group)
+        if kind == "bn2" and not torch.is_grad_enabled():
+            # prediction mode of ltr_batch_norm (utils.py:229-231): the moving statistics instead of the query's own
+            fixed = []
+            for l in lins:
+                m = l["bn2"]
+                if m is None:
+                    fixed.append((None, None))
+                else:
+                    N = l["lin"].weight.shape[0]
+                    fixed.append((m.moving_mean.to(x.device).reshape(N).contiguous(),
+                                  torch.rsqrt(m.moving_var.to(x.device).reshape(N) + BN_EPS).contiguous()))
+            out = _stack_forward(x, float(p), seed, spec, [t.detach() if t is not None else None for t in params], fixed_stats=fixed)[0]
+            return out.view(*x.shape[:-1], out.shape[1])
+        sink = [] if kind == "bn2" else None
+        out = _StackFn.apply(x, float(p), seed, spec, sink, *params)
+        if sink:                                   # moving statistics, averaged over the queries of the batch (utils.py:242-245)
+            with torch.no_grad():
+                for i, mean, rstd in sink:
+                    m = lins[i]["bn2"]
+                    N = lins[i]["lin"].weight.shape[0]
+                    mq = mean.view(-1, N)
+                    vq = 1.0 / (rstd.view(-1, N) ** 2) - BN_EPS
+                    mom = m.momentum
+                    m.moving_mean = ((1.0 - mom) * m.moving_mean.to(x.device).reshape(1, N) + mom * mq).mean(dim=0).reshape(1, 1, N)
+                    m.moving_var = ((1.0 - mom) * m.moving_var.to(x.device).reshape(1, N) + mom * vq).mean(dim=0).reshape(1, 1, N)
+        return out
 
 
 ReluStack = FusedStack

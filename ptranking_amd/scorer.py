@@ -29,9 +29,9 @@ def fused_kind(num_features=None, h_dim=100, out_dim=1, num_layers=3, AF='R', TL
       'single'  the single-kernel scorer (forward = one kernel, backward = one kernel + reduction): AF='R', no batch norm, no tail
                 activation — the benchmark configuration;
       'stack'   the layer-wise fused stack (ptranking_amd/linear.py FusedStack: hand-written GEMMs + batch-norm / activation / dropout
-                kernels): every other working activation, bn_type='BN', tail activation — incl. the reference's DEFAULT pointsf
+                kernels): every other working activation, bn_type='BN' / 'BN2', tail activation — incl. the reference's DEFAULT pointsf
                 (5 layers, GELU, BN affine, Sigmoid tail; ptranking/ltr_adhoc/eval/parameter.py:145-146);
-      None      not covered (bn_type='BN2', RReLU): torch modules (their Linear layers still run the hand-written GEMMs)."""
+      None      not covered (RReLU and the broken get_AF entries): torch modules (their Linear layers still run the hand-written GEMMs)."""
     if AF == 'R' and not BN and not apply_tl_af and h_dim == HIDDEN and out_dim == 1 and 1 <= num_layers <= 8:
         hidden = (num_layers - 1) * 112 * 100 + num_layers * 112 + 112 + 16
         w1 = 112 * ((num_features + 3) // 4 * 4 + 4)
@@ -40,7 +40,7 @@ def fused_kind(num_features=None, h_dim=100, out_dim=1, num_layers=3, AF='R', TL
         # large F (Yahoo: 700): W1 streams from L2 — needs 16-byte aligned rows and at most 48 in-feature tiles
         if hidden * 4 <= 160 * 1024 and num_features % 4 == 0 and (num_features + 15) // 16 <= 48:
             return 'single'
-    if AF in _STACK_AF and (not apply_tl_af or TL_AF in _STACK_AF) and (not BN or bn_type == 'BN') and \
+    if AF in _STACK_AF and (not apply_tl_af or TL_AF in _STACK_AF) and (not BN or bn_type in ('BN', 'BN2')) and \
             (dropout == 0.0 or num_features % 4 == 0 or num_layers == 0):
         return 'stack'
     return None

@@ -36,7 +36,7 @@ def _cpu_forward_with_masks(net_cpu, x, p, seed, R):
     for m in net_cpu:
         if isinstance(m, nn.Dropout):
             if p > 0:
-                x = x * _mask(R, x.shape[-1], p, seed, site) / (1 - p)
+                x = x * _mask(R, x.shape[-1], p, seed, site).view(x.shape) / (1 - p)
             site += 1
         else:
             x = m(x)
@@ -49,7 +49,9 @@ def _cpu_forward_with_masks(net_cpu, x, p, seed, R):
                                  dict(num_layers=3, AF='SE', TL_AF='S', apply_tl_af=True, BN=False, bn_type=None, bn_affine=False),
                                  dict(num_layers=2, AF='LR', TL_AF='E', apply_tl_af=True, BN=True, bn_type='BN', bn_affine=True),
                                  dict(num_layers=4, AF='CE', TL_AF='S', apply_tl_af=False, BN=True, bn_type='BN', bn_affine=True),
-                                 dict(num_layers=3, AF='S', TL_AF='R', apply_tl_af=True, BN=False, bn_type=None, bn_affine=False)])
+                                 dict(num_layers=3, AF='S', TL_AF='R', apply_tl_af=True, BN=False, bn_type=None, bn_affine=False),
+                                 dict(num_layers=3, AF='GE', TL_AF='S', apply_tl_af=True, BN=True, bn_type='BN2', bn_affine=True),
+                                 dict(num_layers=2, AF='R', TL_AF='S', apply_tl_af=False, BN=True, bn_type='BN2', bn_affine=False)])
 @pytest.mark.parametrize("p", [0.0, 0.1])
 def test_fused_stack_matches_torch_cpu_modules(cfg, p):
     from ptranking_amd.host import build_pointsf
@@ -63,6 +65,10 @@ def test_fused_stack_matches_torch_cpu_modules(cfg, p):
         for n_, prm in net.named_parameters():
             if "bn" in n_:
                 prm.add_(0.3 * torch.randn_like(prm))
+        for m_ in net.modules():                            # LTRBatchNorm2: non-trivial moving statistics
+            if hasattr(m_, "moving_mean"):
+                m_.moving_mean = 0.2 * torch.randn_like(m_.moving_mean)
+                m_.moving_var = 1.0 + 0.3 * torch.rand_like(m_.moving_var)
     ref = copy.deepcopy(net)                                # CPU tensors -> FusedStack.forward = the plain torch modules
     net = net.cuda()
     net.train(); ref.train()
@@ -74,20 +80,29 @@ def test_fused_stack_matches_torch_cpu_modules(cfg, p):
     assert net._plan and not net._plan["relu_only"]
     g = torch.randn_like(out)
     out.backward(g)
-    xr = x.clone().reshape(R, 136).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)                      # [B, L, F]: LTRBatchNorm2 normalises over dim 1
     outr = _cpu_forward_with_masks(ref, xr, p, net.last_seed, R)
-    outr.backward(g.cpu().reshape(R, -1))
-    close(out.reshape(R, -1), outr, what="out")
-    close(xg.grad.reshape(R, -1), xr.grad, tol=1e-4, what="dx")
+    outr.backward(g.cpu())
+    close(out, outr, what="out")
+    close(xg.grad, xr.grad, tol=1e-4, what="dx")
     got = dict(net.named_parameters())
     for n_, prm in ref.named_parameters():
         close(got[n_].grad, prm.grad, tol=1e-4, what=n_)
     assert list(net.state_dict()) == list(ref.state_dict())
-    # LTRBatchNorm has no running statistics: evaluation uses the batch statistics too (utils.py:214); no dropout in eval
+    if cfg["bn_type"] == 'BN2':                             # the moving statistics were updated like the reference's (utils.py:242-245)
+        for (na, ma), (nb, mb) in zip(net.named_modules(), ref.named_modules()):
+            if hasattr(ma, "moving_mean"):
+                if p == 0.0:                                # (with dropout the CPU side above bypassed nn.Sequential.forward's own masks)
+                    close(ma.moving_mean.reshape(-1), mb.moving_mean.reshape(-1), tol=1e-4, what=f"{na}.moving_mean")
+                    close(ma.moving_var.reshape(-1), mb.moving_var.reshape(-1), tol=1e-4, what=f"{na}.moving_var")
+                mb.moving_mean, mb.moving_var = ma.moving_mean.cpu().clone(), ma.moving_var.cpu().clone()
+    # LTRBatchNorm has no running statistics: evaluation uses the batch statistics too (utils.py:214); no dropout in eval.
+    # LTRBatchNorm2 decides by torch.is_grad_enabled() (utils.py:229): under no_grad it normalises with the moving statistics
     net.eval(); ref.eval()
     with torch.no_grad():
-        close(net(xg).reshape(R, -1), ref(x.reshape(R, 136)), what="eval")
+        close(net(xg), ref(x), what="eval (no_grad)")
         assert torch.equal(net(xg), net(xg))
+    close(net(xg), ref(x), what="eval (grad enabled: batch statistics)")
 
 
 def test_default_pointsf_ranker_trains_on_the_fused_stack():
