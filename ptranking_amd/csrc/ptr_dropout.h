@@ -13,9 +13,18 @@ __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
 }
 // 64 random bits for features [4*fg, 4*fg+3] of `row` at dropout site `site` (site l = the Dropout in front of hidden layer l)
 __device__ __forceinline__ void drop_bits(uint32_t seed_lo, uint32_t seed_hi, int site, int row, int fg, uint32_t &w0, uint32_t &w1) {
-    const uint32_t key = (uint32_t)row * 0x9E3779B1u + (uint32_t)fg * 0x85EBCA77u + (uint32_t)site * 0xC2B2AE3Du;
+    // 32-bit integer multiplies are quarter rate on CDNA: the row term is loop invariant for a lane (hoisted by the compiler), the
+    // first word gets the full two-multiply finaliser, the second word one more multiply-xorshift round on top of it
+    // (PTR_DROP_FULL_HASH restores the round-1 generator: a second full finaliser)
+    const uint32_t key = (uint32_t)row * 0x9E3779B1u + ((uint32_t)fg * 0x85EBCA77u + (uint32_t)site * 0xC2B2AE3Du);
     w0 = lowbias32(key ^ seed_lo);
+#ifdef PTR_DROP_FULL_HASH
     w1 = lowbias32(w0 ^ seed_hi ^ 0x68E31DA4u);
+#else
+    uint32_t t = w0 ^ seed_hi ^ 0x68E31DA4u;
+    t ^= t >> 15; t *= 0x2C1B3C6Du; t ^= t >> 13;
+    w1 = t;
+#endif
 }
 __device__ __forceinline__ f32x4 drop4(f32x4 v, uint32_t w0, uint32_t w1, uint32_t thr, float scale) {
     // multiplicative masks on purpose: with a select hipcc sinks the producing global load under the predicate and

@@ -91,6 +91,12 @@ __host__ __device__ inline size_t fwd_lds_floats(int F, int NL, bool w1_global) 
 }
 __host__ __device__ inline bool fwd_needs_global_w1(int F, int NL) { return fwd_lds_floats(F, NL, false) * sizeof(float) > 160 * 1024; }
 
+#ifdef PTR_FWD_TRACE   // experiment builds: shader-clock stamps of workgroup 0's first tiles behind the predictions (preds is over-allocated)
+#define FWD_STAMP(i) do { if (blockIdx.x == 0 && lane == 0 && ntile_done < 8) reinterpret_cast<unsigned long long *>(preds + ((R + 3) & ~3) + 4)[(ntile_done * 16 + wave) * 8 + (i)] = clock64(); } while (0)
+#else
+#define FWD_STAMP(i) do { } while (0)
+#endif
+
 template <int RT, int NTHR, bool TRAIN, bool VEC, bool W1G>
 __global__ void __launch_bounds__(NTHR)
 mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs a, float *__restrict__ preds,
@@ -118,11 +124,25 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
     const float scale = TRAIN ? 1.0f / (1.0f - a.p_drop) : 1.0f;
     const int nS1 = (F + 15) >> 4;
 
-    for (int tile = blockIdx.x * wpb + wave; tile < ntiles; tile += gridDim.x * wpb) {
+    int ntile_done = 0;
+    (void)ntile_done;
+#ifndef PTR_FWD_STATIC_TILES
+    // dynamic tile queue per workgroup: the two waves of a SIMD do not progress at the same rate (the older one wins the issue
+    // arbitration: 90 K vs 145 K cycles per tile measured) — with a static split the faster half idles at the end
+    const int tiles_per_block = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int tile_lo = blockIdx.x * tiles_per_block, tile_hi = min(ntiles, tile_lo + tiles_per_block);
+    int *queue = reinterpret_cast<int *>(Wo + kHP + 8);
+    if (tid == 0) *queue = tile_lo + wpb;
+    __syncthreads();
+    for (int tile = tile_lo + wave; tile < tile_hi; ++ntile_done) {
+#else
+    for (int tile = blockIdx.x * wpb + wave; tile < ntiles; tile += gridDim.x * wpb, ++ntile_done) {
+#endif
         const int row0 = tile * rows_per_tile;
         int row[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) row[rt] = row0 + 16 * rt + j;
+        FWD_STAMP(0);
 
         // X loads are branch-free: out-of-range rows / columns read a clamped (valid) address and are zeroed by a select
         const float *xrow[RT];
@@ -173,32 +193,39 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
         f32x4 xcur[RT], xnxt[RT];
         load_raw(0, xcur);
         finish_x(0, xcur);
+        // A operands (weight fragments): the 7 fragments of a super-step are read as one batch (see the hidden layers below)
+        auto read_w1 = [&](int S, int mt) -> f32x4 {
+            const int k0 = 16 * S + 4 * g;
+            if constexpr (W1G) {   // [100][F] in global memory: clamp the padded rows 100..111 and zero them
+                const int wr = 16 * mt + j;
+                const float rok1 = wr < kH ? 1.0f : 0.0f;
+                f32x4 w = *reinterpret_cast<const f32x4 *>(P + (size_t)(wr < kH ? wr : kH - 1) * F + (k0 < F ? k0 : 0));
+#pragma unroll
+                for (int c = 0; c < 4; ++c) w[c] *= rok1;
+                return w;
+            } else {
+                return *reinterpret_cast<const f32x4 *>(W1s + (size_t)(16 * mt + j) * ld1 + k0);
+            }
+        };
         for (int S = 0; S < nS1; ++S) {
             if (S + 1 < nS1) load_raw(S + 1, xnxt);
-            const int k0 = 16 * S + 4 * g;
+            f32x4 wa[kMT];
 #pragma unroll
-            for (int mt = 0; mt < kMT; ++mt) {
-                f32x4 wa;
-                if constexpr (W1G) {   // [100][F] in global memory: clamp the padded rows 100..111 and zero them
-                    const int wr = 16 * mt + j;
-                    const float rok1 = wr < kH ? 1.0f : 0.0f;
-                    wa = *reinterpret_cast<const f32x4 *>(P + (size_t)(wr < kH ? wr : kH - 1) * F + (k0 < F ? k0 : 0));
+            for (int mt = 0; mt < kMT; ++mt) wa[mt] = read_w1(S, mt);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) wa[c] *= rok1;
-                } else {
-                    wa = *reinterpret_cast<const f32x4 *>(W1s + (size_t)(16 * mt + j) * ld1 + k0);
-                }
+            for (int mt = 0; mt < kMT; ++mt)
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt)
-                        acc[mt][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c], xcur[rt][c], acc[mt][rt], 0, 0, 0);
-            }
+                        acc[mt][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mt][c], xcur[rt][c], acc[mt][rt], 0, 0, 0);
             if (S + 1 < nS1) finish_x(S + 1, xnxt);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) xcur[rt] = xnxt[rt];
         }
 
+        FWD_STAMP(1);
         // ---- hidden layers 2..NL: B operand = the previous layer's output registers
         for (int l = 1; l < NL; ++l) {
             f32x4 hin[kMT][RT];
@@ -211,13 +238,21 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
                     for (int c = 0; c < 4; ++c) h[c] = fmaxf(h[c], 0.0f);
                     if constexpr (TRAIN) {
                         uint32_t w0, w1;
+#ifndef PTR_FWD_NOHASH
                         drop_bits(a.seed_lo, a.seed_hi, l, row[rt], 4 * mt + g, w0, w1);
                         h = drop4(h, w0, w1, thr, scale);
+#else
+                        (void)w0; (void)w1;
+#endif
                         if (row[rt] < R) {
                             f32x4 hs = h;
                             if (mt == kMT - 1) hs[0] = g == 1 ? 1.0f : hs[0];   // feature 100 (padding) = 1: the fused backward reads db_l
                                                                                // off this ones column of its A image (scorer_bwd.hip)
+#if !defined(PTR_FWD_NOSTORE)
                             *reinterpret_cast<f32x4 *>(acts + ((size_t)(l - 1) * R + row[rt]) * kAL + 16 * mt + 4 * g) = hs;
+#else
+                            if (hs[0] == 123.456f) acts[0] = 1.0f;
+#endif
                         }
                     }
                     hin[mt][rt] = h;
@@ -229,19 +264,25 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) acc[mt][rt] = b4;
             }
+            // the 7 weight fragments of a super-step are read as ONE batch (one exposed LDS latency per 56 MFMAs): with the read issued
+            // right in front of its 8 MFMAs — what hipcc schedules on its own — every group waits out the full LDS latency
 #pragma unroll
-            for (int S = 0; S < kMT; ++S)
+            for (int S = 0; S < kMT; ++S) {
+                f32x4 wa[kMT];
 #pragma unroll
-                for (int mt = 0; mt < kMT; ++mt) {
-                    const f32x4 wa = *reinterpret_cast<const f32x4 *>(Wl + (size_t)(16 * mt + j) * kH + 16 * S + 4 * g);
+                for (int mt = 0; mt < kMT; ++mt) wa[mt] = *reinterpret_cast<const f32x4 *>(Wl + (size_t)(16 * mt + j) * kH + 16 * S + 4 * g);
+                __builtin_amdgcn_sched_barrier(0);          // keep the batch in front of the MFMAs (the scheduler would sink every read to its use)
+#pragma unroll
+                for (int mt = 0; mt < kMT; ++mt)
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
 #pragma unroll
                         for (int rt = 0; rt < RT; ++rt)
-                            acc[mt][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c], hin[S][rt][c], acc[mt][rt], 0, 0, 0);
-                }
+                            acc[mt][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mt][c], hin[S][rt][c], acc[mt][rt], 0, 0, 0);
+            }
         }
 
+        FWD_STAMP(2);
         // ---- last hidden activation + output layer (100 -> 1): VALU dot product, reduced over the 4 lane groups
         float sc[RT];
 #pragma unroll
@@ -255,8 +296,9 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { h[c] = fmaxf(h[c], 0.0f); sc[rt] = fmaf(h[c], w4[c], sc[rt]); }
                 if constexpr (TRAIN) {
-                    if (row[rt] < R)
+                    if (row[rt] < R) {
                         *reinterpret_cast<f32x4 *>(acts + ((size_t)(NL - 1) * R + row[rt]) * kAL + 16 * mt + 4 * g) = h;
+                    }
                 }
             }
         }
@@ -267,6 +309,12 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
             s += __shfl_xor(s, 32, 64);
             if (g == 0 && row[rt] < R) preds[row[rt]] = s + b_out;
         }
+        FWD_STAMP(3);
+#ifndef PTR_FWD_STATIC_TILES
+        int nxt = 0;
+        if (lane == 0) nxt = atomicAdd(queue, 1);
+        tile = __builtin_amdgcn_readfirstlane(nxt);
+#endif
     }
 }
 
