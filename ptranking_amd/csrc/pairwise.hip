@@ -198,14 +198,16 @@ pairwise_bce_kernel(const float *__restrict__ preds, const float *__restrict__ l
 // LambdaRank "ring" kernel (list lengths up to 256, sigma > 0): ONE wavefront per query, the pair loop runs entirely out of
 // registers with wavefront shuffles — no LDS access, no address arithmetic, no branch inside the O(L^2) loop.
 //
-// Documents sit at their rank position p = DPT*lane + slot (DPT = ceil(L/64) per lane, ring size RS = 64*DPT; positions
-// n..RS-1 hold padding records).  Every lane keeps its own records {s, G, D} fixed and owns DPT travelling records
-// {s, G, D, g}; one ring step moves the travelling records to the neighbouring lane (v_mov_b32_dpp wave_rol:1) and pairs every
-// own slot with every travelling slot: after r steps lane a meets the records of lane a+r, i.e. the circulant schedule of the
-// LDS kernel above, with the partner's gradient share accumulated in the travelling g instead of an LDS read-modify-write.
-// After 32 steps the travelling g of a position sits 32 lanes away from its owner and is added back with one shuffle.
+// Lane a owns documents a, a+64, ... (DPT = ceil(L/64) per lane, ring size RS = 64*DPT; slots n..RS-1 hold padding records)
+// in INPUT order: the pair body needs every record's D = 1/log2(rank+2), not a sorted arrangement, so the ranks are counted
+// (one packed fma-with-clamp per two compares, see below) and nothing is scattered; loads and gradient stores are coalesced.
+// Every lane keeps its own records {s, G, D} fixed and owns DPT travelling records {s, G, D, g}; one ring step moves the
+// travelling records to the neighbouring lane (v_mov_b32_dpp wave_rol:1) and pairs every own slot with every travelling slot:
+// after r steps lane a meets the records of lane a+r, i.e. the circulant schedule of the LDS kernel above, with the partner's
+// gradient share accumulated in the travelling g instead of an LDS read-modify-write.  After 32 steps the travelling g of a
+// record sits 32 lanes away from its owner and is added back with one shuffle.
 //
-// Per pair: ~17 VALU-issue slots incl. 3 transcendentals (the LDS kernel: ~42 + 3 + 3 LDS).  What makes the body that short:
+// Per pair: 16.75 VALU-issue slots incl. 3 transcendentals (the LDS kernel: ~42 + 3 + 3 LDS).  What makes the body that short:
 //   * D = 1/log2(rank+2) is strictly decreasing in the rank, so the sign of dD = D_own - D_T tells which of the two is ranked
 //     first: no position arithmetic and no wrap-around bookkeeping.  prod = (G_own-G_T)*dD > 0  <=>  the first-ranked document
 //     has the larger gain (target 1); wsg = sigma*|dG|*dD is the pair weight carrying the orientation sign, so the own
@@ -217,25 +219,77 @@ pairwise_bce_kernel(const float *__restrict__ preds, const float *__restrict__ l
 // Arithmetic per pair is otherwise the reference's (see the header): p = fl(1/(1+e^-x)), q = fl(1-p), BCE's -100 clamp, and a
 // gradient that is exactly 0 once p rounds to 1.
 using f32x2 = __attribute__((ext_vector_type(2))) float;
+// v_pk_fma_f32 with the clamp modifier: {clamp(a.x*b.x+c.x, 0, 1), clamp(a.y*b.y+c.y, 0, 1)}
+__device__ __forceinline__ f32x2 pk_fma_clamp(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// a - b as ONE packed instruction (the compiler splits a v2f32 subtraction whose lanes are consumed separately)
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// Wavefront sum out of the VALU alone (DPP row operations + one v_readlane; the butterfly wave_sum() goes through the LDS
+// crossbar six times, latency the four co-resident waves cannot hide because they run the same phase).  Fixed order; every lane
+// receives the same value.
+#define PTR_DPP_ADD(v, ctrl, rows) \
+    (v) += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (rows), 0xF, false))
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    PTR_DPP_ADD(v, 0xB1, 0xF);        // quad_perm [1,0,3,2]
+    PTR_DPP_ADD(v, 0x4E, 0xF);        // quad_perm [2,3,0,1]
+    PTR_DPP_ADD(v, 0x141, 0xF);       // row_half_mirror
+    PTR_DPP_ADD(v, 0x140, 0xF);       // row_mirror: every lane holds its row's sum
+    PTR_DPP_ADD(v, 0x142, 0xA);       // row_bcast:15 into rows 1 and 3
+    PTR_DPP_ADD(v, 0x143, 0xC);       // row_bcast:31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+#undef PTR_DPP_ADD
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// 1 / log2(pos + 2)
+__device__ __forceinline__ float inv_log2_pos(int pos) {
+    const float d = __builtin_amdgcn_logf((float)(pos + 2));
+    const float r = __builtin_amdgcn_rcpf(d);
+    return fmaf(r, fmaf(-d, r, 1.0f), r);
+}
+// LDS hand-over between the lanes of ONE wavefront (its own LDS region): LDS operations of a wave execute in order, only the
+// compiler has to be kept from reordering them — no workgroup barrier, the four waves of a block stay independent
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+#ifndef PTR_RING_DPP
+#define PTR_RING_DPP 0x134
+#endif
 __device__ __forceinline__ float dpp_rol1(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x134 /* wave_rol:1 */, 0xF, 0xF, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), PTR_RING_DPP /* wave_rol:1 */, 0xF, 0xF, false));
 }
 
+// The waves of a block are independent (one query each, wave-local LDS hand-overs), so the block size is a launch-time choice:
+// up to 16 waves per workgroup.  256 workgroups of 16 waves spread evenly over the 256 CUs; 1024 workgroups of 4 do not (the
+// dispatcher fills some CUs deeper than others: 33.7 us vs 29.9 us for 4096 queries of 128 documents).
+constexpr int kRingBlock = 1024;
 template <int DPT>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kRingBlock)
 lambdarank_ring_kernel(const float *__restrict__ preds, const float *__restrict__ labels, const int32_t *__restrict__ lens,
                        int B, int L, float sigma, float *__restrict__ loss_q, float *__restrict__ grad) {
-    constexpr int RS = 64 * DPT, QPB = kBlock / kWave;
+    constexpr int RS = 64 * DPT;
+    const int QPB = blockDim.x >> 6;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int q = blockIdx.x * QPB + wv;
     const bool valid = q < B;
-    const int n = valid ? query_len(lens, q, L) : 0;
-    float *keys = smem + (size_t)wv * (3 * RS);            // raw scores for the counting sort; later: gradients by position
-    float *ps = keys + RS;                                 // scores by rank position
-    float *pg = ps + RS;                                   // normalised gains by rank position
+    const int n = __builtin_amdgcn_readfirstlane(valid ? query_len(lens, q, L) : 0);      // wave-uniform: scalar loop control
+    float *keys = smem + (size_t)wv * (2 * RS);            // raw scores, broadcast-read by the rank count
+    int *mark = reinterpret_cast<int *>(keys + RS);        // tie detection
 
-    // ---- coalesced load, rank by score (counting sort, ties by original index), IDCG
+    // ---- coalesced load: lane owns documents i = lane + 64 m, and keeps them (records stay in INPUT order: the pair body only
+    // needs every record's D = 1/log2(rank+2), not a sorted arrangement)
     float si[DPT], li[DPT];
 #pragma unroll
     for (int m = 0; m < DPT; ++m) {
@@ -245,53 +299,76 @@ lambdarank_ring_kernel(const float *__restrict__ preds, const float *__restrict_
         li[m] = in ? labels[(size_t)q * L + i] : 0.0f;
         keys[i] = si[m];
     }
-    __syncthreads();
-    // rank = #{j : s_j > s_i}: one compare + one add-with-carry per key.  Ties (equal scores; rare) are detected by a marker
-    // collision — every real document writes its index at its rank, a document that reads back another index shares its rank —
-    // and only then the wave recounts with the index tie-break (count_ranks).
+    wave_lds_sync();
+    // rank = #{j : s_j > s_i}, ONE VALU slot per compare: t = clamp(BIG*s_j - BIG*s_i, 0, 1) is exactly 1 for s_j > s_i and 0
+    // otherwise (v_pk_fma_f32 with the clamp modifier: two compares per instruction; the fma is exact up to its final rounding, so
+    // the sign is right and 0 means equal), summed in fp32 (exact up to 2^24).  BIG = 2^100: t is fractional only for
+    // 0 < s_j - s_i < 2^-100, and BIG*s overflows only for |s| >= 2^28 (inf - inf = NaN clamps to 0) — either way the sums are
+    // not all integers or two documents share a rank; both are detected below and the wave recounts with compares
+    // (count_ranks), as it does for ties (equal scores; rank = original index order).
     int rk[DPT];
-#pragma unroll
-    for (int m = 0; m < DPT; ++m) rk[m] = 0;
     {
-        const float4 *k4 = reinterpret_cast<const float4 *>(keys);
-        const int n4 = (n + 3) >> 2;
-        for (int j4 = 0; j4 < n4; ++j4) {
-            const float4 v = k4[j4];
+        const float big = 0x1p100f;
+        const f32x2 big2 = {big, big};
+        f32x2 nsb[DPT], cnt[DPT];
 #pragma unroll
-            for (int m = 0; m < DPT; ++m) rk[m] += (v.x > si[m]) + (v.y > si[m]) + (v.z > si[m]) + (v.w > si[m]);
+        for (int m = 0; m < DPT; ++m) {
+            const float v = lane + 64 * m < n ? -si[m] * big : 0.0f;
+            nsb[m] = f32x2{v, v}; cnt[m] = f32x2{0.0f, 0.0f};
         }
-    }
-    int *mark = reinterpret_cast<int *>(ps);
+        const float4 *k4 = reinterpret_cast<const float4 *>(keys);
+        // keys[n..RS) = -inf contribute 0: whole groups of 8 keys, the next group's reads issued ahead of this one's arithmetic
+        const int n8 = (n + 7) >> 3;
+        float4 va = k4[0], vb = k4[1];
+        for (int j8 = 0; j8 < n8; ++j8) {
+            const float4 ua = va, ub = vb;
+            const int nx = min(j8 + 1, RS / 8 - 1);
+            va = k4[2 * nx]; vb = k4[2 * nx + 1];
+            const f32x2 u0 = {ua.x, ua.y}, u1 = {ua.z, ua.w}, u2 = {ub.x, ub.y}, u3 = {ub.z, ub.w};
 #pragma unroll
-    for (int m = 0; m < DPT; ++m) {
-        const int i = lane + 64 * m;
-        if (i < n) mark[rk[m]] = i;
-    }
-    __syncthreads();
-    bool tie = false;
+            for (int m = 0; m < DPT; ++m) {
+                cnt[m] += pk_fma_clamp(u0, big2, nsb[m]);
+                cnt[m] += pk_fma_clamp(u1, big2, nsb[m]);
+                cnt[m] += pk_fma_clamp(u2, big2, nsb[m]);
+                cnt[m] += pk_fma_clamp(u3, big2, nsb[m]);
+            }
+        }
+        bool redo = false;
 #pragma unroll
-    for (int m = 0; m < DPT; ++m) {
-        const int i = lane + 64 * m;
-        tie |= i < n && mark[rk[m]] != i;
+        for (int m = 0; m < DPT; ++m) {
+            const int i = lane + 64 * m;
+            const float c = cnt[m].x + cnt[m].y;
+            rk[m] = (int)c;
+            redo |= i < n && ((float)rk[m] != c || rk[m] >= n);
+            if (i < n && rk[m] < n) mark[rk[m]] = i;
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int m = 0; m < DPT; ++m) {
+            const int i = lane + 64 * m;
+            redo |= i < n && rk[m] < n && mark[rk[m]] != i;
+        }
+        if (__any(redo)) count_ranks<kWave, DPT>(keys, n, lane, si, rk);
     }
-    if (__any(tie)) count_ranks<kWave, DPT>(keys, n, lane, si, rk);
-    __syncthreads();                                      // mark (= ps) is rewritten below
+    // own records {s, G, D}: G = gain / IDCG (labels arrive in ideal order: DCG of the input order is the IDCG), D by rank.
+    // 1/log2(.) = v_log_f32 + v_rcp_f32 with one Newton step (<= 1 ulp; the parity bar is 1e-5).
+    float Di[DPT], Gi[DPT];
     float part = 0.0f;
 #pragma unroll
     for (int m = 0; m < DPT; ++m) {
         const int i = lane + 64 * m;
-        if (i < n) part += gain_of(li[m]) / log2f((float)i + 2.0f);      // labels arrive in ideal order: DCG(input order) = IDCG
+        const bool in = i < n;
+        Gi[m] = in ? gain_of(li[m]) : 0.0f;
+        part = fmaf(Gi[m], inv_log2_pos(i), part);
+        Di[m] = inv_log2_pos(in ? rk[m] : i);              // padding keeps positions n..RS-1
     }
-    const float idcg = wave_sum(part);
+    const float ridcg = 1.0f / wave_sum_dpp(part);
 #pragma unroll
     for (int m = 0; m < DPT; ++m) {
-        const int i = lane + 64 * m;
-        const bool in = i < n;
-        const int r = in ? rk[m] : i;                      // padding keeps positions n..RS-1
-        ps[r] = in ? si[m] : -1e30f;
-        pg[r] = in ? gain_of(li[m]) / idcg : -1.0f;
+        const bool in = lane + 64 * m < n;
+        Gi[m] = in ? Gi[m] * ridcg : -1.0f;
+        si[m] = in ? si[m] : -1e30f;
     }
-    __syncthreads();
 
     // ---- own records by position p = DPT*lane + slot; travelling copies
     const float c2 = sigma * 1.4426950408889634f;          // x*log2(e) folded into sigma
@@ -300,7 +377,7 @@ lambdarank_ring_kernel(const float *__restrict__ preds, const float *__restrict_
     float lacc = 0.0f;
     if constexpr (DPT == 1) {
         // one document per lane: scalar pair body, the travelling record moves one lane per step
-        const float so = ps[lane], go = pg[lane], Do = 1.0f / log2f((float)lane + 2.0f);
+        const float so = si[0], go = Gi[0], Do = Di[0];
         float Ts = so, Tg = go, Td = Do;
         ga[0] = 0.0f; Tacc[0] = 0.0f;
         for (int step = 1; step <= 32; ++step) {
@@ -330,29 +407,35 @@ lambdarank_ring_kernel(const float *__restrict__ preds, const float *__restrict_
         f32x2 Ts[DPT / 2], Tg[DPT / 2], Td[DPT / 2], Ta[DPT / 2], ga2[DPT];
 #pragma unroll
         for (int k = 0; k < DPT; ++k) {
-            const int pos = DPT * lane + k;
-            const float s_ = ps[pos], g_ = pg[pos], d_ = 1.0f / log2f((float)pos + 2.0f);
+            const float s_ = si[k], g_ = Gi[k], d_ = Di[k] * sigma;     // un = sigma*dG*dD: sigma rides on D (signs unchanged)
             so2[k] = f32x2{s_, s_}; go2[k] = f32x2{g_, g_}; Do2[k] = f32x2{d_, d_};
             ga2[k] = f32x2{0.f, 0.f};
             Ts[k / 2][k & 1] = s_; Tg[k / 2][k & 1] = g_; Td[k / 2][k & 1] = d_; Ta[k / 2][k & 1] = 0.0f;
         }
-        const f32x2 c22 = {c2, c2}, sg2 = {sigma, sigma}, one2 = {1.0f, 1.0f};
+        const f32x2 c22 = {c2, c2}, one2 = {1.0f, 1.0f}, half2 = {0.5f, 0.5f};
         auto pair2 = [&](int k, int j, f32x2 mask, bool use_mask) {
             const f32x2 x = (so2[k] - Ts[j]) * c22;
             const f32x2 e = {__builtin_amdgcn_exp2f(-fabsf(x.x)), __builtin_amdgcn_exp2f(-fabsf(x.y))};
             const f32x2 dd = one2 + e;
             f32x2 p = {__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y)};
             p = __builtin_elementwise_fma(p, __builtin_elementwise_fma(-dd, p, one2), p);
-            const f32x2 qv = one2 - p;
-            const f32x2 dDn = Td[j] - Do2[k];
-            f32x2 un = ((go2[k] - Tg[j]) * dDn) * sg2;
+            const f32x2 dDn = Td[j] - Do2[k];                        // D carries sigma
+            f32x2 un = (go2[k] - Tg[j]) * dDn;
             if (use_mask) un = un * mask;
+            // a = probability of the target's outcome (t1 ? p : 1-p), r = 1 - a the gradient factor, without compare/select:
+            // with h = p - 1/2 (exact for p in [0.5, 1]) and c = copysign(h, un):  a = 1/2 - c,  r = 1/2 + c  (both exact:
+            // un < 0 <=> target 1 gives a = p, r = 1-p; otherwise a = 1-p, r = p).  fract() sends r = 1 (p has rounded to 1 on a
+            // target-0 pair) to 0, where the reference's p(1-p) factor vanishes.
+            const f32x2 hh = pk_sub(p, half2);
+            f32x2 c;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) c[h] = __builtin_copysignf(hh[h], un[h]);
+            const f32x2 a = pk_sub(half2, c), r = pk_add(half2, c);
             f32x2 m;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const bool t1 = un[h] < 0.0f;
-                lacc = fmaf(fabsf(un[h]), fmaxf(__builtin_amdgcn_logf(t1 ? p[h] : qv[h]), kClamp), lacc);
-                m[h] = __builtin_copysignf(t1 ? qv[h] : __builtin_amdgcn_fractf(p[h]), dDn[h]);      // one v_bfi_b32
+                lacc = fmaf(fabsf(un[h]), fmaxf(__builtin_amdgcn_logf(a[h]), kClamp), lacc);
+                m[h] = __builtin_copysignf(__builtin_amdgcn_fractf(r[h]), dDn[h]);      // one v_bfi_b32
             }
             ga2[k] = __builtin_elementwise_fma(-un, m, ga2[k]);
             Ta[j] = __builtin_elementwise_fma(un, m, Ta[j]);
@@ -393,24 +476,27 @@ lambdarank_ring_kernel(const float *__restrict__ preds, const float *__restrict_
 #pragma unroll
         for (int k = 0; k < DPT; ++k) { ga[k] = ga2[k].x + ga2[k].y; Tacc[k] = Ta[k / 2][k & 1]; }
     }
-    // the travelling accumulators are half a ring (32 lanes) away from their owners
+    // the travelling accumulators are half a ring (32 lanes) away from their owners; gradients leave in input order, coalesced
+    const float loss = wave_sum_dpp(lacc) * (-0.6931471805599453f / sigma);
 #pragma unroll
     for (int k = 0; k < DPT; ++k) {
         const float tot = ga[k] + __shfl_xor(Tacc[k], 32, 64);
-        keys[DPT * lane + k] = tot;
+        const int i = lane + 64 * k;
+        if (valid && i < L) grad[(size_t)q * L + i] = i < n ? tot : 0.0f;
     }
-    __syncthreads();
-    const float loss = wave_sum(lacc) * (-0.6931471805599453f / sigma);
-    if (valid) {
-#pragma unroll
-        for (int m = 0; m < DPT; ++m) {
-            const int i = lane + 64 * m;
-            if (i < L) grad[(size_t)q * L + i] = i < n ? keys[rk[m]] : 0.0f;
-        }
-        if (lane == 0) loss_q[q] = loss;
-    }
+    if (valid && lane == 0) loss_q[q] = loss;
 }
 
+static int ring_waves() {                         // PTR_RING_WAVES=1/2/4/8/16 pins the waves per workgroup (measurements)
+    const char *e = getenv("PTR_RING_WAVES");
+    const int v = e ? atoi(e) : 0;
+    return v == 1 || v == 2 || v == 4 || v == 8 || v == 16 ? v : 0;
+}
+static int ring_num_cus() {
+    static int n = 0;
+    if (!n) { int dev = 0; hipDeviceProp_t pr; n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
+    return n;
+}
 static int ring_enabled() {                       // PTR_LAMBDARANK_RING=0 selects the LDS kernel (A/B measurements, tests)
     const char *e = getenv("PTR_LAMBDARANK_RING");
     return e ? (atoi(e) != 0) : 1;
@@ -425,8 +511,10 @@ static int launch_pairwise(const float *preds, const float *labels, const int32_
     hipStream_t st = as_stream(stream);
     if (WEIGHTED && B > 0 && L <= 256 && sigma > 0.0f && ring_enabled()) {
         auto go = [&](auto kern, int dpt) -> int {
-            const size_t lds = (size_t)(kBlock / kWave) * 3 * 64 * dpt * sizeof(float);
-            hipLaunchKernelGGL(kern, dim3((B + 3) / 4), dim3(kBlock), lds, st, preds, labels, lens, B, L, sigma, loss_q, grad);
+            int QPB = ring_waves();
+            if (!QPB) { QPB = kRingBlock / kWave; while (QPB > 1 && B < QPB * ring_num_cus()) QPB >>= 1; }
+            const size_t lds = (size_t)QPB * 2 * 64 * dpt * sizeof(float);
+            hipLaunchKernelGGL(kern, dim3((B + QPB - 1) / QPB), dim3(QPB * kWave), lds, st, preds, labels, lens, B, L, sigma, loss_q, grad);
             return check_hip(hipGetLastError(), who);
         };
         int rc = L <= 64 ? go(lambdarank_ring_kernel<1>, 1) : L <= 128 ? go(lambdarank_ring_kernel<2>, 2) : go(lambdarank_ring_kernel<4>, 4);
