@@ -214,7 +214,7 @@ pairwise_bce_kernel(const float *__restrict__ preds, const float *__restrict__ l
 //     gradient share is wsg*(p - t) and the partner's its negative, for either orientation;
 //   * s_first - s_second = |s_own - s_T| (rank order = score order), so x = sigma*|ds| needs no select;
 //   * padding needs no mask: s = -1e30 (=> p = 1, q = 0, gradient factor 0), G = -1 (=> target 1, log p = 0) make every pair
-//     with a padding record contribute exactly 0 to loss and gradients;
+//     with a padding record contribute exactly 0 to loss and gradients (scores are assumed to lie far above -1e30);
 //   * the loss is accumulated as sum |wsg| * max(log2(.), -100/ln2) and scaled by ln2/sigma once per query.
 // Arithmetic per pair is otherwise the reference's (see the header): p = fl(1/(1+e^-x)), q = fl(1-p), BCE's -100 clamp, and a
 // gradient that is exactly 0 once p rounds to 1.

@@ -161,6 +161,37 @@ def test_oracle_pairwise(F, B, L, use_lens):
         G.assert_close(grad, g, f"{name} grad")
 
 
+@pytest.mark.parametrize("L", [40, 128, 200, 256])
+@pytest.mark.parametrize("case", ["huge", "tiny", "all_tied", "some_tied", "mixed_scale"])
+def test_ring_rank_count_fallback(F, L, case):
+    """The ring kernel counts ranks with one packed fma-with-clamp per two compares (exact unless BIG*s overflows or a score
+    difference is below 2^-100) and recounts with compares when the sums are not a permutation: scores that overflow the
+    scaled form, differences below its resolution, and ties must all come out as the oracle's (index-order tie-break)."""
+    from oracle import c_oracle as CO
+    B = 6
+    preds, labels, ln = synth(4000 + L, B, L, lens=True)
+    if case == "huge":
+        preds = preds * np.float32(1e27)                  # BIG*s = inf -> inf - inf = NaN -> clamps to 0 (padding sentinel: -1e30)
+        sigma = 1e-27
+    elif case == "tiny":
+        preds = preds * np.float32(1e-36)                 # differences below 2^-100: fractional counts
+        sigma = 1.0
+    elif case == "all_tied":
+        preds = np.zeros_like(preds)
+        sigma = 1.0
+    elif case == "some_tied":
+        preds = np.round(preds * 2) / 2                   # many equal scores
+        sigma = 1.0
+    else:
+        preds[:, ::3] *= np.float32(1e-34)                # a third of the list far below the resolution, the rest ordinary
+        sigma = 1.0
+    preds = preds.astype(np.float32)
+    loss, grad = loss_and_grad(F.lambdarank_loss, preds, dev(labels), sigma=sigma, lens=dev(ln))
+    lq, g = CO.lambdarank(preds, labels, sigma, lens=ln)
+    G.assert_close(loss, lq.astype(np.float64).sum(), f"lambdarank loss {case}")
+    G.assert_close(grad, g, f"lambdarank grad {case}")
+
+
 @pytest.mark.parametrize("B,L", [(5, 7), (16, 128), (9, 256), (4, 512), (2, 1030)])
 @pytest.mark.parametrize("use_lens", [False, True])
 def test_oracle_lambdaloss_approx(F, B, L, use_lens):
