@@ -126,6 +126,25 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
 
     int ntile_done = 0;
     (void)ntile_done;
+    // First X super-step of a tile, issued one tile AHEAD (while the previous tile runs its last hidden layer): the loads are then
+    // older than that tile's activation stores, so waiting for them does not wait for the stores' acknowledgements (vmcnt counts
+    // in order), and their HBM latency is off the tile's critical path.  Past the end: a valid address, never consumed.
+    auto prefetch_first = [&](int t, f32x4 (&xb)[RT]) {
+        const int tt = t < ntiles ? t : ntiles - 1;
+        const int k0 = 4 * g;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int r = tt * rows_per_tile + 16 * rt + j;
+            const float *xr = X + (size_t)(r < R ? r : R - 1) * F;
+            if constexpr (VEC) {
+                xb[rt] = *reinterpret_cast<const f32x4 *>(xr + (k0 < F ? k0 : 0));
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xb[rt][c] = xr[k0 + c < F ? k0 + c : 0];
+            }
+        }
+    };
+    f32x4 xpre[RT];
 #ifndef PTR_FWD_STATIC_TILES
     // dynamic tile queue per workgroup: the two waves of a SIMD do not progress at the same rate (the older one wins the issue
     // arbitration: 90 K vs 145 K cycles per tile measured) — with a static split the faster half idles at the end
@@ -134,10 +153,24 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
     int *queue = reinterpret_cast<int *>(Wo + kHP + 8);
     if (tid == 0) *queue = tile_lo + wpb;
     __syncthreads();
-    for (int tile = tile_lo + wave; tile < tile_hi; ++ntile_done) {
+    int tile = tile_lo + wave;
 #else
-    for (int tile = blockIdx.x * wpb + wave; tile < ntiles; tile += gridDim.x * wpb, ++ntile_done) {
+    const int tile_hi = ntiles;
+    int tile = blockIdx.x * wpb + wave;
 #endif
+    prefetch_first(tile, xpre);
+    for (; tile < tile_hi; ++ntile_done) {
+        int next_tile = tile_hi;
+        auto advance = [&]() {                      // pop the next tile and start its first X loads
+#ifndef PTR_FWD_STATIC_TILES
+            int nxt = 0;
+            if (lane == 0) nxt = atomicAdd(queue, 1);
+            next_tile = __builtin_amdgcn_readfirstlane(nxt);
+#else
+            next_tile = tile + gridDim.x * wpb;
+#endif
+            prefetch_first(next_tile, xpre);
+        };
         const int row0 = tile * rows_per_tile;
         int row[RT];
 #pragma unroll
@@ -191,7 +224,9 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
             for (int rt = 0; rt < RT; ++rt) acc[mt][rt] = b4;
         }
         f32x4 xcur[RT], xnxt[RT];
-        load_raw(0, xcur);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) xcur[rt] = xpre[rt];
+        if (NL == 1) advance();
         finish_x(0, xcur);
         // A operands (weight fragments): the 7 fragments of a super-step are read as one batch (see the hidden layers below)
         auto read_w1 = [&](int S, int mt) -> f32x4 {
@@ -207,12 +242,16 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
                 return *reinterpret_cast<const f32x4 *>(W1s + (size_t)(16 * mt + j) * ld1 + k0);
             }
         };
+        // X is prefetched TWO super-steps ahead: one super-step of MFMAs (~0.8 us) does not cover the HBM latency while the
+        // activation stores of the co-resident waves load the memory pipeline
+        f32x4 xnn[RT];
+        load_raw(nS1 > 1 ? 1 : 0, xnxt);
         for (int S = 0; S < nS1; ++S) {
-            if (S + 1 < nS1) load_raw(S + 1, xnxt);
+            load_raw(S + 2 < nS1 ? S + 2 : 0, xnn);           // past the end: a valid address, never consumed
             f32x4 wa[kMT];
 #pragma unroll
             for (int mt = 0; mt < kMT; ++mt) wa[mt] = read_w1(S, mt);
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (RT > 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mt = 0; mt < kMT; ++mt)
 #pragma unroll
@@ -220,9 +259,9 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt)
                         acc[mt][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mt][c], xcur[rt][c], acc[mt][rt], 0, 0, 0);
-            if (S + 1 < nS1) finish_x(S + 1, xnxt);
+            finish_x(S + 1, xnxt);                            // S + 1 == nS1: finishes garbage nobody reads
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) xcur[rt] = xnxt[rt];
+            for (int rt = 0; rt < RT; ++rt) { xcur[rt] = xnxt[rt]; xnxt[rt] = xnn[rt]; }
         }
 
         FWD_STAMP(1);
@@ -237,26 +276,15 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
 #pragma unroll
                     for (int c = 0; c < 4; ++c) h[c] = fmaxf(h[c], 0.0f);
                     if constexpr (TRAIN) {
-                        uint32_t w0, w1;
 #ifndef PTR_FWD_NOHASH
+                        uint32_t w0, w1;
                         drop_bits(a.seed_lo, a.seed_hi, l, row[rt], 4 * mt + g, w0, w1);
                         h = drop4(h, w0, w1, thr, scale);
-#else
-                        (void)w0; (void)w1;
 #endif
-                        if (row[rt] < R) {
-                            f32x4 hs = h;
-                            if (mt == kMT - 1) hs[0] = g == 1 ? 1.0f : hs[0];   // feature 100 (padding) = 1: the fused backward reads db_l
-                                                                               // off this ones column of its A image (scorer_bwd.hip)
-#if !defined(PTR_FWD_NOSTORE)
-                            *reinterpret_cast<f32x4 *>(acts + ((size_t)(l - 1) * R + row[rt]) * kAL + 16 * mt + 4 * g) = hs;
-#else
-                            if (hs[0] == 123.456f) acts[0] = 1.0f;
-#endif
-                        }
                     }
                     hin[mt][rt] = h;
                 }
+            if (l == NL - 1) advance();
             const float *Wl = Wh + (size_t)(l - 1) * kHP * kH;
 #pragma unroll
             for (int mt = 0; mt < kMT; ++mt) {
@@ -271,7 +299,28 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
                 f32x4 wa[kMT];
 #pragma unroll
                 for (int mt = 0; mt < kMT; ++mt) wa[mt] = *reinterpret_cast<const f32x4 *>(Wl + (size_t)(16 * mt + j) * kH + 16 * S + 4 * g);
-                __builtin_amdgcn_sched_barrier(0);          // keep the batch in front of the MFMAs (the scheduler would sink every read to its use)
+                if constexpr (RT > 1) __builtin_amdgcn_sched_barrier(0);   // keep the batch in front of the MFMAs (the scheduler would sink every
+                                                                           // read to its use); 16-row tiles: 128 VGPRs cannot hold a batch
+                if constexpr (TRAIN) {
+                    // the layer input is stored for the backward pass one feature tile per super-step, spread over the layer's MFMAs
+                    // (28 stores issued back to back at the layer transition stall the wave on the store path)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        if (row[rt] < R) {
+                            f32x4 hs = hin[S][rt];
+                            if (S == kMT - 1) hs[0] = g == 1 ? 1.0f : hs[0];      // feature 100 (padding) = 1: the fused backward reads db_l
+                                                                                  // off this ones column of its A image (scorer_bwd.hip)
+#if defined(PTR_FWD_L2STORE)     // experiment: same store instructions, L2-resident target
+                            *reinterpret_cast<f32x4 *>(acts + ((size_t)(l - 1) * R + (row[rt] & 4095)) * kAL + 16 * S + 4 * g) = hs;
+#elif !defined(PTR_FWD_NOSTORE)
+                            *reinterpret_cast<f32x4 *>(acts + ((size_t)(l - 1) * R + row[rt]) * kAL + 16 * S + 4 * g) = hs;
+#else
+                            if (hs[0] == 123.456f) acts[0] = 1.0f;
+#endif
+                        }
+                    }
+                    if constexpr (RT > 1) __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int mt = 0; mt < kMT; ++mt)
 #pragma unroll
@@ -297,7 +346,13 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
                 for (int c = 0; c < 4; ++c) { h[c] = fmaxf(h[c], 0.0f); sc[rt] = fmaf(h[c], w4[c], sc[rt]); }
                 if constexpr (TRAIN) {
                     if (row[rt] < R) {
+#if defined(PTR_FWD_L2STORE)
+                        *reinterpret_cast<f32x4 *>(acts + ((size_t)(NL - 1) * R + (row[rt] & 4095)) * kAL + 16 * mt + 4 * g) = h;
+#elif defined(PTR_FWD_NOSTORE)
+                        if (h[0] == 123.456f) acts[1] = 1.0f;
+#else
                         *reinterpret_cast<f32x4 *>(acts + ((size_t)(NL - 1) * R + row[rt]) * kAL + 16 * mt + 4 * g) = h;
+#endif
                     }
                 }
             }
@@ -310,11 +365,7 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
             if (g == 0 && row[rt] < R) preds[row[rt]] = s + b_out;
         }
         FWD_STAMP(3);
-#ifndef PTR_FWD_STATIC_TILES
-        int nxt = 0;
-        if (lane == 0) nxt = atomicAdd(queue, 1);
-        tile = __builtin_amdgcn_readfirstlane(nxt);
-#endif
+        tile = next_tile;
     }
 }
 
@@ -813,7 +864,7 @@ static int env_flag(const char *name, int dflt) {
     const char *e = getenv(name);
     return e ? (atoi(e) != 0) : dflt;
 }
-static int fwd_wide() { static int v = -1; if (v < 0) v = env_flag("PTR_FWD_WIDE", 0); return v; }
+static int fwd_wide() { static int v = -2; if (v == -2) v = env_flag("PTR_FWD_WIDE", -1); return v; }   // -1: by configuration
 static int dw_staged() { static int v = -1; if (v < 0) v = env_flag("PTR_DW_STAGED", 1); return v; }
 static int dw_rb() { static int v = -1; if (v < 0) { const char *e = getenv("PTR_DW_RB"); v = (e && atoi(e) == 32) ? 32 : 16; } return v; }   // 16 measured best (32: 1.09 vs 1.05 ms backward)
 static int dz_wide() { static int v = -1; if (v < 0) v = env_flag("PTR_DZ_WIDE", 0); return v; }
@@ -855,10 +906,14 @@ extern "C" int ptr_mlp_forward(const float *X, const float *params, int R, int F
     const bool w1g = fwd_needs_global_w1(F, NL);
     const size_t lds = fwd_lds_floats(F, NL, w1g) * sizeof(float);
     const bool vec = (F % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
-    const bool wide = fwd_wide() != 0;            // 16 waves x 16-row tiles (4 waves/SIMD) or 8 waves x 32-row tiles
+    // 16 waves x 16-row tiles (4 waves/SIMD) or 8 waves x 32-row tiles (half the weight-fragment LDS reads per MFMA).  Measured
+    // inside the train step (rocprofv3, F=136): the 16-row form is 7-9 % faster from 1024 to 4096 queries of 128 documents and
+    // 20-30 % faster below 256 (twice the waves on few tiles); in eval mode and with first-layer weights streamed from L2
+    // (F=700) the 32-row form wins.  PTR_FWD_WIDE=0/1 pins the choice.
+    const bool wide = fwd_wide() < 0 ? (train && !w1g) : fwd_wide() != 0;
     const int rows_per_tile = wide ? 16 : 32, wpb = wide ? 16 : 8;
     const int ntiles = (R + rows_per_tile - 1) / rows_per_tile;
-    const int grid = ntiles < wpb * mlp_num_cus() ? (ntiles + wpb - 1) / wpb : mlp_num_cus();
+    const int grid = ntiles < mlp_num_cus() ? ntiles : mlp_num_cus();      // few tiles: one per CU (the SIMD to itself) before two per CU
     auto launch = [&](auto kern) -> int {
         if (int e = allow_lds(kern, lds)) return e;
         hipLaunchKernelGGL(kern, dim3(grid > 0 ? grid : 1), dim3(wpb * 64), lds, as_stream(stream), X, params, a, preds, acts);
