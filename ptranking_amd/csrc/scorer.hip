@@ -92,7 +92,7 @@ __host__ __device__ inline size_t fwd_lds_floats(int F, int NL, bool w1_global) 
 __host__ __device__ inline bool fwd_needs_global_w1(int F, int NL) { return fwd_lds_floats(F, NL, false) * sizeof(float) > 160 * 1024; }
 
 #ifdef PTR_FWD_TRACE   // experiment builds: shader-clock stamps of workgroup 0's first tiles behind the predictions (preds is over-allocated)
-#define FWD_STAMP(i) do { if (blockIdx.x == 0 && lane == 0 && ntile_done < 8) reinterpret_cast<unsigned long long *>(preds + ((R + 3) & ~3) + 4)[(ntile_done * 16 + wave) * 8 + (i)] = clock64(); } while (0)
+#define FWD_STAMP(i) do { if (blockIdx.x == 0 && lane == 0 && ntile_done < 8) { unsigned long long *tr_ = reinterpret_cast<unsigned long long *>(preds + ((R + 3) & ~3) + 4) + (ntile_done * 16 + wave) * 8; tr_[(i)] = clock64(); if ((i) == 0) tr_[4] = wall_clock64(); if ((i) == 3) tr_[5] = wall_clock64(); } } while (0)   /* slots 4/5: 100 MHz real-time counter at tile start / end */
 #else
 #define FWD_STAMP(i) do { } while (0)
 #endif
@@ -183,7 +183,11 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             rok[rt] = row[rt] < R;
+#ifdef PTR_FWD_XL2      // experiment: the same loads from an L2-resident part of X
+            xrow[rt] = X + (size_t)((rok[rt] ? row[rt] : R - 1) & 4095) * F;
+#else
             xrow[rt] = X + (size_t)(rok[rt] ? row[rt] : R - 1) * F;
+#endif
         }
         // load_raw only issues the loads; finish_x (zero padding + input dropout) runs AFTER the MFMAs of the super-step the
         // loads are prefetched under — anything consuming the loaded value earlier would pull the s_waitcnt in front of them
@@ -223,11 +227,13 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) acc[mt][rt] = b4;
         }
-        f32x4 xcur[RT], xnxt[RT];
+        // X is prefetched TWO super-steps ahead through three register buffers that rotate by name (the loop is unrolled by three:
+        // a v_mov rotation would read the newest, still in-flight loads and put their full latency back on the critical path)
+        f32x4 xa[RT], xb[RT], xc[RT];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) xcur[rt] = xpre[rt];
+        for (int rt = 0; rt < RT; ++rt) xa[rt] = xpre[rt];
         if (NL == 1) advance();
-        finish_x(0, xcur);
+        finish_x(0, xa);
         // A operands (weight fragments): the 7 fragments of a super-step are read as one batch (see the hidden layers below)
         auto read_w1 = [&](int S, int mt) -> f32x4 {
             const int k0 = 16 * S + 4 * g;
@@ -242,12 +248,9 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
                 return *reinterpret_cast<const f32x4 *>(W1s + (size_t)(16 * mt + j) * ld1 + k0);
             }
         };
-        // X is prefetched TWO super-steps ahead: one super-step of MFMAs (~0.8 us) does not cover the HBM latency while the
-        // activation stores of the co-resident waves load the memory pipeline
-        f32x4 xnn[RT];
-        load_raw(nS1 > 1 ? 1 : 0, xnxt);
-        for (int S = 0; S < nS1; ++S) {
-            load_raw(S + 2 < nS1 ? S + 2 : 0, xnn);           // past the end: a valid address, never consumed
+        auto l1_step = [&](int S, f32x4 (&cur)[RT], f32x4 (&nxt)[RT], f32x4 (&nn)[RT]) {
+            load_raw(S + 2 < nS1 ? S + 2 : 0, nn);            // past the end: a valid address, never consumed
+            __builtin_amdgcn_sched_barrier(0);                // the loads stay HERE (the scheduler sinks them towards their use)
             f32x4 wa[kMT];
 #pragma unroll
             for (int mt = 0; mt < kMT; ++mt) wa[mt] = read_w1(S, mt);
@@ -258,10 +261,19 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt)
-                        acc[mt][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mt][c], xcur[rt][c], acc[mt][rt], 0, 0, 0);
-            finish_x(S + 1, xnxt);                            // S + 1 == nS1: finishes garbage nobody reads
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) { xcur[rt] = xnxt[rt]; xnxt[rt] = xnn[rt]; }
+                        acc[mt][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mt][c], cur[rt][c], acc[mt][rt], 0, 0, 0);
+            finish_x(S + 1, nxt);                             // S + 1 == nS1: finishes values nobody reads
+        };
+        load_raw(nS1 > 1 ? 1 : 0, xb);
+        int S1 = 0;
+        for (; S1 + 3 <= nS1; S1 += 3) {                      // branch-free body: the compiler counts the loads in flight exactly
+            l1_step(S1, xa, xb, xc);
+            l1_step(S1 + 1, xb, xc, xa);
+            l1_step(S1 + 2, xc, xa, xb);
+        }
+        if (S1 < nS1) {                                       // nS1 % 3 leftover super-steps
+            l1_step(S1, xa, xb, xc);
+            if (S1 + 1 < nS1) l1_step(S1 + 1, xb, xc, xa);
         }
 
         FWD_STAMP(1);

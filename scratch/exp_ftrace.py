@@ -21,4 +21,5 @@ for train in (1, 0):
         d = np.diff(tr[t, :8, :4], axis=1)
         tot = tr[t, :8, 3] - tr[t, :8, 0]
         gap = tr[t, :8, 0] - tr[t - 1, :8, 3]
-        print(f"  tile {t}: layer1 {d[:,0].mean():7.0f}  hidden {d[:,1].mean():7.0f}  epilogue {d[:,2].mean():6.0f}  total {tot.mean():7.0f}  gap-to-prev {gap.mean():6.0f}   per-wave totals {tot}")
+        mhz = (tr[t, :8, 3] - tr[t, :8, 0]) / np.maximum(tr[t, :8, 5] - tr[t, :8, 4], 1) * 100.0
+        print(f"  tile {t}: shader clock {mhz.mean():6.0f} MHz  layer1 {d[:,0].mean():7.0f}  hidden {d[:,1].mean():7.0f}  epilogue {d[:,2].mean():6.0f}  total {tot.mean():7.0f}  gap-to-prev {gap.mean():6.0f}   per-wave totals {tot}")
