@@ -45,10 +45,13 @@ MSLR_P = [0.5147, 0.3250, 0.1339, 0.0183, 0.0081]   # label histogram of MSLR-WE
 SEED = 137                        # ptranking/ltr_global.py:7
 NUM_SIMD = 256 * 4                # 256 CUs x 4 SIMDs
 PEAK_CLOCK_HZ = 2.4e9
-# pair-loop instructions per pair evaluation of lambdarank_ring_kernel<DPT> read off the gfx950 ISA; a wave64 VALU
-# instruction (packed or not) occupies its SIMD for 4 cycles (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU in profiles/r02_sq_c2.txt)
-RING_INSTR_PER_PAIR = {1: 28.0, 2: 19.2, 4: 19.8}
+# pair-loop VALU instructions per pair evaluation of lambdarank_ring_kernel<DPT> read off the gfx950 ISA, 3 of them
+# transcendental (v_exp/v_rcp/v_log).  A wave64 VALU instruction (packed or not) occupies its SIMD for 4 cycles, a transcendental
+# for 8: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4.6 cycles for the kernel's mix (profiles/r02_sq_c2.txt)
+RING_INSTR_PER_PAIR = {1: 25.0, 2: 16.75, 4: 15.5625}
+RING_TRANS_PER_PAIR = 3.0
 VALU_CYCLES_PER_INSTR = 4.0
+TRANS_CYCLES_PER_INSTR = 8.0
 
 
 def synth_batch(gen, B, L, F, device):
@@ -303,14 +306,17 @@ def main():
             pairs = B * (Lk * (Lk - 1) // 2)
             gbps = bytes_ / (t_ms * 1e-3) / 1e9
             dpt = 1 if Lk <= 64 else 2 if Lk <= 128 else 4
-            bound = NUM_SIMD * PEAK_CLOCK_HZ * 64.0 / (RING_INSTR_PER_PAIR[dpt] * VALU_CYCLES_PER_INSTR)
+            cyc = (RING_INSTR_PER_PAIR[dpt] - RING_TRANS_PER_PAIR) * VALU_CYCLES_PER_INSTR + RING_TRANS_PER_PAIR * TRANS_CYCLES_PER_INSTR
+            bound = NUM_SIMD * PEAK_CLOCK_HZ * 64.0 / cyc
             return {"kernel": f"lambdarank_ring_kernel<{dpt}> (fused LambdaRank dNDCG loss + gradient, one wavefront per query, register/DPP ring)",
                     "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
                     "traffic": traffic, "avg_launch_ms": t_ms, "algorithmic_bytes_per_launch": bytes_, "pairs_per_s": pairs / (t_ms * 1e-3),
                     "valu_roofline": {"bound": "valu-issue", "achieved": pairs / (t_ms * 1e-3), "unit": "pairs/s", "peak": bound,
                                       "frac": pairs / (t_ms * 1e-3) / bound, "instr_per_pair": RING_INSTR_PER_PAIR[dpt],
-                                      "cycles_per_wave64_valu_instr": VALU_CYCLES_PER_INSTR,
-                                      "note": "peak = 1024 SIMDs x 2.4 GHz x 64 lanes / (pair-loop instructions per pair x 4 cycles); "
+                                      "cycles_per_wave64_valu_instr": VALU_CYCLES_PER_INSTR, "transcendentals_per_pair": RING_TRANS_PER_PAIR,
+                                      "cycles_per_transcendental": TRANS_CYCLES_PER_INSTR, "issue_cycles_per_pair": cyc,
+                                      "note": "peak = 1024 SIMDs x 2.4 GHz x 64 lanes / pair-loop issue cycles per pair (4 per VALU "
+                                              "instruction, 8 per transcendental); the shader clock sustained under this kernel is ~2.1 GHz; "
                                               "avg_launch_ms is a HIP-event bracket and includes ~10 us of launch overhead the rocprofv3 "
                                               "kernel time (profiles/r02_*kernel_stats.csv) does not; SQ counters: profiles/r02_sq_c2.txt"},
                     "note": "O(L^2) pair work per 12L+4 bytes: VALU-bound by construction (DESIGN.md 3.1)"}
@@ -328,7 +334,7 @@ def main():
             kernels["lambdarank_loss_grad_L256"] = loss_kernel_entry(256, l256, None)
         if t_fwd:
             tf = fwd_flop / (t_fwd * 1e-3) / 1e12
-            kernels["scorer_forward"] = {"kernel": "mlp_fwd_kernel<2,TRAIN,VEC> (fused pointsf scorer forward, fp32 MFMA 16x16x4, dropout in-kernel)",
+            kernels["scorer_forward"] = {"kernel": "mlp_fwd_kernel<RT,TRAIN,VEC> (fused pointsf scorer forward, fp32 MFMA 16x16x4, dropout in-kernel; training: 16 waves x 16-row tiles)",
                                          "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                          "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_bytes("ptr::mlp_fwd_kernel"), "avg_launch_ms": t_fwd,
                                          "algorithmic_flop_per_launch": fwd_flop, "algorithmic_bytes_per_launch": R * (4 * F + 4),

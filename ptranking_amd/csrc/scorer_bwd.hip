@@ -170,7 +170,11 @@ __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 #define BWD_STAMP(i)                                                                                                    \
     do {                                                                                                                \
         if (blockIdx.x == 0 && lane == 0 && nslab_done < 8)                                                             \
-            reinterpret_cast<unsigned long long *>(ws + (size_t)gridDim.x * np_stride)[(nslab_done * kBW + W) * 16 + (i)] = clock64(); \
+        {                                                                                                               \
+            unsigned long long *tr_ = reinterpret_cast<unsigned long long *>(ws + (size_t)gridDim.x * np_stride) + (nslab_done * kBW + W) * 16; \
+            tr_[(i)] = clock64();                                                                                       \
+            if ((i) == 0) tr_[15] = wall_clock64();          /* 100 MHz real-time counter at slab start */              \
+        }                                                                                                               \
     } while (0)
 #else
 #define BWD_STAMP(i) do { } while (0)

@@ -24,3 +24,6 @@ for s_ in range(2, 5):
     d = np.diff(tr[s_, :, :9], axis=1)
     for w in range(8):
         print("   w%d " % w + " ".join(f"{names[i]}={d[w, i]:5d}" for i in range(8)) + f"  total={tr[s_, w, 8] - tr[s_, w, 0]}")
+# sustained shader clock: shader-clock stamps against the 100 MHz real-time counter (slot 15) between the starts of slabs 1 and 7
+mhz = (tr[7, :, 0] - tr[1, :, 0]) / np.maximum(tr[7, :, 15] - tr[1, :, 15], 1) * 100.0
+print("shader clock inside mlp_bwd_fused_kernel: %.0f MHz (per wave %s)" % (mhz.mean(), np.round(mhz).astype(int)))
