@@ -262,22 +262,33 @@ def main():
             by_batch[str(bq)] = {"queries_per_s_per_gpu": bq * args.sweep_steps / el, "ms_per_step": 1e3 * el / args.sweep_steps,
                                  "steps": args.sweep_steps, "is_value": False}
 
-    # the north-star kernel at its stated list length (BASELINE.json: list_len=256), same number of queries, loss kernel alone
-    l256 = None
-    if rank == 0 and headline:
+    # the loss kernel alone, at the headline list length and at the north-star's stated one (BASELINE.json: list_len=256), same
+    # number of queries: 40 launches of the C entry back to back (no loss_out: the kernel only, no slot sum) inside ONE HIP-event
+    # pair on the launch stream — the per-call event bracket of the timed step also holds the slot-sum kernel and two event gaps
+    ring_alone = {}
+    if rank == 0 and args.loss == "LambdaRank" and args.scorer == "pointsf":
+        import ctypes as C
         gen = torch.Generator(device=device).manual_seed(SEED + 7)
-        p256 = torch.randn((B, 256), generator=gen, device=device)
-        _, Y256 = synth_batch(gen, B, 256, 1, device)
-        for _ in range(5):
-            pa.functional.lambdarank_loss(p256, Y256, sigma=1.0)
-        torch.cuda.synchronize()
-        _lib.TIMING = {}
-        for _ in range(30):
-            pa.functional.lambdarank_loss(p256, Y256, sigma=1.0)
-        torch.cuda.synchronize()
-        ev = _lib.TIMING["ptr_lambdarank_fwd_bwd"]
-        _lib.TIMING = None
-        l256 = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        for Lk in sorted({L, 256}):
+            if Lk > 256:
+                continue
+            pk = torch.randn((B, Lk), generator=gen, device=device)
+            _, Yk = synth_batch(gen, B, Lk, 1, device)
+            lq = torch.empty(B, device=device); gk = torch.empty_like(pk)
+            st = _lib.current_stream(device)
+            def go():
+                _lib.call("ptr_lambdarank_fwd_bwd", _lib.ptr(pk), _lib.ptr(Yk), None, B, Lk, C.c_float(1.0), None, _lib.ptr(lq), _lib.ptr(gk), st)
+            for _ in range(5):
+                go()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(40):
+                go()
+            e1.record()
+            torch.cuda.synchronize()
+            ring_alone[Lk] = e0.elapsed_time(e1) / 40
+    l256 = ring_alone.get(256)
 
     if rank == 0:
         def avg_ms(name):
@@ -317,14 +328,15 @@ def main():
                                       "cycles_per_transcendental": TRANS_CYCLES_PER_INSTR, "issue_cycles_per_pair": cyc,
                                       "note": "peak = 1024 SIMDs x 2.4 GHz x 64 lanes / pair-loop issue cycles per pair (4 per VALU "
                                               "instruction, 8 per transcendental); the shader clock sustained under this kernel is ~2.1 GHz; "
-                                              "avg_launch_ms is a HIP-event bracket and includes ~10 us of launch overhead the rocprofv3 "
-                                              "kernel time (profiles/r02_*kernel_stats.csv) does not; SQ counters: profiles/r02_sq_c2.txt"},
+                                              "avg_launch_ms = 40 back-to-back launches of the kernel inside one HIP-event pair / 40 (rocprofv3 kernel "
+                                              "time: profiles/r02_*kernel_stats.csv); SQ counters: profiles/r02_sq_c2.txt"},
                     "note": "O(L^2) pair work per 12L+4 bytes: VALU-bound by construction (DESIGN.md 3.1)"}
 
         kernels = {}
         if t_loss:
             if args.loss == "LambdaRank" and L <= 256:
-                kernels["lambdarank_loss_grad"] = loss_kernel_entry(L, t_loss, pmc_bytes("ptr::lambdarank_ring_kernel"))
+                kernels["lambdarank_loss_grad"] = loss_kernel_entry(L, ring_alone.get(L, t_loss), pmc_bytes("ptr::lambdarank_ring_kernel"))
+                kernels["lambdarank_loss_grad"]["entry_ms_in_step"] = t_loss      # C entry inside the timed step: ring kernel + slot sum
             else:
                 gbps = B * (12 * L + 4) / (t_loss * 1e-3) / 1e9
                 kernels["loss_grad"] = {"kernel": f"{loss_entry} (fused {args.loss} loss + gradient)", "bound": "hbm", "achieved": gbps,
