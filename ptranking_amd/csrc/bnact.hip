@@ -57,127 +57,271 @@ __device__ __forceinline__ float drop_factor(const BnActArgs &a, int row, int co
     return drop_keep1(a.seed_lo, a.seed_hi, a.site, row, col, thr) ? inv_keep : 0.0f;
 }
 
-// Column sums of two per-element quantities over a chunk of rows -> partial[chunk][2][N].
-//   MODE 0: (z, -)                            forward statistics, pass 1 (mean)
-//   MODE 2: ((z - mean)^2, -)                 forward statistics, pass 2 (two-pass variance: no E[z^2] - mean^2 cancellation)
-//   MODE 1: (dy, dy * xhat)                   backward statistics, dy = da * dropout * AF'(y), y = gamma * xhat + beta
-template <int MODE>
+// keep / (1 - p) factors of columns [4*cg, 4*cg+3] of `row` (one hash for the four)
+__device__ __forceinline__ f32x4 drop_factor4(const BnActArgs &a, int row, int cg, uint32_t thr, float inv_keep) {
+    if (a.p_drop <= 0.0f) return f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+    uint32_t w0, w1;
+    drop_bits(a.seed_lo, a.seed_hi, a.site, row, cg, w0, w1);
+    return f32x4{(w0 & 0xFFFFu) >= thr ? inv_keep : 0.0f, (w0 >> 16) >= thr ? inv_keep : 0.0f, (w1 & 0xFFFFu) >= thr ? inv_keep : 0.0f,
+                 (w1 >> 16) >= thr ? inv_keep : 0.0f};
+}
+
+// Column statistics of a chunk of rows -> partial[chunk][2][N], ONE pass over the data, W = 4 (float4 per thread) or 1 columns per thread.
+//   MODE 0: (mean_b, M2_b = sum (z - mean_b)^2) of the chunk's rows: sums of d = z - k and d^2 around the pivot k = the chunk's first
+//           row (the column's own scale: E[d^2] - E[d]^2 then cancels at most a few bits, unlike E[z^2] - mean^2), combined over the
+//           chunks by the parallel-variance formula in the finishing kernel
+//   MODE 1: (sum dy, sum dy * xhat), dy = da * dropout * AF'(y), y = gamma * xhat + beta        (batch-norm backward)
+// Threads: column group c_in (W columns) x row lane rl; a row lane walks the chunk's rows rl, rl + rsub, ... four rows in flight.
+template <int MODE, int W>
 __global__ void __launch_bounds__(256)
 colsum2_kernel(const float *__restrict__ z, const float *__restrict__ da, const float *__restrict__ mean, const float *__restrict__ rstd,
                const float *__restrict__ gamma, const float *__restrict__ beta, BnActArgs a, float *__restrict__ partial) {
-    __shared__ float red[2][256];
-    const int N = a.N, R = a.R;
+    using vec = float __attribute__((ext_vector_type(W)));
+    __shared__ float red[2 * W][256];
+    const int N = a.N, R = a.R, NG = N / W;                  // W == 4 only when N % 4 == 0
     const int tid = threadIdx.x;
-    const int cols_per_pass = N < 256 ? N : 256;
-    const int rsub = 256 / cols_per_pass;                    // row lanes per pass
-    const int c_in = tid % cols_per_pass, rl = tid / cols_per_pass;
+    const int groups_per_pass = NG < 256 ? NG : 256;
+    const int rsub = 256 / groups_per_pass;                  // row lanes per pass
+    const int c_in = tid % groups_per_pass, rl = tid / groups_per_pass;
     const int chunk = a.group > 0 ? a.group : (R + gridDim.x - 1) / gridDim.x;     // grouped: one workgroup per group (query)
     const int r_begin = blockIdx.x * chunk, r_end = min(R, r_begin + chunk);
     const size_t so = a.group > 0 ? (size_t)blockIdx.x * N : 0;                  // offset of this group's statistics
     const uint32_t thr = drop_thr(a.p_drop);
     const float inv_keep = a.p_drop > 0.0f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
-    for (int c0 = 0; c0 < N; c0 += cols_per_pass) {
-        const int c = c0 + c_in;
-        float s1 = 0.0f, s2 = 0.0f;
-        if (c < N && rl < rsub) {
-            float mu = 0.f, rs = 1.f, ga = 1.f, be = 0.f;
-            if (MODE == 1 && a.has_bn) { mu = mean[so + c]; rs = rstd[so + c]; ga = gamma ? gamma[c] : 1.0f; be = beta ? beta[c] : 0.0f; }
-            if (MODE == 2) mu = mean[so + c];
-            for (int r = r_begin + rl; r < r_end; r += rsub) {
-                const float zv = z[(size_t)r * a.ld + c];
-                if (MODE == 0) {
-                    s1 += zv;
-                } else if (MODE == 2) {
-                    const float d = zv - mu;
-                    s1 = fmaf(d, d, s1);
+    auto ldv = [&](const float *ptr_) -> vec {
+        if constexpr (W == 4) return *reinterpret_cast<const vec *>(ptr_);
+        else return vec{*ptr_};
+    };
+    for (int g0 = 0; g0 < NG; g0 += groups_per_pass) {
+        const int cg = g0 + c_in, c = cg * W;
+        const bool on = cg < NG && rl < rsub && r_begin < r_end;
+        vec s1, s2, kv, mu, rs, ga, be;
+        for (int e = 0; e < W; ++e) { s1[e] = 0.f; s2[e] = 0.f; kv[e] = 0.f; mu[e] = 0.f; rs[e] = 1.f; ga[e] = 1.f; be[e] = 0.f; }
+        if (on) {
+            if constexpr (MODE == 0) kv = ldv(z + (size_t)r_begin * a.ld + c);
+            if (MODE == 1 && a.has_bn) {
+                mu = ldv(mean + so + c); rs = ldv(rstd + so + c);
+                if (gamma) ga = ldv(gamma + c);
+                if (beta) be = ldv(beta + c);
+            }
+            auto acc = [&](int r, vec zv, vec dv) {
+                if constexpr (MODE == 0) {
+                    const vec d = zv - kv;
+                    s1 += d;
+                    for (int e = 0; e < W; ++e) s2[e] = fmaf(d[e], d[e], s2[e]);
                 } else {
-                    const float xh = a.has_bn ? (zv - mu) * rs : zv;
-                    const float y = a.has_bn ? fmaf(ga, xh, be) : zv;
-                    const float dy = da[(size_t)r * a.ld + c] * drop_factor(a, r, c, thr, inv_keep) * af_bwd(a.af, y);
-                    s1 += dy;
-                    s2 = fmaf(dy, xh, s2);
+                    vec keep;
+                    if constexpr (W == 4) keep = drop_factor4(a, r, cg, thr, inv_keep);
+                    else keep[0] = drop_factor(a, r, c, thr, inv_keep);
+                    for (int e = 0; e < W; ++e) {
+                        const float xh = a.has_bn ? (zv[e] - mu[e]) * rs[e] : zv[e];
+                        const float y = a.has_bn ? fmaf(ga[e], xh, be[e]) : zv[e];
+                        const float dy = dv[e] * keep[e] * af_bwd(a.af, y);
+                        s1[e] += dy;
+                        s2[e] = fmaf(dy, xh, s2[e]);
+                    }
                 }
+            };
+            int r = r_begin + rl;
+            for (; r + 3 * rsub < r_end; r += 4 * rsub) {          // four independent rows in flight
+                vec zv[4], dv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    zv[u] = ldv(z + (size_t)(r + u * rsub) * a.ld + c);
+                    if constexpr (MODE == 1) dv[u] = ldv(da + (size_t)(r + u * rsub) * a.ld + c); else dv[u] = zv[u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc(r + u * rsub, zv[u], dv[u]);
+            }
+            for (; r < r_end; r += rsub) {
+                const vec zv = ldv(z + (size_t)r * a.ld + c);
+                vec dv = zv;
+                if constexpr (MODE == 1) dv = ldv(da + (size_t)r * a.ld + c);
+                acc(r, zv, dv);
             }
         }
-        red[0][tid] = s1;
-        red[1][tid] = s2;
+        for (int e = 0; e < W; ++e) { red[e][tid] = s1[e]; red[W + e][tid] = s2[e]; }
         __syncthreads();
-        if (rl == 0 && c < N) {                               // fixed-order sum over the row lanes
-            float t1 = 0.0f, t2 = 0.0f;
-            for (int k = 0; k < rsub; ++k) { t1 += red[0][k * cols_per_pass + c_in]; t2 += red[1][k * cols_per_pass + c_in]; }
-            partial[((size_t)blockIdx.x * 2 + 0) * N + c] = t1;
-            partial[((size_t)blockIdx.x * 2 + 1) * N + c] = t2;
+        if (rl == 0 && cg < NG) {                                 // fixed-order sum over the row lanes
+            vec t1, t2;
+            for (int e = 0; e < W; ++e) { t1[e] = 0.f; t2[e] = 0.f; }
+            for (int k = 0; k < rsub; ++k)
+                for (int e = 0; e < W; ++e) { t1[e] += red[e][k * groups_per_pass + c_in]; t2[e] += red[W + e][k * groups_per_pass + c_in]; }
+            if constexpr (MODE == 0) {
+                const float nrows = (float)max(r_end - r_begin, 1);
+                for (int e = 0; e < W; ++e) {
+                    const float m1 = t1[e] / nrows;
+                    t2[e] = fmaxf(t2[e] - t1[e] * m1, 0.0f);      // M2 around the chunk mean
+                    t1[e] = kv[e] + m1;                           // chunk mean
+                }
+            }
+            for (int e = 0; e < W; ++e) {
+                partial[((size_t)blockIdx.x * 2 + 0) * N + c + e] = t1[e];
+                partial[((size_t)blockIdx.x * 2 + 1) * N + c + e] = t2[e];
+            }
         }
         __syncthreads();
     }
 }
 
-// out1 / out2 = fixed-order sums of the partials; FINISH 1: out1 = sum / R (mean); FINISH 2: out1 = 1 / sqrt(sum / R + eps) (rstd)
+// Fixed-order combination of the chunk partials by 8 columns x 32 partial lanes per workgroup (lane bl sums the partials bl, bl + 32, ...
+// four at a time, the 32 lane sums are added in lane order).
+//   FINISH 0: out1 = sum partial[.][0], out2 = sum partial[.][1]
+//   FINISH 1: partials are (chunk mean, chunk M2) over `chunk` rows each (the last one shorter): out1 = mean, out2 = 1 / sqrt(var + eps),
+//             var = (sum M2_b + n_b (mean_b - mean)^2) / R   (biased, as BatchNorm normalises)
 template <int FINISH>
 __global__ void __launch_bounds__(256)
-colsum2_reduce_kernel(const float *__restrict__ partial, int nblk, int N, int R, float eps, float *__restrict__ out1, float *__restrict__ out2) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= N) return;
+colsum2_reduce_kernel(const float *__restrict__ partial, int nblk, int N, int R, int chunk, float eps, float *__restrict__ out1,
+                      float *__restrict__ out2) {
+    constexpr int CL = 8, BL = 32;
+    __shared__ float red[2][BL][CL + 1];
+    const int cl = threadIdx.x & (CL - 1), bl = threadIdx.x / CL;
+    const int c = blockIdx.x * CL + cl;
+    const bool on = c < N;
+    auto rows_of = [&](int b) { return (float)(min(R, (b + 1) * chunk) - b * chunk); };
+    auto p0 = [&](int b) { return b < nblk ? partial[((size_t)b * 2 + 0) * N + c] : 0.0f; };
+    auto p1 = [&](int b) { return b < nblk ? partial[((size_t)b * 2 + 1) * N + c] : 0.0f; };
     float s1 = 0.0f, s2 = 0.0f;
-    for (int b = 0; b < nblk; ++b) { s1 += partial[((size_t)b * 2 + 0) * N + c]; s2 += partial[((size_t)b * 2 + 1) * N + c]; }
-    if (FINISH == 1) {
-        out1[c] = s1 / (float)R;
-    } else if (FINISH == 2) {
-        out1[c] = 1.0f / sqrtf(s1 / (float)R + eps);
-    } else {
-        out1[c] = s1;
-        out2[c] = s2;
+    if (on)
+        for (int b = bl; b < nblk; b += 4 * BL) {
+            const float a0 = p0(b), a1 = p0(b + BL), a2 = p0(b + 2 * BL), a3 = p0(b + 3 * BL);
+            if (FINISH == 0) {
+                const float b0 = p1(b), b1 = p1(b + BL), b2 = p1(b + 2 * BL), b3 = p1(b + 3 * BL);
+                s1 += (a0 + a1) + (a2 + a3);
+                s2 += (b0 + b1) + (b2 + b3);
+            } else {
+                s1 += (rows_of(b) * a0 + (b + BL < nblk ? rows_of(b + BL) * a1 : 0.0f)) +
+                      ((b + 2 * BL < nblk ? rows_of(b + 2 * BL) * a2 : 0.0f) + (b + 3 * BL < nblk ? rows_of(b + 3 * BL) * a3 : 0.0f));
+            }
+        }
+    red[0][bl][cl] = s1; red[1][bl][cl] = s2;
+    __syncthreads();
+    float t1 = 0.0f, t2 = 0.0f;
+    for (int k = 0; k < BL; ++k) { t1 += red[0][k][cl]; t2 += red[1][k][cl]; }      // every lane: the same fixed order
+    if (FINISH == 0) {
+        if (on && bl == 0) { out1[c] = t1; out2[c] = t2; }
+        return;
+    }
+    const float mean_tot = t1 / (float)R;
+    float m2 = 0.0f;
+    if (on)
+        for (int b = bl; b < nblk; b += 4 * BL) {
+            float part[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int bb = b + u * BL;
+                const float mb = p0(bb), qb = p1(bb);
+                const float d = mb - mean_tot;
+                part[u] = bb < nblk ? qb + rows_of(bb) * d * d : 0.0f;
+            }
+            m2 += (part[0] + part[1]) + (part[2] + part[3]);
+        }
+    __syncthreads();
+    red[0][bl][cl] = m2;
+    __syncthreads();
+    if (on && bl == 0) {
+        float v = 0.0f;
+        for (int k = 0; k < BL; ++k) v += red[0][k][cl];
+        out1[c] = mean_tot;
+        out2[c] = 1.0f / sqrtf(v / (float)R + eps);
     }
 }
 
-// grouped statistics: the per-group partial IS the group's sum.  FINISH 1: mean = sum / L; FINISH 2: rstd = 1 / sqrt(sum / L + eps)
-template <int FINISH>
+// grouped statistics: the per-group partial IS the group's (mean, M2): mean = partial[g][0], rstd = 1 / sqrt(M2 / L + eps)
 __global__ void __launch_bounds__(256)
-group_finish_kernel(const float *__restrict__ partial, size_t G, int N, int L, float eps, float *__restrict__ out) {
+group_finish_kernel(const float *__restrict__ partial, size_t G, int N, int L, float eps, float *__restrict__ mean, float *__restrict__ rstd) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= G * N) return;
     const size_t gidx = i / N;
     const int c = (int)(i - gidx * N);
-    const float sv = partial[(gidx * 2 + 0) * N + c];
-    out[i] = FINISH == 1 ? sv / (float)L : 1.0f / sqrtf(sv / (float)L + eps);
+    mean[i] = partial[(gidx * 2 + 0) * N + c];
+    rstd[i] = 1.0f / sqrtf(partial[(gidx * 2 + 1) * N + c] / (float)L + eps);
 }
 
-// a_out = dropout(AF(BN(z)))
+// a_out = dropout(AF(BN(z))), W columns per thread
+template <int W>
 __global__ void __launch_bounds__(256)
 bnact_fwd_kernel(const float *__restrict__ z, const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ gamma,
                  const float *__restrict__ beta, BnActArgs a, float *__restrict__ out) {
+    using vec = float __attribute__((ext_vector_type(W)));
+    const int NG = a.N / W;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)a.R * a.N) return;
-    const int r = (int)(i / a.N), c = (int)(i - (size_t)r * a.N);
-    float y = z[(size_t)r * a.ld + c];
+    if (i >= (size_t)a.R * NG) return;
+    const int r = (int)(i / NG), cg = (int)(i - (size_t)r * NG), c = cg * W;
+    auto ldv = [&](const float *ptr_) -> vec {
+        if constexpr (W == 4) return *reinterpret_cast<const vec *>(ptr_);
+        else return vec{*ptr_};
+    };
+    vec y = ldv(z + (size_t)r * a.ld + c);
     const size_t so = a.group > 0 ? (size_t)(r / a.group) * a.N : 0;
-    if (a.has_bn) y = fmaf(gamma ? gamma[c] : 1.0f, (y - mean[so + c]) * rstd[so + c], beta ? beta[c] : 0.0f);
-    const float h = af_fwd(a.af, y);
-    out[(size_t)r * a.ld + c] = h * drop_factor(a, r, c, drop_thr(a.p_drop), a.p_drop > 0.0f ? 1.0f / (1.0f - a.p_drop) : 1.0f);
+    if (a.has_bn) {
+        const vec mu = ldv(mean + so + c), rs = ldv(rstd + so + c);
+        vec ga, be;
+        for (int e = 0; e < W; ++e) { ga[e] = 1.0f; be[e] = 0.0f; }
+        if (gamma) ga = ldv(gamma + c);
+        if (beta) be = ldv(beta + c);
+        for (int e = 0; e < W; ++e) y[e] = fmaf(ga[e], (y[e] - mu[e]) * rs[e], be[e]);
+    }
+    const uint32_t thr = drop_thr(a.p_drop);
+    const float inv_keep = a.p_drop > 0.0f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+    vec keep;
+    if constexpr (W == 4) keep = drop_factor4(a, r, cg, thr, inv_keep);
+    else keep[0] = drop_factor(a, r, c, thr, inv_keep);
+    vec o;
+    for (int e = 0; e < W; ++e) o[e] = af_fwd(a.af, y[e]) * keep[e];
+    if constexpr (W == 4) *reinterpret_cast<vec *>(out + (size_t)r * a.ld + c) = o;
+    else out[(size_t)r * a.ld + c] = o[0];
 }
 
-// dz = gamma * rstd * (dy - sum_dy / R - xhat * sum_dyx / R)        (no BN: dz = dy)
+// dz = gamma * rstd * (dy - sum_dy / R - xhat * sum_dyx / R)        (no BN: dz = dy), W columns per thread
+template <int W>
 __global__ void __launch_bounds__(256)
 bnact_bwd_kernel(const float *__restrict__ z, const float *__restrict__ da, const float *__restrict__ mean, const float *__restrict__ rstd,
                  const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ sum_dy,
                  const float *__restrict__ sum_dyx, BnActArgs a, float *__restrict__ dz) {
+    using vec = float __attribute__((ext_vector_type(W)));
+    const int NG = a.N / W;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)a.R * a.N) return;
-    const int r = (int)(i / a.N), c = (int)(i - (size_t)r * a.N);
-    const float zv = z[(size_t)r * a.ld + c];
-    const float thr_keep = drop_factor(a, r, c, drop_thr(a.p_drop), a.p_drop > 0.0f ? 1.0f / (1.0f - a.p_drop) : 1.0f);
+    if (i >= (size_t)a.R * NG) return;
+    const int r = (int)(i / NG), cg = (int)(i - (size_t)r * NG), c = cg * W;
+    auto ldv = [&](const float *ptr_) -> vec {
+        if constexpr (W == 4) return *reinterpret_cast<const vec *>(ptr_);
+        else return vec{*ptr_};
+    };
+    const vec zv = ldv(z + (size_t)r * a.ld + c), dv = ldv(da + (size_t)r * a.ld + c);
+    const uint32_t thr = drop_thr(a.p_drop);
+    const float inv_keep = a.p_drop > 0.0f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+    vec keep;
+    if constexpr (W == 4) keep = drop_factor4(a, r, cg, thr, inv_keep);
+    else keep[0] = drop_factor(a, r, c, thr, inv_keep);
+    vec o;
     if (a.has_bn) {
         // grouped: sum_dy / sum_dyx are the per-group partials [G][2][N] of colsum2_kernel<1> (sum_dyx = sum_dy + N), mean over L rows
         const size_t so = a.group > 0 ? (size_t)(r / a.group) * a.N : 0, ss = a.group > 0 ? 2 * so : 0;
-        const float ga = gamma ? gamma[c] : 1.0f, rs = rstd[so + c];
-        const float xh = (zv - mean[so + c]) * rs;
-        const float y = fmaf(ga, xh, beta ? beta[c] : 0.0f);
-        const float dy = da[(size_t)r * a.ld + c] * thr_keep * af_bwd(a.af, y);
+        const vec mu = ldv(mean + so + c), rs = ldv(rstd + so + c), sdy = ldv(sum_dy + ss + c), sdyx = ldv(sum_dyx + ss + c);
+        vec ga, be;
+        for (int e = 0; e < W; ++e) { ga[e] = 1.0f; be[e] = 0.0f; }
+        if (gamma) ga = ldv(gamma + c);
+        if (beta) be = ldv(beta + c);
         const float invR = 1.0f / (float)(a.group > 0 ? a.group : a.R);
-        dz[(size_t)r * a.ld + c] = (ga * rs) * (dy - sum_dy[ss + c] * invR - xh * (sum_dyx[ss + c] * invR));
+        for (int e = 0; e < W; ++e) {
+            const float xh = (zv[e] - mu[e]) * rs[e];
+            const float y = fmaf(ga[e], xh, be[e]);
+            const float dy = dv[e] * keep[e] * af_bwd(a.af, y);
+            o[e] = (ga[e] * rs[e]) * (dy - sdy[e] * invR - xh * (sdyx[e] * invR));
+        }
     } else {
-        dz[(size_t)r * a.ld + c] = da[(size_t)r * a.ld + c] * thr_keep * af_bwd(a.af, zv);
+        for (int e = 0; e < W; ++e) o[e] = dv[e] * keep[e] * af_bwd(a.af, zv[e]);
     }
+    if constexpr (W == 4) *reinterpret_cast<vec *>(dz + (size_t)r * a.ld + c) = o;
+    else dz[(size_t)r * a.ld + c] = o[0];
+}
+
+// float4 path: column count and leading dimension multiples of 4, every (non-null) pointer 16-byte aligned
+template <class... P> static bool vec4_ok(int N, int ld, P... ptrs) {
+    bool ok = (N % 4 == 0) && (ld % 4 == 0);
+    ((ok = ok && ((reinterpret_cast<uintptr_t>(ptrs) & 15) == 0)), ...);
+    return ok;
 }
 
 static int bn_blocks(int R) {
@@ -209,20 +353,16 @@ extern "C" int ptr_bn_stats(const float *z, int ld, int R, int N, int group_rows
     if (group_rows < 0 || (group_rows > 0 && R % group_rows)) { set_error("%s: R=%d is not a multiple of group_rows=%d", who, R, group_rows); return PTR_ERR_INVALID_ARG; }
     hipStream_t st = as_stream(stream);
     BnActArgs a{group_rows, R, N, ld, 0, 0, 0.0f, 0, 0, 0};
+    const bool v4 = vec4_ok(N, ld, z, ws, mean, rstd);
+    const int nb = group_rows > 0 ? R / group_rows : bn_blocks(R);
+    if (v4) hipLaunchKernelGGL((colsum2_kernel<0, 4>), dim3(nb), dim3(256), 0, st, z, nullptr, nullptr, nullptr, nullptr, nullptr, a, ws);
+    else hipLaunchKernelGGL((colsum2_kernel<0, 1>), dim3(nb), dim3(256), 0, st, z, nullptr, nullptr, nullptr, nullptr, nullptr, a, ws);
     if (group_rows > 0) {
-        const int G = R / group_rows;
-        const unsigned fin = (unsigned)(((size_t)G * N + 255) / 256);
-        hipLaunchKernelGGL(colsum2_kernel<0>, dim3(G), dim3(256), 0, st, z, nullptr, nullptr, nullptr, nullptr, nullptr, a, ws);
-        hipLaunchKernelGGL(group_finish_kernel<1>, dim3(fin), dim3(256), 0, st, ws, (size_t)G, N, group_rows, eps, mean);
-        hipLaunchKernelGGL(colsum2_kernel<2>, dim3(G), dim3(256), 0, st, z, nullptr, mean, nullptr, nullptr, nullptr, a, ws);
-        hipLaunchKernelGGL(group_finish_kernel<2>, dim3(fin), dim3(256), 0, st, ws, (size_t)G, N, group_rows, eps, rstd);
-        return check_hip(hipGetLastError(), who);
+        const unsigned fin = (unsigned)(((size_t)nb * N + 255) / 256);
+        hipLaunchKernelGGL(group_finish_kernel, dim3(fin), dim3(256), 0, st, ws, (size_t)nb, N, group_rows, eps, mean, rstd);
+    } else {
+        hipLaunchKernelGGL(colsum2_reduce_kernel<1>, dim3((N + 7) / 8), dim3(256), 0, st, ws, nb, N, R, (R + nb - 1) / nb, eps, mean, rstd);
     }
-    const int nb = bn_blocks(R);
-    hipLaunchKernelGGL(colsum2_kernel<0>, dim3(nb), dim3(256), 0, st, z, nullptr, nullptr, nullptr, nullptr, nullptr, a, ws);
-    hipLaunchKernelGGL(colsum2_reduce_kernel<1>, dim3((N + 255) / 256), dim3(256), 0, st, ws, nb, N, R, eps, mean, nullptr);
-    hipLaunchKernelGGL(colsum2_kernel<2>, dim3(nb), dim3(256), 0, st, z, nullptr, mean, nullptr, nullptr, nullptr, a, ws);
-    hipLaunchKernelGGL(colsum2_reduce_kernel<2>, dim3((N + 255) / 256), dim3(256), 0, st, ws, nb, N, R, eps, rstd, nullptr);
     return check_hip(hipGetLastError(), who);
 }
 
@@ -236,8 +376,13 @@ extern "C" int ptr_bnact_forward(const float *z, int ld, int R, int N, int group
     if (!z || !out || (mean && !rstd)) { set_error("%s: NULL pointer", who); return PTR_ERR_INVALID_ARG; }
     if (group_rows < 0 || (group_rows > 0 && R % group_rows)) { set_error("%s: R=%d is not a multiple of group_rows=%d", who, R, group_rows); return PTR_ERR_INVALID_ARG; }
     BnActArgs a{mean ? group_rows : 0, R, N, ld, af, mean ? 1 : 0, p_drop, (uint32_t)seed, (uint32_t)(seed >> 32), site};
-    const size_t n = (size_t)R * N;
-    hipLaunchKernelGGL(bnact_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), z, mean, rstd, gamma, beta, a, out);
+    if (vec4_ok(N, ld, z, out, mean, rstd, gamma, beta)) {
+        const size_t n = (size_t)R * (N / 4);
+        hipLaunchKernelGGL(bnact_fwd_kernel<4>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), z, mean, rstd, gamma, beta, a, out);
+    } else {
+        const size_t n = (size_t)R * N;
+        hipLaunchKernelGGL(bnact_fwd_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), z, mean, rstd, gamma, beta, a, out);
+    }
     return check_hip(hipGetLastError(), who);
 }
 
@@ -255,17 +400,24 @@ extern "C" int ptr_bnact_backward(const float *z, const float *da, int ld, int R
     hipStream_t st = as_stream(stream);
     BnActArgs a{mean ? group_rows : 0, R, N, ld, af, mean ? 1 : 0, p_drop, (uint32_t)seed, (uint32_t)(seed >> 32), site};
     const float *sum_dy = nullptr, *sum_dyx = nullptr;
+    const bool v4 = vec4_ok(N, ld, z, da, dz, ws, mean, rstd, gamma, beta, dgamma, dbeta);
     if (mean) {
         const int nb = a.group > 0 ? R / a.group : bn_blocks(R);
-        float *tot_dy = ws + (size_t)nb * 2 * N, *tot_dyx = tot_dy + N;
-        hipLaunchKernelGGL(colsum2_kernel<1>, dim3(nb), dim3(256), 0, st, z, da, mean, rstd, gamma, beta, a, ws);
-        hipLaunchKernelGGL(colsum2_reduce_kernel<0>, dim3((N + 255) / 256), dim3(256), 0, st, ws, nb, N, R, 0.0f, tot_dy, tot_dyx);
-        if (dbeta) { if (int e = check_hip(hipMemcpyAsync(dbeta, tot_dy, N * sizeof(float), hipMemcpyDeviceToDevice, st), who)) return e; }
-        if (dgamma) { if (int e = check_hip(hipMemcpyAsync(dgamma, tot_dyx, N * sizeof(float), hipMemcpyDeviceToDevice, st), who)) return e; }
+        // totals over all rows: straight into dbeta / dgamma when the caller wants them
+        float *tot_dy = dbeta ? dbeta : ws + (size_t)nb * 2 * N, *tot_dyx = dgamma ? dgamma : ws + (size_t)nb * 2 * N + N;
+        if (v4) hipLaunchKernelGGL((colsum2_kernel<1, 4>), dim3(nb), dim3(256), 0, st, z, da, mean, rstd, gamma, beta, a, ws);
+        else hipLaunchKernelGGL((colsum2_kernel<1, 1>), dim3(nb), dim3(256), 0, st, z, da, mean, rstd, gamma, beta, a, ws);
+        if (a.group == 0 || dbeta || dgamma)
+            hipLaunchKernelGGL(colsum2_reduce_kernel<0>, dim3((N + 7) / 8), dim3(256), 0, st, ws, nb, N, R, 0, 0.0f, tot_dy, tot_dyx);
         sum_dy = a.group > 0 ? ws : tot_dy;                 // grouped: the per-group partials themselves
         sum_dyx = a.group > 0 ? ws + N : tot_dyx;
     }
-    const size_t n = (size_t)R * N;
-    hipLaunchKernelGGL(bnact_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, z, da, mean, rstd, gamma, beta, sum_dy, sum_dyx, a, dz);
+    if (v4) {
+        const size_t n = (size_t)R * (N / 4);
+        hipLaunchKernelGGL(bnact_bwd_kernel<4>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, z, da, mean, rstd, gamma, beta, sum_dy, sum_dyx, a, dz);
+    } else {
+        const size_t n = (size_t)R * N;
+        hipLaunchKernelGGL(bnact_bwd_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, z, da, mean, rstd, gamma, beta, sum_dy, sum_dyx, a, dz);
+    }
     return check_hip(hipGetLastError(), who);
 }
