@@ -627,19 +627,24 @@ layernorm_bwd_kernel(const float *__restrict__ X, const float *__restrict__ a2, 
         part[(size_t)blockIdx.x * 2 * F + d] = (red[d] + red[(size_t)2 * F + d]) + (red[(size_t)4 * F + d] + red[(size_t)6 * F + d]);
 }
 
-// Fixed-order reduction of the per-block partials: 64 columns x 4 row slices per block.
+// Fixed-order reduction of the per-block partials: 16 columns x 16 partial lanes per workgroup (lane sl sums the partials sl, sl + 16, ...
+// four at a time; the 16 lane sums are added in lane order).
 __global__ void __launch_bounds__(256)
 layernorm_reduce_kernel(const float *__restrict__ part, int nblk, int F, float *__restrict__ da2, float *__restrict__ db2) {
-    __shared__ float sl[4][64];
-    const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int d = blockIdx.x * 64 + col;
+    constexpr int CL = 16, BL = 16;
+    __shared__ float red[BL][CL + 1];
+    const int cl = threadIdx.x & (CL - 1), sl = threadIdx.x / CL;
+    const int d = blockIdx.x * CL + cl;
+    const bool on = d < 2 * F;
+    auto at = [&](int k) { return k < nblk ? part[(size_t)k * 2 * F + d] : 0.0f; };
     float s = 0.0f;
-    if (d < 2 * F)
-        for (int k = slice; k < nblk; k += 4) s += part[(size_t)k * 2 * F + d];
-    sl[slice][col] = s;
+    if (on)
+        for (int k = sl; k < nblk; k += 4 * BL) s += (at(k) + at(k + BL)) + (at(k + 2 * BL) + at(k + 3 * BL));
+    red[sl][cl] = s;
     __syncthreads();
-    if (slice == 0 && d < 2 * F) {
-        const float t = (sl[0][col] + sl[1][col]) + (sl[2][col] + sl[3][col]);
+    if (sl == 0 && on) {
+        float t = 0.0f;
+        for (int k = 0; k < BL; ++k) t += red[k][cl];
         if (d < F) da2[d] = t; else db2[d - F] = t;
     }
 }
@@ -802,6 +807,6 @@ extern "C" int ptr_layernorm_backward(const float *X, const float *a2, const flo
     else if (ni == 3) rc0 = launch.template operator()<3>(); else if (ni == 4) rc0 = launch.template operator()<4>();
     else rc0 = launch.template operator()<0>();
     if (rc0) return rc0;
-    hipLaunchKernelGGL(layernorm_reduce_kernel, dim3((2 * F + 63) / 64), dim3(256), 0, st, ws, blocks, F, da2, db2);
+    hipLaunchKernelGGL(layernorm_reduce_kernel, dim3((2 * F + 15) / 16), dim3(256), 0, st, ws, blocks, F, da2, db2);
     return check_hip(hipGetLastError(), who);
 }
