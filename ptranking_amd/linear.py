@@ -53,13 +53,14 @@ def _bwd_input(dy2, weight, gate=None, p=0.0):
     return dx
 
 
-def _bwd_weight(x2, ldx, dy2, want_bias):
+def _bwd_weight(x2, ldx, dy2, want_bias, dw_out=None, db_out=None):
+    """dW, db; dw_out / db_out: contiguous tensors to write them into (gradient sinks of a flattened stack)."""
     R, K = x2.shape
     N = dy2.shape[1]
     dev = x2.device
     ws = torch.empty(_lib.query("ptr_linear_backward_weight_ws_floats", R, K, N), device=dev, dtype=torch.float32)
-    dw = torch.empty((N, K), device=dev, dtype=torch.float32)
-    db = torch.empty(N, device=dev, dtype=torch.float32) if want_bias else None
+    dw = dw_out if dw_out is not None else torch.empty((N, K), device=dev, dtype=torch.float32)
+    db = (db_out if db_out is not None else torch.empty(N, device=dev, dtype=torch.float32)) if want_bias else None
     with torch.cuda.device(dev):
         _lib.call("ptr_linear_backward_weight", _lib.ptr(x2), ldx, _lib.ptr(dy2), N, R, K, N, _lib.ptr(ws), _lib.ptr(dw), _lib.ptr(db),
                   _lib.current_stream(dev))
@@ -196,14 +197,14 @@ def _bnact_fwd(z, group, mean, rstd, gamma, beta, af, p, seed, site):
     return out
 
 
-def _bnact_bwd(z, da, group, mean, rstd, gamma, beta, af, p, seed, site):
+def _bnact_bwd(z, da, group, mean, rstd, gamma, beta, af, p, seed, site, dg_out=None, db_out=None):
     R, N = z.shape
     dev = z.device
     has_bn = mean is not None
     ws = torch.empty(_lib.query("ptr_bn_ws_floats", R, N, group) + 2 * N, device=dev, dtype=torch.float32) if has_bn else None
     dz = torch.empty_like(z)
-    dg = torch.empty(N, device=dev, dtype=torch.float32) if (has_bn and gamma is not None) else None
-    db = torch.empty(N, device=dev, dtype=torch.float32) if (has_bn and beta is not None) else None
+    dg = (dg_out if dg_out is not None else torch.empty(N, device=dev, dtype=torch.float32)) if (has_bn and gamma is not None) else None
+    db = (db_out if db_out is not None else torch.empty(N, device=dev, dtype=torch.float32)) if (has_bn and beta is not None) else None
     with torch.cuda.device(dev):
         _lib.call("ptr_bnact_backward", _lib.ptr(z), _lib.ptr(da), N, R, N, group, _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(beta), af,
                   C.c_float(p), C.c_uint64(seed), site, _lib.ptr(ws), _lib.ptr(dz), _lib.ptr(dg), _lib.ptr(db), _lib.current_stream(dev))
@@ -265,11 +266,12 @@ class _StackFn(torch.autograd.Function):
     and the layer inputs are kept for backward."""
 
     @staticmethod
-    def forward(ctx, x, p, seed, spec, sink, *params):
+    def forward(ctx, x, p, seed, spec, sink, gsinks, *params):
         out, ins, zs, stats, lda = _stack_forward(x, p, seed, spec, params, sink=sink)
         flat_stats = [t for ms in stats for t in ms]
         ctx.save_for_backward(*ins, *zs, *flat_stats, *params)
         ctx.meta = (spec[0], p, seed, spec, lda)
+        ctx.gsinks = gsinks            # per parameter: the tensor its gradient is WRITTEN into (flattened stack), or None
         return out.view(*x.shape[:-1], out.shape[1])
 
     @staticmethod
@@ -282,6 +284,10 @@ class _StackFn(torch.autograd.Function):
         dev = dout.device
         d = dout.reshape(-1, dout.shape[-1]).contiguous()
         grads = [None] * len(params)
+        gs = ctx.gsinks() if ctx.gsinks is not None else None      # claimed once per zero_grad(): a second backward accumulates
+        if gs is None:
+            gs = [None] * len(params)
+        ret = lambda g, k: None if gs[k] is not None else g        # sunk gradients are not handed to autograd
         for i in range(n - 1, -1, -1):
             W = params[per * i]
             gamma, beta = (params[per * i + 2], params[per * i + 3]) if has_bn else (None, None)
@@ -289,12 +295,13 @@ class _StackFn(torch.autograd.Function):
             af = afs[i] if hidden else tail_af
             if hidden or af != 0:
                 pd = p if (hidden and i < n - 2) else 0.0
-                d, dg, dbt = _bnact_bwd(zs[i], d, group, fs[2 * i], fs[2 * i + 1], gamma, beta, af, pd, seed, i + 1)
+                d, dg, dbt = _bnact_bwd(zs[i], d, group, fs[2 * i], fs[2 * i + 1], gamma, beta, af, pd, seed, i + 1,
+                                        gs[per * i + 2] if has_bn else None, gs[per * i + 3] if has_bn else None)
                 if has_bn:
-                    grads[per * i + 2], grads[per * i + 3] = dg, dbt
+                    grads[per * i + 2], grads[per * i + 3] = ret(dg, per * i + 2), ret(dbt, per * i + 3)
             a_in = ins[i]
-            dw, db = _bwd_weight(a_in, lda if i == 0 else a_in.shape[1], d, params[per * i + 1] is not None)
-            grads[per * i], grads[per * i + 1] = dw, db
+            dw, db = _bwd_weight(a_in, lda if i == 0 else a_in.shape[1], d, params[per * i + 1] is not None, gs[per * i], gs[per * i + 1])
+            grads[per * i], grads[per * i + 1] = ret(dw, per * i), ret(db, per * i + 1)
             if i > 0:
                 d = _bwd_input(d, W)
             elif ctx.needs_input_grad[0]:
@@ -305,8 +312,8 @@ class _StackFn(torch.autograd.Function):
                         _lib.call("ptr_dropout_apply", _lib.ptr(dx), dx.shape[1], dx.shape[0], dx.shape[1], C.c_float(p), C.c_uint64(seed), 0,
                                   _lib.ptr(dxd), dx.shape[1], _lib.current_stream(dev))
                     dx = dxd
-                return (dx.view(*dout.shape[:-1], W.shape[1]), None, None, None, None, *grads)
-        return (None, None, None, None, None, *grads)
+                return (dx.view(*dout.shape[:-1], W.shape[1]), None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, *grads)
 
 
 class FusedStack(nn.Sequential):
@@ -320,6 +327,43 @@ class FusedStack(nn.Sequential):
 
     tail_relu = False        # kept for the pure-ReLU fast path
     _plan = None
+    _flat = None             # (flat parameter buffer, flat gradient buffer) once flatten_parameters() has re-homed the parameters
+    _grads_fresh = False     # set by the owning optimiser's zero_grad(): the next backward may WRITE the gradients (no accumulation)
+
+    def flatten_parameters(self):
+        """Re-home every parameter in ONE flat fp32 buffer and its gradient in one flat gradient buffer (parameters and `.grad`s
+        become views; names, shapes and state_dict are unchanged): one optimiser kernel and one all-reduce for the whole stack, and
+        the general stack's backward writes dW / db / dgamma / dbeta straight into the gradient buffer.  Call after .cuda()."""
+        if self._flat is not None:
+            return self._flat
+        ps = list(self.parameters())
+        dev = ps[0].device
+        sizes = [(p.numel() + 3) // 4 * 4 for p in ps]                 # 16-byte aligned slices (float4 kernels)
+        flat = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
+        gflat = torch.zeros_like(flat)
+        off = 0
+        with torch.no_grad():
+            for p, sz in zip(ps, sizes):
+                n = p.numel()
+                flat[off:off + n].copy_(p.data.reshape(-1))
+                p.data = flat[off:off + n].view(p.shape)
+                p.grad = gflat[off:off + n].view(p.shape)
+                off += sz
+        self._flat = (flat, gflat)
+        return self._flat
+
+    def _claim_sinks(self, params):
+        """Gradient sinks for one backward: each leaf parameter's `.grad` view, handed out only for the FIRST backward after the
+        optimiser's zero_grad() (a second backward before the next zero_grad accumulates through autograd as usual)."""
+        if self._flat is None:
+            return None
+
+        def claim():
+            if not self._grads_fresh:
+                return None
+            self._grads_fresh = False
+            return [p.grad if (isinstance(p, nn.Parameter) and p.grad is not None and p.grad.is_contiguous()) else None for p in params]
+        return claim
 
     def _make_plan(self):
         mods = list(self)
@@ -415,7 +459,7 @@ class FusedStack(nn.Sequential):
             out = _stack_forward(x, float(p), seed, spec, [t.detach() if t is not None else None for t in params], fixed_stats=fixed)[0]
             return out.view(*x.shape[:-1], out.shape[1])
         sink = [] if kind == "bn2" else None
-        out = _StackFn.apply(x, float(p), seed, spec, sink, *params)
+        out = _StackFn.apply(x, float(p), seed, spec, sink, self._claim_sinks(params), *params)
         if sink:                                   # moving statistics, averaged over the queries of the batch (utils.py:242-245)
             with torch.no_grad():
                 for i, mean, rstd in sink:

@@ -203,11 +203,30 @@ class FlatAdam(torch.optim.Optimizer):
         self._opt_called = True           # what torch.optim.lr_scheduler's wrapper of step() records
 
 
+class FlatViewAdam(FlatAdam):
+    """FlatAdam over the ONE flat buffer a FusedStack's parameters are views of (linear.FusedStack.flatten_parameters): one Adam
+    kernel for the whole scoring function instead of torch.optim's multi-tensor update (0.34 ms of host time per step for the
+    22 tensors of the default pointsf), zero_grad() = one memset that also tells the stack that its next backward may write the
+    gradients in place."""
+
+    def __init__(self, stack, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        flat, gflat = stack.flatten_parameters()
+        self.stack = stack
+        self.flat_param = torch.nn.Parameter(flat)          # shares the storage the module's parameters view
+        self.flat_param.grad = gflat
+        super().__init__([self.flat_param], lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+
+    def zero_grad(self, set_to_none=True):
+        self.flat_param.grad.zero_()
+        self.stack._grads_fresh = True
+
+
 class FusedScorerMixin:
     """Makes a ranker build the fused scorer + FlatAdam whenever its pointsf configuration allows it (otherwise the base
     class's own torch modules are used).  Set `use_fused_scorer = False` on the class or instance to opt out."""
 
     use_fused_scorer = True
+    use_flat_stack_optimizer = True     # FusedStack + Adam: parameters re-homed in one flat buffer, FlatViewAdam
 
     def ini_pointsf(self, **kw):
         on_gpu = bool(getattr(self, "gpu", False)) and torch.cuda.is_available()
@@ -225,5 +244,10 @@ class FusedScorerMixin:
         if isinstance(sf, FusedPointScorer) and self.opt == 'Adam':
             self.optimizer = FlatAdam(self.get_parameters(), lr=self.lr, weight_decay=self.weight_decay)
             self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=20, gamma=0.5)   # ranker.py:525
+        elif (self.opt == 'Adam' and type(sf).__name__ == 'FusedStack' and self.use_flat_stack_optimizer
+              and all(p.is_cuda and p.dtype == torch.float32 for p in sf.parameters())):
+            self.optimizer = FlatViewAdam(sf, lr=self.lr, weight_decay=self.weight_decay)
+            self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=20, gamma=0.5)   # ranker.py:525
+            self._dp_single = self.optimizer.flat_param     # data parallelism: ONE all-reduce of the flat gradient (rankers.FusedStepMixin)
         else:
             super().config_optimizer()

@@ -72,6 +72,59 @@ def test_two_ranks_on_one_gpu_match_the_full_batch(name, tmp_path):
     assert float((r0["grads"] - ref).abs().max()) <= 2e-5 * scale
 
 
+# ------------------------------------------------------------------------------------------------ layer-wise stack (flat parameters)
+GSF = {"sf_id": "pointsf", "opt": "Adam", "lr": 1e-3,
+       "pointsf": dict(num_features=136, num_layers=3, AF="GE", TL_AF="S", apply_tl_af=True, BN=False, bn_type=None,
+                       bn_affine=False, dropout=0.0)}
+
+
+def _make_stack():
+    import ptranking_amd as pa
+    torch.manual_seed(21)
+    r = pa.LambdaRank(sf_para_dict=copy.deepcopy(GSF), model_para_dict=dict(pa.DEFAULT_PARAS["LambdaRank"]), gpu=True, device="cuda:0")
+    r.init()
+    r.train_mode()
+    return r
+
+
+def _stack_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      PTR_DP_BACKEND="gloo")
+    import ptranking_amd as pa
+    from ptranking_amd import dp
+    dp.init_from_env()
+    X, Y = _data()
+    lo, hi = dp.shard_queries(X.size(0))
+    r = _make_stack()
+    grads = None
+    for step in range(2):
+        loss, _ = r.train_op(X[lo:hi].cuda(), Y[lo:hi].cuda(), epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
+        if step == 0:
+            grads = r.optimizer.flat_param.grad.detach().cpu().clone()
+    torch.save({"flat": r.optimizer.flat_param.detach().cpu(), "grads": grads}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_stack_under_data_parallelism(tmp_path):
+    """GELU stack (FusedStack, parameters in one flat buffer, FlatViewAdam): ONE all-reduce of the flat gradient; replicas stay
+    bit-identical and the exchanged gradient equals the single-process full-batch gradient."""
+    import ptranking_amd as pa
+    from ptranking_amd.scorer import FlatViewAdam
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_stack_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"rank{i}.pt") for i in range(2))
+    assert torch.equal(r0["flat"], r1["flat"]), "replicas diverged"
+    assert torch.equal(r0["grads"], r1["grads"])
+    X, Y = _data()
+    r = _make_stack()
+    assert isinstance(r.optimizer, FlatViewAdam)
+    r.train_op(X.cuda(), Y.cuda(), epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
+    ref = r.optimizer.flat_param.grad.detach().cpu()
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((r0["grads"] - ref).abs().max()) <= 2e-5 * scale
+
+
 # ------------------------------------------------------------------------------------------------ listsf under data parallelism
 LSF = {"sf_id": "listsf", "opt": "Adagrad", "lr": 1e-3,
        "listsf": dict(num_features=24, ff_dims=[16, 32], AF="R", TL_AF="GE", apply_tl_af=False, BN=False, bn_type="BN2",
