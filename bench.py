@@ -11,7 +11,7 @@ Rank 0 prints ONE JSON line (contract in the task statement).  `value` is measur
 4096; weak scaling — or --global-batch G for strong scaling); `by_batch` carries SURVEY.md 8(d)'s sweep 64 / 256 / 1024 / 4096
 queries per GPU (1024 is the survey's headline batch) measured the same way with fewer steps.  Extra objects:
   roofline      the dominant kernel of the step by time (the fused single-pass scorer backward, fp32 MFMA): algorithmic flops per
-                launch / its average launch duration measured with HIP events on the launch stream during the timed region, vs
+                launch / its average launch duration measured with HIP events on the launch stream during the timed region (every 4th step), vs
                 the 157.3 TFLOP/s fp32 MFMA peak; `traffic` = PMC HBM bytes (profiles/r02_pmc_traffic.json), `algorithmic_bytes_*`
                 = SURVEY 8(d)'s definition (features + scores), `design_bytes_*` = what the design additionally moves (stored
                 activations, partial gradients)
@@ -43,6 +43,7 @@ HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E spec peak (/opt/skills/guides/M
 MFMA_F32_PEAK_TFLOPS = 157.3      # dense fp32-input MFMA peak = fp32 vector peak (same guide)
 MSLR_P = [0.5147, 0.3250, 0.1339, 0.0183, 0.0081]   # label histogram of MSLR-WEB30K
 SEED = 137                        # ptranking/ltr_global.py:7
+EVENT_EVERY = 4                   # per-kernel HIP-event brackets on every 4th step of the timed region
 NUM_SIMD = 256 * 4                # 256 CUs x 4 SIMDs
 PEAK_CLOCK_HZ = 2.4e9
 # pair-loop VALU instructions per pair evaluation of lambdarank_ring_kernel<DPT> read off the gfx950 ISA, 3 of them
@@ -157,7 +158,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--loss", default="LambdaRank", choices=["RankNet", "LambdaRank", "LambdaLoss", "ApproxNDCG", "ListNet", "ListMLE"],
                     help="ranker of the train step (the headline metric is LambdaRank; the others cover BASELINE.json configs 3-5)")
-    ap.add_argument("--scorer", default="pointsf", choices=["pointsf", "listsf"],
+    ap.add_argument("--scorer", default="pointsf", choices=["pointsf", "pointsf_default", "listsf"],
                     help="listsf = BASELINE.json config 5: 2-head / 6-layer DASALC encoder (fused MFMA attention), use with --loss LambdaLoss "
                          "--list-len 256 --batch 1024")
     args = ap.parse_args()
@@ -187,6 +188,9 @@ def main():
             sfd = {"sf_id": "listsf", "opt": "Adagrad", "lr": 1e-3,
                    "listsf": dict(num_features=F, ff_dims=[128, 256, 512], AF="R", TL_AF="GE", apply_tl_af=False, BN=False, bn_type="BN2",
                                   bn_affine=False, n_heads=2, encoder_layers=6, encoder_type="DASALC")}
+        elif args.scorer == "pointsf_default":      # the driver's default scoring function, parameter.py:145-146
+            sfd = {"sf_id": "pointsf", "opt": "Adam", "lr": 1e-3,
+                   "pointsf": dict(num_features=F, num_layers=5, AF="GE", TL_AF="S", apply_tl_af=True, BN=True, bn_type="BN", bn_affine=True)}
         else:
             sfd = sf_para_dict(F)
         if args.loss == "ListNet":
@@ -211,32 +215,35 @@ def main():
         gen = torch.Generator(device=device).manual_seed(SEED + 1000 * rank + Bq)   # every rank owns different queries
         batches = [synth_batch(gen, Bq, L, F, device) for _ in range(max(1, args.nbatches))]
 
-        def run_steps(n):
-            """n train steps, accumulating the loss on the device exactly like DeviceTrainLoop.train does (no host sync)."""
+        def run_steps(n, hooks=None):
+            """n train steps, accumulating the loss on the device exactly like DeviceTrainLoop.train does (no host sync).
+            hooks = (entry-point timings, all-reduce timings): HIP-event brackets around every C-ABI call of every EVENT_EVERY-th
+            step (two events per call are not free: at 64 queries per step they would be a fifth of the step)."""
             acc = torch.zeros((), device=device)
             for i in range(n):
                 X, Y = batches[i % len(batches)]
+                on = hooks is not None and i % EVENT_EVERY == 0
+                if on:
+                    _lib.TIMING, dp.TIMING = hooks
                 loss, _ = ranker.train_op(X, Y, epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
+                if on:
+                    _lib.TIMING, dp.TIMING = None, None
                 acc += loss.detach()
             return acc
 
         # Untimed pre-warm with EXACTLY the code of the timed region (event hooks included): the first launch of every kernel
         # lazily loads its code object (tens of ms each), and a fresh box needs a few hundred ms before clocks / allocator settle.
-        _lib.TIMING, dp.TIMING = {}, []
         for _ in range(prewarm_rounds):   # a FIXED count: every rank must issue the same number of all-reduces
-            float(run_steps(20).item())
-        _lib.TIMING, dp.TIMING = None, None
+            float(run_steps(20, ({}, [])).item())
         gc.collect()
         gc.disable()                      # no collector pauses inside the timed region
         run_steps(warmup)
         sync()
-        _lib.TIMING, dp.TIMING = {}, []
+        timing, ar_timing = {}, []
         t0 = time.perf_counter()
-        epoch_loss = run_steps(steps)
+        epoch_loss = run_steps(steps, (timing, ar_timing))
         sync()
         elapsed = time.perf_counter() - t0
-        timing, ar_timing = _lib.TIMING, dp.TIMING
-        _lib.TIMING, dp.TIMING = None, None
         gc.enable()
         if world > 1:
             t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -297,6 +304,7 @@ def main():
 
         R = B * L
         NL = 3
+        timed_steps = (args.steps + EVENT_EVERY - 1) // EVENT_EVERY       # steps of the timed region that carried event brackets
         fwd_flop = 2.0 * (100 * F + (NL - 1) * 100 * 100 + 100) * R          # algorithmic: 2*(100F + 2*100*100 + 100) per document
         bwd_flop = 2.0 * (100 * F + (NL - 1) * 100 * 100) * R + 2.0 * (NL - 1) * 100 * 100 * R + 2.0 * 100 * R   # dW + dZ chain + top
         step_ms = 1e3 * elapsed / args.steps
@@ -357,7 +365,7 @@ def main():
             kernels["loss_slot_sum"] = {"avg_launch_ms": t_sum}
         if world > 1 and ar_timing:
             kernels["gradient_allreduce"] = {"rccl_ranks": world, "allreduce_ms": float(np.mean([a.elapsed_time(b) for a, b in ar_timing])),
-                                             "bytes": 4 * (100 * F + 100 + (NL - 1) * 10100 + 101), "calls_per_step": len(ar_timing) / args.steps}
+                                             "bytes": 4 * (100 * F + 100 + (NL - 1) * 10100 + 101), "calls_per_step": len(ar_timing) / timed_steps}
         if t_bwd and args.scorer == "pointsf":
             tf = bwd_flop / (t_bwd * 1e-3) / 1e12
             fused = (NL == 3 and 129 <= F <= 144 and F % 4 == 0)
@@ -384,7 +392,19 @@ def main():
                                              "achieved_TFLOPs": 2.5 * att_flop / (t_ab * 1e-3) / 1e12}
             for nm in ("ptr_layernorm_forward", "ptr_layernorm_backward", "ptr_linear_forward", "ptr_linear_backward"):
                 if avg_ms(nm):
-                    kernels[nm] = {"avg_launch_ms": avg_ms(nm), "launches_per_step": len(timing[nm]) / args.steps}
+                    kernels[nm] = {"avg_launch_ms": avg_ms(nm), "launches_per_step": len(timing[nm]) / timed_steps}
+        elif args.scorer == "pointsf_default" and avg_ms("ptr_linear_forward"):
+            # layer-wise stack: 6 Linear layers (F -> 100 x5 -> 1), each linear -> batch statistics -> normalise / GELU / dropout
+            t_lf = avg_ms("ptr_linear_forward")
+            hid_flop = 2.0 * R * 100 * 100
+            roofline = {"kernel": "linear_fwd_kernel (hidden 100 -> 100 layers of the layer-wise stack, fp32 MFMA 16x16x4)", "bound": "hbm",
+                        "achieved": R * 800 / (t_lf * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": R * 800 / (t_lf * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                        "traffic": None, "avg_launch_ms": t_lf, "algorithmic_bytes_per_launch": R * 800, "algorithmic_flop_per_launch": hid_flop,
+                        "note": "average over the stack's linear launches (forward and backward-input share the entry point); a 100 -> 100 layer "
+                                "moves 800 B per document for 20 kflop: HBM-bound as a separate kernel (ridge ~29 flop/B)"}
+            for nm in ("ptr_linear_forward", "ptr_linear_backward_weight", "ptr_bn_stats", "ptr_bnact_forward", "ptr_bnact_backward"):
+                if avg_ms(nm):
+                    kernels[nm] = {"avg_launch_ms": avg_ms(nm), "launches_per_step": len(timing[nm]) / timed_steps}
         else:   # scorer configuration not fusable: the loss kernel is the only kernel of ours in the step
             roofline = dict(kernels.get("lambdarank_loss_grad", kernels.get("loss_grad", {})))
         qps = world * B * args.steps / elapsed
@@ -396,6 +416,8 @@ def main():
             "ms_per_step": step_ms, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"{args.loss} train step (pointsf 3x100 ReLU scorer, dropout 0.1, Adam), " if args.scorer == "pointsf" else
+                                    f"{args.loss} train step (the reference's DEFAULT pointsf: 5 x [Linear 100 -> BatchNorm(affine) -> GELU] + "
+                                    f"Linear -> BatchNorm -> Sigmoid, dropout 0.1, Adam), " if args.scorer == "pointsf_default" else
                                     f"{args.loss} train step (listsf: 2-head 6-layer DASALC encoder + 128/256/512 feed-forward stacks, "
                                     f"dropout 0.1, Adagrad), ") + f"MSLR-WEB30K-shaped synthetic, {F} feats, list_len={L}, "
                                     f"{B} queries per GPU per step (`value`; by_batch = SURVEY 8(d) sweep, 1024 = the survey's headline batch)",
