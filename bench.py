@@ -198,7 +198,7 @@ def main():
         else:
             r = cls(sf_para_dict=sfd, model_para_dict=dict(pa.DEFAULT_PARAS[args.loss]), gpu=True, device=device)
         if args.loss == "ListMLE":
-            r.tie_shuffle = "device"             # the reference's B host-side randperm calls per step would dominate
+            assert r.tie_shuffle == "device"     # the product default (the reference's B host-side randperm calls per step would dominate)
         r.init()
         r.train_mode()                           # dropout 0.1 active, exactly like the reference's train()
         return r

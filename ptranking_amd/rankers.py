@@ -307,7 +307,10 @@ class RankMSELoss(FusedStepMixin):
 
 
 class ListMLELoss(FusedStepMixin):
-    tie_shuffle = "torch"     # "torch": the reference's randperm stream (parity); "device": counter-based HIP kernel
+    # "device" (default): one counter-based HIP kernel shuffles the ties of the whole batch; "torch": the reference's construction, one
+    # torch.randperm per query from the global torch RNG (B host-driven calls per step).  Neither reproduces the reference's CPU
+    # random stream on a GPU; both draw tie orders uniformly (tests/test_parity_gpu.py::test_tie_shuffle_is_uniform_enough).
+    tie_shuffle = "device"
     _tie_seed = 137           # ptranking/ltr_global.py:7
     _tie_calls = 0
 

@@ -75,6 +75,8 @@ def test_listmle_ranker_torch_tie_shuffle_matches_reference_stream():
     ranker.init()
     X, Y = make_data(6, 4, 30, 24)
     preds = ranker.forward(X.cuda()).detach()
+    assert ranker.tie_shuffle == "device"                 # product default = what bench.py measures
+    ranker.tie_shuffle = "torch"
     torch.manual_seed(99)
     perm_dev = ranker._shuffle_ties(Y.cuda())
     torch.manual_seed(99)
