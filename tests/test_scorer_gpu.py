@@ -1,6 +1,6 @@
-"""GPU: the fused fp32-MFMA pointsf scorer (forward / backward / FlatAdam) against plain PyTorch fp32 modules built the way
-the reference builds them (ptranking/base/utils.py:288-356), with identical weights and — in training mode — the identical
-dropout masks exported from the kernel's counter-based generator."""
+"""GPU: the fused fp32-MFMA pointsf scorer (forward / backward / FlatAdam) against plain PyTorch fp32 modules ON THE CPU, built the
+way the reference builds them (ptranking/base/utils.py:288-356; pinned to the reference's own outputs by tests/test_ffnet_cpu.py),
+with identical weights and — in training mode — the identical dropout masks exported from the kernel's counter-based generator."""
 import pytest
 import torch
 
@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 def torch_scorer(F, NL):
     from ptranking_amd.host import build_pointsf
-    return build_pointsf(num_features=F, num_layers=NL, AF="R", BN=False, apply_tl_af=False, dropout=0.0).cuda()
+    return build_pointsf(num_features=F, num_layers=NL, AF="R", BN=False, apply_tl_af=False, dropout=0.0)     # CPU: plain torch ops
 
 
 def make_pair(F, NL, dropout=0.1, seed=0):
@@ -17,7 +17,7 @@ def make_pair(F, NL, dropout=0.1, seed=0):
     torch.manual_seed(seed)
     fused = FusedPointScorer(F, num_layers=NL, dropout=dropout).cuda()
     ref = torch_scorer(F, NL)
-    ref.load_state_dict(fused.state_dict())          # reference-named keys: ff_2.weight ... ff_{NL+2}.bias
+    ref.load_state_dict({k: v.cpu() for k, v in fused.state_dict().items()})   # reference-named keys: ff_2.weight ... ff_{NL+2}.bias
     return fused, ref
 
 
@@ -36,7 +36,7 @@ def test_eval_forward_matches_torch(F, NL, shape):
     X = torch.randn(*shape, F, device="cuda")
     with torch.no_grad():
         out = fused(X)
-        exp = ref(X)
+        exp = ref(X.cpu())
     assert out.shape == exp.shape == (*shape, 1)
     close(out, exp)
 
@@ -45,10 +45,10 @@ def _train_reference(ref, fused, X2d, seed, p, NL):
     """Re-run the forward in torch with the kernel's own dropout masks."""
     R = X2d.shape[0]
     lin = [m for m in ref if isinstance(m, torch.nn.Linear)]
-    a = X2d * fused.dropout_mask(R, 0, seed) / (1 - p)
+    a = X2d.cpu() * fused.dropout_mask(R, 0, seed).cpu() / (1 - p)
     for l in range(NL):
         h = torch.relu(lin[l](a))
-        a = h * fused.dropout_mask(R, l + 1, seed) / (1 - p) if l < NL - 1 else h
+        a = h * fused.dropout_mask(R, l + 1, seed).cpu() / (1 - p) if l < NL - 1 else h
     return lin[NL](a)
 
 
@@ -67,7 +67,7 @@ def test_train_forward_backward_match_torch_with_same_masks(F, NL, R, monkeypatc
     close(out, exp)
     w = torch.randn(R, 1, device="cuda")
     (out * w).sum().backward()
-    (exp * w).sum().backward()
+    (exp * w.cpu()).sum().backward()
     got = fused.views(grad=True)
     for name, prm in ref.named_parameters():
         close(got[name], prm.grad, tol=5e-5)
@@ -79,7 +79,7 @@ def test_gradients_without_dropout_and_in_eval_mode():
     X = torch.randn(777, 136, device="cuda")
     w = torch.randn(777, 1, device="cuda")
     (fused(X) * w).sum().backward()
-    (ref(X) * w).sum().backward()
+    (ref(X.cpu()) * w.cpu()).sum().backward()
     got = fused.views(grad=True)
     for name, prm in ref.named_parameters():
         close(got[name], prm.grad, tol=5e-5)
@@ -159,6 +159,7 @@ def test_ranker_uses_the_fused_scorer_and_the_fused_stack_for_other_configs():
     r2 = pa.LambdaRank(sf_para_dict=sf2, model_para_dict={"sigma": 1.0}, gpu=True, device="cuda:0")
     r2.init()
     from ptranking_amd.linear import FusedStack
-    assert isinstance(r2.point_sf, FusedStack) and isinstance(r2.optimizer, torch.optim.Adam)   # GELU: the layer-wise fused stack
+    from ptranking_amd.scorer import FlatViewAdam
+    assert isinstance(r2.point_sf, FusedStack) and isinstance(r2.optimizer, FlatViewAdam)   # GELU: the layer-wise fused stack, flat parameters
     loss2, _ = r2.train_op(X, Y, epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
     assert torch.isfinite(loss2)
