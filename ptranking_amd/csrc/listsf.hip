@@ -27,6 +27,14 @@
 namespace ptr {
 
 constexpr int kRC = 32;                // rows per LDS chunk (dK / dV)
+// workgroups per CU the attention kernels are compiled for (register budget): the backward kernels gain 4 % from a third wave per
+// SIMD (<= 168 VGPRs), the forward loses 10 % (measured at 1024 x 256 x 136, 2 heads: scratch/exp_attn.py)
+#ifndef PTR_ATTN_MINBLK_FWD
+#define PTR_ATTN_MINBLK_FWD 2
+#endif
+#ifndef PTR_ATTN_MINBLK_BWD
+#define PTR_ATTN_MINBLK_BWD (DT <= 5 ? 3 : 2)      // head dimensions above 80 would spill 80-170 registers at 168
+#endif
 
 struct AttnArgs {
     int B, L, H, dh, F;
@@ -177,7 +185,7 @@ __device__ __forceinline__ float xor_sum(float v) {
 
 // ============================================================================================ forward
 template <int DT, int RT, int NW>
-__global__ void __launch_bounds__(NW * 64, 2)
+__global__ void __launch_bounds__(NW * 64, PTR_ATTN_MINBLK_FWD)
 mhsa_fwd_kernel(const float *__restrict__ Q, const float *__restrict__ K, const float *__restrict__ V,
                 const int32_t *__restrict__ lens, AttnArgs a, float *__restrict__ O, float *__restrict__ LSE) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -316,7 +324,7 @@ attn_rowdot_kernel(const float *__restrict__ O, const float *__restrict__ dO, At
 
 // ============================================================================================ backward: dQ
 template <int DT, int NW>
-__global__ void __launch_bounds__(NW * 64, 2)
+__global__ void __launch_bounds__(NW * 64, PTR_ATTN_MINBLK_BWD)
 mhsa_bwd_dq_kernel(const float *__restrict__ Q, const float *__restrict__ K, const float *__restrict__ V,
                    const float *__restrict__ dO, const float *__restrict__ LSE, const float *__restrict__ Dv,
                    const int32_t *__restrict__ lens, AttnArgs a, float *__restrict__ dQ) {
@@ -409,7 +417,7 @@ mhsa_bwd_dq_kernel(const float *__restrict__ Q, const float *__restrict__ K, con
 
 // ============================================================================================ backward: dK, dV
 template <int DT, int NW>
-__global__ void __launch_bounds__(NW * 64, 2)
+__global__ void __launch_bounds__(NW * 64, PTR_ATTN_MINBLK_BWD)
 mhsa_bwd_dkv_kernel(const float *__restrict__ Q, const float *__restrict__ K, const float *__restrict__ V,
                     const float *__restrict__ dO, const float *__restrict__ LSE, const float *__restrict__ Dv,
                     const int32_t *__restrict__ lens, AttnArgs a, float *__restrict__ dK, float *__restrict__ dV) {
@@ -705,8 +713,9 @@ extern "C" int ptr_mhsa_forward(const float *Q, const float *K, const float *V, 
             return check_hip(hipGetLastError(), who);
         };
         // two row tiles per wave (every K / V operand read feeds two MFMAs) when the rows exist and the registers allow it
+        static const int rt1 = [] { const char *e = getenv("PTR_ATTN_RT1"); return e ? atoi(e) : 0; }();    // measurements
         if constexpr (D <= 5) {
-            if (L > 64) return attn_waves() == 8 && L > 128 ? launch.template operator()<2, 8>() : launch.template operator()<2, 4>();
+            if (L > 64 && !rt1) return attn_waves() == 8 && L > 128 ? launch.template operator()<2, 8>() : launch.template operator()<2, 4>();
         }
         return attn_waves() == 8 && L > 64 ? launch.template operator()<1, 8>() : launch.template operator()<1, 4>();
     });
