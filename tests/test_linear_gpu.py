@@ -128,3 +128,28 @@ def test_relu_stack_matches_torch_cpu_with_the_kernels_own_masks(dims, tail_relu
         a, b = net(x), net(x)
     assert torch.equal(a, b)
     assert list(net.state_dict()) == [f"ff_{i + 2}.{k}" for i in range(n) for k in ("weight", "bias")]
+
+
+@pytest.mark.parametrize("R,N,group", [(70000, 100, 0), (4097, 24, 0), (6 * 129, 100, 129), (512, 7, 0), (300, 136, 0)])
+def test_bn_stats_single_pass_is_accurate_with_large_offsets(R, N, group):
+    """Column mean / rstd in ONE pass (pivoted sums per 256-row chunk + parallel-variance combination) against float64 — on data
+    whose mean is 1e3..1e4 times its standard deviation, where E[z^2] - mean^2 in fp32 would lose every digit."""
+    from ptranking_amd.linear import _bn_stats, BN_EPS
+    torch.manual_seed(R + N)
+    base = torch.randn(1, N, dtype=torch.float64) * 300.0 + 1000.0
+    sd = torch.rand(1, N, dtype=torch.float64) * 0.2 + 0.05
+    z64 = base + sd * torch.randn(R, N, dtype=torch.float64)
+    z64[0] += 5.0 * sd[0]                                         # an outlying pivot row
+    z = z64.float().cuda().contiguous()
+    mean, rstd = _bn_stats(z, group)
+    zz = z.double().cpu()
+    if group:
+        zz = zz.view(R // group, group, N)
+        m_ref = zz.mean(dim=1).reshape(-1)
+        v_ref = zz.var(dim=1, unbiased=False).reshape(-1)
+    else:
+        m_ref = zz.mean(dim=0)
+        v_ref = zz.var(dim=0, unbiased=False)
+    r_ref = 1.0 / torch.sqrt(v_ref + BN_EPS)
+    assert float(((mean.double().cpu() - m_ref).abs() / m_ref.abs()).max()) < 5e-7       # a few fp32 ulps of the mean itself
+    assert float(((rstd.double().cpu() - r_ref).abs() / r_ref).max()) < 2e-4, float(((rstd.double().cpu() - r_ref).abs() / r_ref).max())
