@@ -233,10 +233,12 @@ def main():
 
         # Untimed pre-warm with EXACTLY the code of the timed region (event hooks included): the first launch of every kernel
         # lazily loads its code object (tens of ms each), and a fresh box needs a few hundred ms before clocks / allocator settle.
-        for _ in range(prewarm_rounds):   # a FIXED count: every rank must issue the same number of all-reduces
-            float(run_steps(20, ({}, [])).item())
+        # The collector runs BEFORE the pre-warm: tens of ms of host work with an idle GPU right in front of the timed region let the
+        # clocks fall back, and W = 5 warm-up steps (5 ms) do not bring them up again (7 % on a 20-step run).
         gc.collect()
         gc.disable()                      # no collector pauses inside the timed region
+        for _ in range(prewarm_rounds):   # a FIXED count: every rank must issue the same number of all-reduces
+            float(run_steps(20, ({}, [])).item())
         run_steps(warmup)
         sync()
         timing, ar_timing = {}, []
