@@ -1,0 +1,47 @@
+"""bench.py keeps the driver's contract: flags, ONE JSON line on stdout, the required keys, `roofline` and `cpu_baseline` objects."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config"]
+
+
+def test_bench_cli_and_cpu_baseline_helpers():
+    """CPU: the argument parser accepts the driver's flags; the cpu_baseline leg (the oracle's torch-CPU train step) runs."""
+    sys.path.insert(0, ROOT)
+    import bench
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup", "--global-batch", "--sweep"):
+        assert flag in out.stdout
+    cb = bench.cpu_baseline(16, 24, 0.6)
+    assert cb["kind"] == "port" and cb["unit"] == "queries/s" and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_contract_json_line():
+    env = dict(os.environ)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--batch", "256",
+                          "--sweep", "64", "--cpu-seconds", "0.5"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None and "workload" in d["config"]
+    assert abs(d["value"] - 256 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    cb = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert "64" in d["by_batch"] and d["by_batch"]["64"]["queries_per_s_per_gpu"] > 0
