@@ -13,7 +13,8 @@ __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
 }
 // 64 random bits for features [4*fg, 4*fg+3] of `row` at dropout site `site` (site l = the Dropout in front of hidden layer l)
 __device__ __forceinline__ void drop_bits(uint32_t seed_lo, uint32_t seed_hi, int site, int row, int fg, uint32_t &w0, uint32_t &w1) {
-    // 32-bit integer multiplies are quarter rate on CDNA: the row term is loop invariant for a lane (hoisted by the compiler), the
+    // A VALU instruction takes its cycles away from the matrix pipe of its SIMD (no MFMA / VALU overlap: scratch/clock), and 32-bit
+    // integer multiplies are quarter rate on CDNA: the row term is loop invariant for a lane (hoisted by the compiler), the
     // first word gets the full two-multiply finaliser, the second word one more multiply-xorshift round on top of it
     // (PTR_DROP_FULL_HASH restores the round-1 generator: a second full finaliser)
     const uint32_t key = (uint32_t)row * 0x9E3779B1u + ((uint32_t)fg * 0x85EBCA77u + (uint32_t)site * 0xC2B2AE3Du);

@@ -172,6 +172,7 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
             prefetch_first(next_tile, xpre);
         };
         const int row0 = tile * rows_per_tile;
+        const bool tile_full = row0 + rows_per_tile <= R;
         int row[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) row[rt] = row0 + 16 * rt + j;
@@ -208,8 +209,10 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 f32x4 v = xb[rt];
+                if (16 * S + 16 > F || !tile_full) {              // uniform: only the last super-step and the tail tile need the zero padding
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] *= ((k0 + c < F) && rok[rt]) ? 1.0f : 0.0f;
+                    for (int c = 0; c < 4; ++c) v[c] *= ((k0 + c < F) && rok[rt]) ? 1.0f : 0.0f;
+                }
                 if constexpr (TRAIN) {
                     uint32_t w0, w1;
                     drop_bits(a.seed_lo, a.seed_hi, 0, row[rt], k0 >> 2, w0, w1);

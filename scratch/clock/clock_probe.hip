@@ -22,7 +22,21 @@ __device__ __forceinline__ void body(int iters, float *sink, unsigned long long 
     float *dst = sink + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const unsigned long long c0 = clock64(), r0 = wall_clock64();
     for (int it = 0; it < iters; ++it) {
-        if constexpr (MODE == 1) {
+        if constexpr (MODE == 5 || MODE == 6) {
+            // co-issue: MODE 5 = the waves of the upper half of the block stream VALU fmas while the lower half streams MFMAs (do VALU
+            // instructions of one wave take matrix-pipe time from its SIMD partner?); MODE 6 = every wave: 8 MFMAs + 16 VALU fmas
+            const bool valu_wave = MODE == 5 && (threadIdx.x >> 6) >= (blockDim.x >> 7);
+            if (valu_wave || MODE == 6) {
+#pragma unroll
+                for (int u = 0; u < (MODE == 6 ? 2 : 4); ++u)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[i][0]) : "v"(b), "v"(a));
+            }
+            if (!valu_wave) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+            }
+        } else if constexpr (MODE == 1) {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -43,4 +57,4 @@ __device__ __forceinline__ void body(int iters, float *sink, unsigned long long 
     if (threadIdx.x == 0) { out[2 * blockIdx.x] = c1 - c0; out[2 * blockIdx.x + 1] = r1 - r0; }
 }
 #define PROBE(M) extern "C" __global__ void __launch_bounds__(512) probe##M(int iters, float *sink, unsigned long long *out) { body<M>(iters, sink, out); }
-PROBE(0) PROBE(1) PROBE(2) PROBE(3) PROBE(4)
+PROBE(0) PROBE(1) PROBE(2) PROBE(3) PROBE(4) PROBE(5) PROBE(6)

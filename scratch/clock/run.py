@@ -5,7 +5,7 @@ hip = C.CDLL("libamdhip64.so")
 mod = C.c_void_p()
 assert hip.hipModuleLoad(C.byref(mod), os.path.join(here, "clock_probe.hsaco").encode()) == 0
 fns = {}
-for m in range(5):
+for m in range(7):
     fns[m] = C.c_void_p()
     assert hip.hipModuleGetFunction(C.byref(fns[m]), mod, f"probe{m}".encode()) == 0
 grid = 256 * 2
@@ -35,3 +35,15 @@ for g, blk in ((256, 256), (256, 512), (512, 512), (768, 512), (1024, 512)):
         ms, mhz = run(0, 40000, g, blk)
     n = 8 * 40000 * (blk // 64) * g
     print(f"  grid {g:5d} x {blk} threads ({g * blk // 64 / 1024:.0f} waves/SIMD): {ms:7.3f} ms  {n * 2048 / (ms * 1e-3) / 1e12:6.1f} TFLOP/s  clock {mhz.mean():.0f} MHz")
+
+print("co-issue (512 blocks x 512 threads = 4 waves/SIMD):")
+for rep in range(2):
+    ms0, mhz0 = run(0, 20000, 512, 512)
+for rep in range(2):
+    ms5, mhz5 = run(5, 20000, 512, 512)
+for rep in range(2):
+    ms6, mhz6 = run(6, 20000, 512, 512)
+n = 8 * 20000 * 8 * 512
+print(f"  all 8 waves MFMA                         : {ms0:7.3f} ms  {n * 2048 / (ms0 * 1e-3) / 1e12:6.1f} TFLOP/s  {mhz0.mean():.0f} MHz")
+print(f"  4 waves MFMA + 4 waves VALU (32 fma/iter): {ms5:7.3f} ms  {n / 2 * 2048 / (ms5 * 1e-3) / 1e12:6.1f} TFLOP/s from half the MFMA work  {mhz5.mean():.0f} MHz")
+print(f"  every wave 8 MFMA + 16 VALU fma per iter : {ms6:7.3f} ms  {n * 2048 / (ms6 * 1e-3) / 1e12:6.1f} TFLOP/s  {mhz6.mean():.0f} MHz")

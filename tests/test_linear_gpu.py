@@ -87,15 +87,10 @@ def test_relu_stack_matches_torch_cpu_with_the_kernels_own_masks(dims, tail_relu
     assert isinstance(net, ReluStack)
     net.train()
     R = 777
-    x = torch.randn(3, R // 3, dims[0], device="cuda", requires_grad=True)
-    out = net(x)
-    assert out.shape == (3, R // 3, dims[-1])
-    g = torch.randn_like(out)
-    out.backward(g)
-    seed = net.last_seed
     n = len(dims) - 1
+    lins = [m_ for m_ in net if isinstance(m_, nn.Linear)]
 
-    def mask(site, width):                       # keep mask of dropout site `site` = ptr_dropout_apply on ones * (1 - p)
+    def mask(site, width, seed):                 # keep mask of dropout site `site` = ptr_dropout_apply on ones * (1 - p)
         if p == 0.0 or n == 1:
             return None
         ones = torch.ones(R, width, device="cuda")
@@ -105,7 +100,33 @@ def test_relu_stack_matches_torch_cpu_with_the_kernels_own_masks(dims, tail_relu
                       _lib.current_stream(ones.device))
             return (m > 0).float().cpu()
         return None
-    masks = [mask(0, dims[0])] + [mask(i + 1, dims[i + 1]) for i in range(n - 2)] + [None]
+
+    # A hidden pre-activation within rounding distance of 0 lands on either side of the ReLU depending on the summation order (the
+    # CPU reference in fp32 and in fp64 already disagree on such a unit) and flips a whole gate of the gradient: draw the data
+    # again until the float64 pre-activations keep a distance of 1e-6 from 0 (one draw in three to five does).
+    for attempt in range(80):
+        x = torch.randn(3, R // 3, dims[0], device="cuda", requires_grad=True)
+        out = net(x)
+        seed = net.last_seed
+        masks = [mask(0, dims[0], seed)] + [mask(i + 1, dims[i + 1], seed) for i in range(n - 2)] + [None]
+        a64 = x.detach().cpu().reshape(R, dims[0]).double()
+        if masks[0] is not None:
+            a64 = a64 * masks[0].double() / (1 - p)
+        zmin = float("inf")
+        for i, l in enumerate(lins):
+            z64 = a64 @ l.weight.detach().cpu().double().t() + l.bias.detach().cpu().double()
+            if i < n - 1 or tail_relu:
+                zmin = min(zmin, float(z64.abs().min()))
+            a64 = torch.relu(z64)
+            if i < n - 2 and masks[i + 1] is not None:
+                a64 = a64 * masks[i + 1].double() / (1 - p)
+        if zmin >= 1e-6:
+            break
+        net.zero_grad()
+    assert zmin >= 1e-6, "no draw without a pre-activation at rounding distance of 0"
+    assert out.shape == (3, R // 3, dims[-1])
+    g = torch.randn_like(out)
+    out.backward(g)
     params = []
     for m_ in net:
         if isinstance(m_, nn.Linear):
@@ -115,10 +136,10 @@ def test_relu_stack_matches_torch_cpu_with_the_kernels_own_masks(dims, tail_relu
     ref.backward(g.cpu().reshape(R, dims[-1]))
     close(out.reshape(R, -1), ref, what="out")
     close(x.grad.reshape(R, -1), xr.grad, tol=5e-5, what="dx")
-    lins = [m_ for m_ in net if isinstance(m_, nn.Linear)]
+    ptol = 5e-5
     for i, m_ in enumerate(lins):
-        close(m_.weight.grad, params[2 * i].grad, tol=5e-5, what=f"dW{i}")
-        close(m_.bias.grad, params[2 * i + 1].grad, tol=5e-5, what=f"db{i}")
+        close(m_.weight.grad, params[2 * i].grad, tol=ptol, what=f"dW{i}")
+        close(m_.bias.grad, params[2 * i + 1].grad, tol=ptol, what=f"db{i}")
     if p > 0 and n > 1:
         keep = masks[0].mean().item()
         assert abs(keep - (1 - p)) < 0.01
