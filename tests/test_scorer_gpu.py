@@ -163,3 +163,27 @@ def test_ranker_uses_the_fused_scorer_and_the_fused_stack_for_other_configs():
     assert isinstance(r2.point_sf, FusedStack) and isinstance(r2.optimizer, FlatViewAdam)   # GELU: the layer-wise fused stack, flat parameters
     loss2, _ = r2.train_op(X, Y, epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
     assert torch.isfinite(loss2)
+
+
+def test_dropout_generator_independence_within_and_across_rows():
+    """Keep decisions of the counter-based generator: the four elements of a feature group, neighbouring feature groups of one row
+    (they share the row key), neighbouring rows of one feature group and the same element at neighbouring sites are pairwise
+    independent (joint keep rate = 0.81 at p = 0.1), and no column / row is biased."""
+    from ptranking_amd.scorer import FusedPointScorer
+    f = FusedPointScorer(136, 3, dropout=0.1).cuda()
+    for seed in (1, 2 ** 40 + 12345, 987654321):
+        m = f.dropout_mask(16384, 0, seed)                       # [R, 136] 1 / 0
+        h = f.dropout_mask(16384, 1, seed)                       # [R, 100]
+        assert abs(m.mean().item() - 0.9) < 1.5e-3
+        tol = 4e-3
+        for a, b, what in ((m[:, 0::4], m[:, 1::4], "elements 0/1"), (m[:, 1::4], m[:, 2::4], "elements 1/2"),
+                           (m[:, 2::4], m[:, 3::4], "elements 2/3"), (m[:, 0::4], m[:, 3::4], "elements 0/3"),
+                           (m[:, :-4], m[:, 4:], "neighbouring feature groups"), (m[:, :-8], m[:, 8:], "feature groups two apart"),
+                           (m[:-1], m[1:], "neighbouring rows"), (m[:-64], m[64:], "rows 64 apart"),
+                           (m[:, :100], h, "sites 0 / 1")):
+            joint = (a * b).mean().item()
+            assert abs(joint - 0.81) < tol, f"{what}: joint keep rate {joint:.4f} (seed {seed})"
+        assert (m.mean(dim=0) - 0.9).abs().max() < 0.012 and (h.mean(dim=0) - 0.9).abs().max() < 0.012
+        # runs along a row: P(two neighbours dropped) = 0.01
+        dd = ((1 - m[:, :-1]) * (1 - m[:, 1:])).mean().item()
+        assert abs(dd - 0.01) < 1.5e-3, dd
