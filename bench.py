@@ -370,7 +370,7 @@ def main():
                                              "bytes": 4 * (100 * F + 100 + (NL - 1) * 10100 + 101), "calls_per_step": len(ar_timing) / timed_steps}
         if t_bwd and args.scorer == "pointsf":
             tf = bwd_flop / (t_bwd * 1e-3) / 1e12
-            fused = (NL == 3 and 129 <= F <= 144 and F % 4 == 0)
+            fused = (NL == 3 and 129 <= F <= 143 and F % 4 == 0)
             roofline = {"kernel": ("mlp_bwd_fused_kernel<3,9> (single-pass scorer backward: dZ chain + all weight gradients, fp32 MFMA 16x16x4) "
                                    "+ reduce_partials_kernel" if fused else "mlp_bwd_dz + 3 x mlp_bwd_dw + reduce_partials (layer-wise backward)"),
                         "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,

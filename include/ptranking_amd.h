@@ -153,7 +153,7 @@ int ptr_sum_f32(const float *x, int n, float scale, float *out, void *stream);
  * (rows padded to 112 floats = 7 aligned 64-byte sectors).
  * ptr_mlp_backward: dpreds [R] -> grad (every entry overwritten); ws (ptr_mlp_backward_ws_floats) and dz (ptr_mlp_backward_dz_floats
  * floats: [NL][R][PTR_MLP_ACT_LD] for the layer-wise kernels, 0 => may be NULL when the single-pass fused backward serves the
- * configuration — NL = 3, 129..144 features, F % 4 == 0) are caller-provided scratch; p_drop / seed must be the forward call's.
+ * configuration — NL = 3, F in {132, 136, 140}) are caller-provided scratch; p_drop / seed must be the forward call's.
  * All calls are deterministic. */
 size_t ptr_mlp_num_params(int F, int NL);
 size_t ptr_mlp_backward_ws_floats(int F, int NL);

@@ -17,8 +17,11 @@ __device__ __forceinline__ void drop_bits(uint32_t seed_lo, uint32_t seed_hi, in
     // integer multiplies are quarter rate on CDNA: the row term is loop invariant for a lane (hoisted by the compiler), the
     // first word gets the full two-multiply finaliser, the second word one more multiply-xorshift round on top of it
     // (PTR_DROP_FULL_HASH restores the round-1 generator: a second full finaliser)
+    // seed_lo enters ADDITIVELY: a replica that owns rows [row0, row0 + n) of a global batch passes seed_lo + row0 * 0x9E3779B1 and draws
+    // exactly the masks the single-device run draws for those rows (ptranking_amd/dp.py fold_row_offset) — data-parallel replicas never
+    // share masks, and N ranks x B/N queries reproduce one rank x B
     const uint32_t key = (uint32_t)row * 0x9E3779B1u + ((uint32_t)fg * 0x85EBCA77u + (uint32_t)site * 0xC2B2AE3Du);
-    w0 = lowbias32(key ^ seed_lo);
+    w0 = lowbias32(key + seed_lo);
 #ifdef PTR_DROP_FULL_HASH
     w1 = lowbias32(w0 ^ seed_hi ^ 0x68E31DA4u);
 #else

@@ -559,7 +559,9 @@ static int bwd_fused_enabled() {
 bool bwd_fused_supported(int F, int NL, const void *X, const void *acts) {
     if (!bwd_fused_enabled()) return false;
     const int NT1 = (F + 15) / 16;
-    return NL == 3 && NT1 == 9 && F % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 && (reinterpret_cast<uintptr_t>(acts) & 15) == 0;
+    // F < 16 * NT1: the X image needs a free column F for the ones column that makes column F of dW_0 the bias gradient
+    // (F = 144 fills all nine tiles: it takes the layer-wise kernels)
+    return NL == 3 && NT1 == 9 && F % 4 == 0 && F < 16 * NT1 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 && (reinterpret_cast<uintptr_t>(acts) & 15) == 0;
 }
 
 int bwd_fused_grid(int R) {

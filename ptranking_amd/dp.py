@@ -67,6 +67,28 @@ def init_from_env(backend=None):
     return rk, ws, local
 
 
+ROW_KEY = 0x9E3779B1        # the per-row multiplier of the counter-based dropout generator (csrc/ptr_dropout.h drop_bits)
+ROW_OFFSET = None           # explicit global index of this rank's first row (unequal shards); None: rank * local rows
+
+
+def fold_row_offset(seed, row0):
+    """Dropout seed of a replica whose local row r is global row row0 + r: the generator keys an element by
+    lowbias32(row * ROW_KEY + column/site terms + seed_lo), so adding row0 * ROW_KEY to the low seed word shifts the row index."""
+    lo = (seed + row0 * ROW_KEY) & 0xFFFFFFFF
+    return ((seed >> 32) << 32) | lo
+
+
+def local_dropout_seed(seed, local_rows):
+    """The seed this rank passes to the dropout kernels for a batch of `local_rows` rows (documents for the pointwise scorers).  With
+    every rank drawing the same base seed (same torch.manual_seed, as the reference's single process would) and equal shards this
+    makes rank r's row i use the mask of global row r * local_rows + i: replicas never share masks and N ranks
+    x B/N reproduce one rank x B.  Single process: the seed unchanged."""
+    if not is_distributed():
+        return seed if ROW_OFFSET is None else fold_row_offset(seed, int(ROW_OFFSET))
+    row0 = int(ROW_OFFSET) if ROW_OFFSET is not None else rank() * int(local_rows)
+    return fold_row_offset(seed, row0)
+
+
 def shard_queries(num_queries, rank_=None, world_=None):
     """Contiguous slice [lo, hi) of the query dimension owned by this rank (remainder spread over the first ranks)."""
     r = rank() if rank_ is None else rank_
@@ -74,6 +96,32 @@ def shard_queries(num_queries, rank_=None, world_=None):
     base, rem = divmod(num_queries, w)
     lo = r * base + min(r, rem)
     return lo, lo + base + (1 if r < rem else 0)
+
+
+class ViewGradBucket:
+    """FlatGradBucket's interface over a gradient buffer that ALREADY is flat and owned by someone else (scorer.FlatViewAdam: the
+    module parameters' .grad are views of it and the fused stack writes its gradients straight into it): `gbuf` = [numel gradient
+    floats | spare tail], of which `extra` tail floats travel with the gradients in the one all-reduce.  Nothing is re-pointed."""
+
+    def __init__(self, gbuf, numel, extra, on_zero):
+        if gbuf.numel() < numel + extra:
+            raise ValueError("gradient buffer has no room for the extra scalars")
+        self.numel, self.extra = numel, extra
+        self.flat = gbuf[:numel + extra]
+        self._on_zero = on_zero
+
+    @property
+    def extras(self):
+        return self.flat[self.numel:]
+
+    def zero(self):
+        self._on_zero()                 # the owner's zero_grad(): memset + "next backward may write in place"
+        if self.extra:
+            self.extras.zero_()
+
+    def all_reduce(self):
+        if is_distributed():
+            _timed_all_reduce(self.flat)
 
 
 class FlatGradBucket:

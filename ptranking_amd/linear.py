@@ -19,6 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
+from . import dp
 
 NONE, RELU, RELU_DROPOUT = 0, 1, 2
 
@@ -340,7 +341,8 @@ class FusedStack(nn.Sequential):
         dev = ps[0].device
         sizes = [(p.numel() + 3) // 4 * 4 for p in ps]                 # 16-byte aligned slices (float4 kernels)
         flat = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
-        gflat = torch.zeros_like(flat)
+        self._gbuf = torch.zeros(sum(sizes) + 4, device=dev, dtype=torch.float32)    # 4 spare floats: scalars that ride in the DP all-reduce
+        gflat = self._gbuf[:sum(sizes)]
         off = 0
         with torch.no_grad():
             for p, sz in zip(ps, sizes):
@@ -351,6 +353,25 @@ class FusedStack(nn.Sequential):
                 off += sz
         self._flat = (flat, gflat)
         return self._flat
+
+    def reattach_grads(self):
+        """Every parameter's .grad must alias its slice of the flat gradient buffer (what FlatViewAdam steps on).  module.zero_grad(),
+        a foreign optimiser's zero_grad(set_to_none=True) or a gradient bucket re-point it: a gradient found elsewhere is moved into
+        its slice (the slice was zeroed by the last zero_grad), a missing one leaves the zeroed slice.  Returns how many were re-homed."""
+        if self._flat is None:
+            return 0
+        gflat = self._flat[1]
+        off, moved = 0, 0
+        for p in self.parameters():
+            n = p.numel()
+            view = gflat[off:off + n].view(p.shape)
+            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
+                if p.grad is not None:
+                    view.copy_(p.grad)
+                p.grad = view
+                moved += 1
+            off += (n + 3) // 4 * 4
+        return moved
 
     def _claim_sinks(self, params):
         """Gradient sinks for one backward: each leaf parameter's `.grad` view, handed out only for the FIRST backward after the
@@ -418,7 +439,13 @@ class FusedStack(nn.Sequential):
             return super().forward(x)
         lins = plan["lins"]
         p = plan["p"] if self.training else 0.0
+        if p > 0.0 and len(lins) > 1 and x.shape[-1] % 4:
+            # the fused input dropout works on float4 feature groups: other widths (46-feature MQ2007/2008 data in front of a listsf
+            # head / tail stack or a GELU pointsf) run module by module — FusedLinear GEMMs take any K, nn.Dropout / torch activations
+            return super().forward(x)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0      # CPU generator: no device sync
+        if p > 0.0:
+            seed = dp.local_dropout_seed(seed, x.numel() // x.shape[-1])           # data-parallel replicas draw the masks of THEIR global rows
         self.last_seed = seed
         if plan["relu_only"]:
             params = []

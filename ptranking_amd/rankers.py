@@ -74,9 +74,10 @@ class FusedStepMixin:
             return None                    # autograd path (torch's lr schedulers wrap step() themselves — that wrapper is fine)
         self._direct_check(kwargs)
         lens = kwargs.get('lens')
-        if lens is not None and not (lens.is_cuda and lens.dtype == torch.int32 and lens.is_contiguous()):
-            return None
         B, L, Fd = X.shape
+        if L > _lib.MAX_LIST_LEN or (lens is not None and not (lens.is_cuda and lens.dtype == torch.int32 and lens.is_contiguous()
+                                                               and lens.shape == (B,))):
+            return None                    # the autograd path validates (functional._batch) and raises
         R, NL, dev = B * L, sf.num_layers, X.device
         cache = self.__dict__.setdefault("_direct_buffers", {})
         buf = cache.get((B, L))
@@ -94,6 +95,8 @@ class FusedStepMixin:
             flat.grad = torch.empty_like(flat)
         p = sf.dropout
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0      # same CPU-generator draw as FusedPointScorer.forward
+        if p > 0.0:
+            seed = dp.local_dropout_seed(seed, R)
         loss = torch.empty(1, device=dev)
         entry, params = spec
         with torch.cuda.device(dev):
@@ -114,7 +117,12 @@ class FusedStepMixin:
 
     def _bucket(self, extra=0):
         if self._grad_bucket is None or self._grad_bucket.extra != extra:
-            self._grad_bucket = dp.FlatGradBucket(list(self.get_parameters()), extra=extra)
+            if hasattr(self.optimizer, "grad_bucket"):
+                # FlatViewAdam: the stack's gradients already live in ONE flat buffer that the optimiser steps on — a FlatGradBucket
+                # would re-point every .grad away from it and Adam would step on zeros
+                self._grad_bucket = self.optimizer.grad_bucket(extra)
+            else:
+                self._grad_bucket = dp.FlatGradBucket(list(self.get_parameters()), extra=extra)
         return self._grad_bucket
 
     def _fused_step(self, loss):

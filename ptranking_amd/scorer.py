@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from . import dp
 
 HIDDEN = 100   # ptranking/base/point_ranker.py:30
 ACT_LD = 112   # PTR_MLP_ACT_LD: leading dimension of the stored activations / dZ scratch
@@ -150,6 +151,8 @@ class FusedPointScorer(nn.Module):
         p = self.dropout if self.training else 0.0
         store = torch.is_grad_enabled() and self.flat.requires_grad
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0     # CPU generator: no device sync
+        if p > 0.0:
+            seed = dp.local_dropout_seed(seed, X2d.shape[0])                     # replicas draw the masks of THEIR global rows (dp.py)
         preds = _ScorerFn.apply(X2d, self.flat, self.num_features, self.num_layers, p, seed, store)
         return preds.view(*lead, 1)
 
@@ -219,6 +222,19 @@ class FlatViewAdam(FlatAdam):
     def zero_grad(self, set_to_none=True):
         self.flat_param.grad.zero_()
         self.stack._grads_fresh = True
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        # the stack's gradients only reach flat_param.grad while every parameter's .grad aliases its slice of it: re-home
+        # anything that module.zero_grad(), a foreign zero_grad(set_to_none=True) or a gradient bucket re-pointed
+        self.stack.reattach_grads()
+        return super().step(closure)
+
+    def grad_bucket(self, extra):
+        """dp.FlatGradBucket's interface over the flat gradient buffer itself (+ `extra` <= 4 scalars in its spare tail): the one
+        all-reduce of a loss that ships scalars with its gradients (ApproxNDCG's batch coupling, RankMSE's batch mean)."""
+        n = self.flat_param.numel()
+        return dp.ViewGradBucket(self.stack._gbuf, n, extra, self.zero_grad)
 
 
 class FusedScorerMixin:

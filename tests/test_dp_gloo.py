@@ -157,3 +157,27 @@ def test_flat_bucket_views_and_sharding():
     assert b.flat.abs().sum() == 0 and all(p.grad is not None for p in lin.parameters())
     assert [dp.shard_queries(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
     assert dp.world_size() == 1 and dp.rank() == 0 and not dp.is_distributed()
+
+
+def test_row_offset_folding_and_view_bucket():
+    """dp.fold_row_offset shifts the row index the dropout generator sees (csrc/ptr_dropout.h: key = row * ROW_KEY + ... + seed_lo);
+    dp.ViewGradBucket is FlatGradBucket's interface over a buffer someone else owns (no re-pointing of .grad)."""
+    from ptranking_amd import dp
+    seed = (123456789 << 32) | 0xFFFFFF00
+    for row0 in (0, 1, 4096 * 128, 2 ** 31 + 5):
+        s2 = dp.fold_row_offset(seed, row0)
+        assert s2 >> 32 == seed >> 32 and 0 <= s2 < 2 ** 62
+        for row in (0, 7, 1000):                          # generator key of local row `row` under s2 == key of global row row0 + row under seed
+            k_local = (row * dp.ROW_KEY + (s2 & 0xFFFFFFFF)) & 0xFFFFFFFF
+            k_global = ((row0 + row) * dp.ROW_KEY + (seed & 0xFFFFFFFF)) & 0xFFFFFFFF
+            assert k_local == k_global
+    assert dp.local_dropout_seed(seed, 100) == seed        # single process: unchanged
+    gbuf = torch.arange(14, dtype=torch.float32)
+    zeroed = []
+    b = dp.ViewGradBucket(gbuf, 10, 2, lambda: (gbuf[:10].zero_(), zeroed.append(1)))
+    assert b.flat.numel() == 12 and b.extras.data_ptr() == gbuf[10:].data_ptr()
+    b.extras[0] = 5.0
+    b.zero()
+    assert zeroed == [1] and float(gbuf[:12].abs().sum()) == 0 and float(gbuf[12]) == 12.0
+    with pytest.raises(ValueError):
+        dp.ViewGradBucket(gbuf, 13, 2, lambda: None)

@@ -1,0 +1,263 @@
+"""GPU parity in the regime bench.py measures (lead item): batches large enough that the persistent kernels take many
+trips round their loops — the fused scorer backward's slab loop with its double-buffered LDS-DMA prefetch, parity flip and redundant
+last pass (scorer_bwd.hip), the forward's per-workgroup tile queue and 3-buffer X rotation (scorer.hip), the layer-wise backward for
+F = 700, and the 16-waves-per-workgroup launches of the loss kernels at B = 4096.
+
+References: plain torch modules ON THE CPU built like ptranking/base/utils.py:288-356 (float64, so that the comparison measures the
+kernel's error and not the CPU's own fp32 summation order) with the kernel's exported dropout masks; the C oracle (oracle/ltr_oracle.c)
+for the losses; oracle.torch_ref.cpu_train_step's op sequence (ptranking/base/ranker.py:589-603) for the whole step.
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, tol, what):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, f"{what}: max|diff|={err:.3e} > {tol * scale:.3e} (scale {scale:.3e})"
+
+
+def _cpu_modules(fused, F, NL, dtype):
+    from ptranking_amd.host import build_pointsf
+    ref = build_pointsf(num_features=F, num_layers=NL, AF="R", BN=False, apply_tl_af=False, dropout=0.0)
+    ref.load_state_dict({k: v.cpu() for k, v in fused.state_dict().items()})
+    return ref.to(dtype)
+
+
+def _masks(fused, R, seed, p, NL):
+    return [fused.dropout_mask(R, s, seed).cpu() for s in range(NL)] if p > 0 else None
+
+
+def _screen_relu_kinks(X_cpu, ref64, masks, p, NL, thresh=1e-5, chunk=65536):
+    """A hidden pre-activation within rounding distance of 0 lands on either side of the ReLU depending on the fp32 summation order
+    (tests/test_linear_gpu.py:104): among 10^7..10^8 pre-activations a few always do, and each flips one gate of the backward.  Rows
+    are independent and the masks depend on the row INDEX only, so the rows whose float64 pre-activations come within `thresh` of the
+    kink are simply redrawn (about 2 in 1000) until none is left.  In place; returns the number of redrawn rows."""
+    lin = [m for m in ref64 if isinstance(m, torch.nn.Linear)]
+    g = torch.Generator().manual_seed(99)
+    R, redrawn = X_cpu.shape[0], 0
+    todo = torch.arange(R)
+    for _ in range(20):
+        bad_all = []
+        for r0 in range(0, todo.numel(), chunk):
+            rows = todo[r0:r0 + chunk]
+            with torch.no_grad():
+                a = X_cpu[rows].double()
+                if p > 0:
+                    a = a * masks[0][rows].double() / (1 - p)
+                near = torch.zeros(rows.numel(), dtype=torch.bool)
+                for l in range(NL):
+                    z = lin[l](a)
+                    near |= (z.abs() < thresh).any(dim=1)
+                    h = torch.relu(z)
+                    a = h * masks[l + 1][rows].double() / (1 - p) if (p > 0 and l < NL - 1) else h
+            bad_all.append(rows[near])
+        todo = torch.cat(bad_all)
+        if todo.numel() == 0:
+            return redrawn
+        redrawn += todo.numel()
+        X_cpu[todo] = torch.randn(todo.numel(), X_cpu.shape[1], generator=g)
+    raise AssertionError("could not draw kink-free rows")
+
+
+def _masked_forward(ref, fused, X2d_cpu, seed, p, NL, dtype, chunk=65536, masks=None):
+    """The reference's (Dropout -> Linear -> ReLU) x NL -> Linear with the kernel's own keep masks, chunked over rows."""
+    lin = [m for m in ref if isinstance(m, torch.nn.Linear)]
+    R = X2d_cpu.shape[0]
+    if masks is None:
+        masks = _masks(fused, R, seed, p, NL)
+    outs = []
+    for r0 in range(0, R, chunk):
+        a = X2d_cpu[r0:r0 + chunk].to(dtype)
+        if p > 0:
+            a = a * masks[0][r0:r0 + chunk].to(dtype) / (1 - p)
+        for l in range(NL):
+            h = torch.relu(lin[l](a))
+            a = h * masks[l + 1][r0:r0 + chunk].to(dtype) / (1 - p) if (p > 0 and l < NL - 1) else h
+        outs.append(lin[NL](a))
+    return torch.cat(outs, dim=0)
+
+
+# (a) fused single-pass backward (129 <= F <= 143, F % 4 == 0) far beyond one trip per workgroup; (b) F = 700: W1 streams from L2
+# in the forward, layer-wise backward.  R = 8192 k + 17: a ragged tail tile / slab after many full ones.
+@pytest.mark.parametrize("F,NL,R", [(136, 3, 65536), (136, 3, 524288), (136, 3, 8192 * 5 + 17), (136, 3, 8192 * 37 + 17),
+                                    (132, 3, 8192 * 9 + 3), (140, 2, 8192 * 6 + 61), (700, 3, 65536), (700, 3, 8192 * 9 + 17),
+                                    (136, 1, 100001), (46, 3, 70001), (256, 2, 66000)])
+def test_scorer_train_forward_backward_at_bench_scale(F, NL, R, monkeypatch):
+    from ptranking_amd.scorer import FusedPointScorer
+    p = 0.1
+    torch.manual_seed(R % 1000 + F)
+    fused = FusedPointScorer(F, num_layers=NL, dropout=p).cuda()
+    fused.train()
+    ref = _cpu_modules(fused, F, NL, torch.float64)
+    seed = 987654321 + R + F
+    masks = _masks(fused, R, seed, p, NL)
+    Xc = torch.randn(R, F)
+    _screen_relu_kinks(Xc, ref, masks, p, NL)
+    X = Xc.cuda()
+    monkeypatch.setattr(torch, "randint", lambda *a, **k: torch.tensor([seed]))
+    out = fused(X)
+    monkeypatch.undo()
+    exp = _masked_forward(ref, fused, Xc, seed, p, NL, torch.float64, masks=masks)
+    close(out.reshape(-1), exp.reshape(-1), 2e-5, "preds")
+    w = torch.randn(R, 1, device="cuda")
+    (out * w).sum().backward()
+    (exp * w.cpu().double()).sum().backward()
+    got = fused.views(grad=True)
+    for name, prm in ref.named_parameters():
+        close(got[name], prm.grad, 5e-5, name)
+    # eval forward (no stored activations, other tile schedule) at the same scale
+    fused.eval()
+    with torch.no_grad():
+        out_e = fused(X)
+        exp_e = _masked_forward(ref, fused, X.cpu(), 0, 0.0, NL, torch.float64)
+    close(out_e.reshape(-1), exp_e.reshape(-1), 2e-5, "eval preds")
+
+
+def test_scorer_backward_is_run_to_run_bit_stable_at_bench_scale():
+    """Fixed-order partial sums: two backward launches over 524 288 rows give identical bits (no float atomics)."""
+    from ptranking_amd.scorer import FusedPointScorer
+    fused = FusedPointScorer(136, 3, dropout=0.1).cuda()
+    fused.train()
+    X = torch.randn(524288, 136, device="cuda")
+    w = torch.randn(524288, 1, device="cuda")
+    grads = []
+    for _ in range(2):
+        torch.manual_seed(5)
+        fused.flat.grad = None
+        (fused(X) * w).sum().backward()
+        grads.append(fused.flat.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+
+
+# (c) the direct train step (five C-ABI calls) at SURVEY 8(d)'s headline batch, dropout on, against the CPU op sequence
+@pytest.mark.parametrize("name,paras,oracle_fn,okw,B,L", [
+    ("LambdaRank", dict(sigma=1.0), "lambdarank_loss", dict(sigma=1.0), 1024, 128),
+    ("RankNet", dict(sigma=1.0), "ranknet_loss", dict(sigma=1.0), 1024, 32),
+    ("ListNet", None, "listnet_loss", {}, 512, 256),
+])
+def test_direct_train_step_at_headline_batch_matches_cpu_reference(name, paras, oracle_fn, okw, B, L):
+    from oracle import torch_ref as T
+    import ptranking_amd as pa
+    F, NL, p = 136, 3, 0.1
+    sf = {"sf_id": "pointsf", "opt": "Adam", "lr": 1e-3,
+          "pointsf": dict(num_features=F, num_layers=NL, AF="R", TL_AF="S", apply_tl_af=False, BN=False, bn_type=None, bn_affine=False,
+                          dropout=p)}
+    torch.manual_seed(137)
+    cls = getattr(pa, name)
+    ranker = cls(sf_para_dict=copy.deepcopy(sf), gpu=True, device="cuda:0") if paras is None else \
+        cls(sf_para_dict=copy.deepcopy(sf), model_para_dict=dict(paras), gpu=True, device="cuda:0")
+    ranker.init()
+    ranker.train_mode()
+    fused = ranker.point_sf
+    assert type(fused).__name__ == "FusedPointScorer" and fused.dropout == p
+    cpu_net = _cpu_modules(fused, F, NL, torch.float32)
+    cpu_opt = torch.optim.Adam(cpu_net.parameters(), lr=1e-3, weight_decay=1e-3)
+    rng = np.random.default_rng(5)
+    X = torch.from_numpy(rng.standard_normal((B, L, F)).astype(np.float32))
+    Y = rng.choice(5, size=(B, L), p=[0.5147, 0.3250, 0.1339, 0.0183, 0.0081]).astype(np.float32)
+    Y[:, 0] = np.maximum(Y[:, 0], 1)
+    Y = torch.from_numpy(-np.sort(-Y, axis=1))
+    Xd, Yd = X.cuda(), Y.cuda()
+    loss_fn = getattr(T, oracle_fn)
+    for step in range(3):
+        torch.manual_seed(1000 + step)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())          # the draw _direct_train_op / FusedPointScorer.forward make
+        torch.manual_seed(1000 + step)
+        loss, stop = ranker.train_op(Xd, Yd, epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
+        assert "_direct_buffers" in ranker.__dict__, "the direct step must be the path taken"
+        preds = _masked_forward(cpu_net, fused, X.reshape(-1, F), seed, p, NL, torch.float32).view(B, L)
+        ref_loss = loss_fn(preds, Y, **okw)
+        cpu_opt.zero_grad()
+        ref_loss.backward()
+        cpu_opt.step()
+        assert stop is False
+        G.assert_close(loss.item(), ref_loss.item(), f"{name} loss step {step}")
+    for (n1, p1), (n2, p2) in zip(fused.state_dict().items(), cpu_net.named_parameters()):
+        assert n1 == n2
+        if n1 == f"ff_{NL + 2}.bias":
+            continue   # shift-invariant losses: this gradient is identically 0, Adam turns rounding noise into +-lr moves
+        assert torch.allclose(p1.detach().cpu(), p2.detach(), rtol=1e-4, atol=2e-5), n1
+
+
+# (d) the loss kernels at B = 4096 (launch geometry of the benchmark) against the C oracle
+def _synth(seed, B, L, yahoo=False):
+    rng = np.random.default_rng(seed)
+    preds = rng.standard_normal((B, L)).astype(np.float32)
+    pr = [0.2609, 0.3580, 0.2855, 0.0767, 0.0189] if yahoo else [0.5147, 0.3250, 0.1339, 0.0183, 0.0081]
+    labels = rng.choice(5, size=(B, L), p=pr).astype(np.float32)
+    labels[:, 0] = np.maximum(labels[:, 0], 1.0)
+    labels = -np.sort(-labels, axis=1)
+    return preds, labels
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _lg(fn, preds_np, *args, **kw):
+    p = _dev(preds_np).requires_grad_(True)
+    loss = fn(p, *args, **kw)
+    loss.backward()
+    return loss.detach().cpu().numpy(), p.grad.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("L", [128, 256, 512])
+@pytest.mark.parametrize("use_lens", [False, True])
+def test_losses_at_bench_batch_against_the_c_oracle(L, use_lens):
+    from oracle import c_oracle as CO
+    from ptranking_amd import functional as F
+    B = 4096
+    preds, labels = _synth(900 + L, B, L, yahoo=(L == 512))
+    ln, lens_t = None, None
+    if use_lens:
+        rng = np.random.default_rng(L)
+        ln = rng.integers(1, L + 1, size=B).astype(np.int32)
+        ln[::7] = L
+        for b in range(B):
+            labels[b, ln[b]:] = 0
+            if labels[b, :ln[b]].max() < 1:
+                labels[b, 0] = 1
+        lens_t = _dev(ln)
+    y = _dev(labels)
+    for name, fn, orc in (("lambdarank", F.lambdarank_loss, CO.lambdarank), ("ranknet", F.ranknet_loss, CO.ranknet)):
+        loss, grad = _lg(fn, preds, y, sigma=1.0, lens=lens_t)
+        lq, g = orc(preds, labels, 1.0, lens=ln)
+        G.assert_close(loss, lq.astype(np.float64).sum(), f"{name} loss")
+        G.assert_close(grad, g, f"{name} grad")
+    for lt, code, k in (("NDCG_Loss2", 1, 5), ("NDCG_Loss2++", 2, L)):
+        loss, grad = _lg(F.lambdaloss_loss, preds, y, k=k, sigma=1.0, mu=5.0, loss_type=lt, presort=True, lens=lens_t)
+        lq, g = CO.lambdaloss(preds, labels, k, 1.0, 5.0, code, True, lens=ln)
+        G.assert_close(loss, lq.astype(np.float64).sum(), f"lambdaloss {lt}")
+        G.assert_close(grad, g, f"lambdaloss {lt} grad")
+    for couple in (True, False):
+        loss, grad = _lg(F.approxndcg_loss, preds, y, alpha=10.0, presort=True, couple_batch=couple, lens=lens_t)
+        ol, dcg, inv, g = CO.approxndcg(preds, labels, 10.0, True, couple, lens=ln)
+        G.assert_close(loss, ol, f"approxndcg couple={couple}")
+        G.assert_close(grad, g, f"approxndcg couple={couple} grad")
+    loss, grad = _lg(F.listnet_loss, preds, y, lens=lens_t)
+    lq, g = CO.listnet(preds, labels, lens=ln)
+    G.assert_close(loss, lq.astype(np.float64).sum(), "listnet loss")
+    G.assert_close(grad, g, "listnet grad")
+    perm = F.shuffle_ties_order(y, seed=11, lens=lens_t)
+    loss, grad = _lg(F.listmle_loss, preds, perm, lens=lens_t)
+    lq, g = CO.listmle(preds, perm.cpu().numpy(), lens=ln)
+    G.assert_close(loss, lq.astype(np.float64).sum(), "listmle loss")
+    G.assert_close(grad, g, "listmle grad")
+    # metrics + sort at the same batch
+    ks = [1, 3, 5, 10, 20, 50]
+    out = F.metrics_at_ks(_dev(preds), y, ks, presort=True, lens=lens_t)
+    ref = CO.metrics_at_ks(preds, labels, ks, True, lens=ln)
+    for m in ("ndcg", "nerr", "ap", "p"):
+        G.assert_close(out[m].cpu().numpy(), ref[m], m)
+    vals, idx = F.sort_desc(_dev(preds), lens=lens_t)
+    rv, ri = CO.sort_desc(preds, lens=ln)
+    assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(vals.cpu().numpy(), rv)

@@ -171,3 +171,63 @@ def test_flat_stack_optimizer_matches_torch_adam():
         if k.startswith("ff_") and k.endswith(".bias"):
             continue
         close(states[0][k], states[1][k], 5e-5, f"{k} after 4 steps")
+
+
+@pytest.mark.parametrize("sf_id", ["pointsf", "listsf"])
+def test_widths_that_are_not_multiples_of_4_train_with_dropout(sf_id):
+    """46-feature data (MQ2007 / MQ2008) with dropout 0.1.  The fused input dropout works on float4 feature groups; these
+    stacks run module by module (FusedLinear GEMMs take any K) instead of raising — GELU pointsf and the listsf head / tail stacks."""
+    import ptranking_amd as pa
+    if sf_id == "pointsf":
+        sf = {"sf_id": "pointsf", "opt": "Adam", "lr": 1e-3,
+              "pointsf": dict(num_features=46, num_layers=3, AF='GE', TL_AF='S', apply_tl_af=False, BN=False, bn_type=None, bn_affine=False,
+                              dropout=0.1)}
+        r = pa.LambdaRank(sf_para_dict=sf, model_para_dict={"sigma": 1.0}, gpu=True, device="cuda:0")
+    else:
+        listsf = dict(num_features=46, ff_dims=[32, 64], AF='R', TL_AF='GE', apply_tl_af=False, BN=False, bn_type='BN2', bn_affine=False,
+                      n_heads=2, encoder_layers=2, encoder_type='DASALC', dropout=0.1)
+        sf = dict(sf_id='listsf', opt='Adagrad', lr=0.001, listsf=listsf)
+        r = pa.LambdaLoss(sf_para_dict=copy.deepcopy(sf), model_para_dict=dict(pa.DEFAULT_PARAS["LambdaLoss"]), gpu=True, device="cuda:0")
+    r.init()
+    r.train_mode()
+    X = torch.randn(6, 40, 46, device="cuda")
+    Y = torch.sort(torch.randint(0, 5, (6, 40), device="cuda").float(), dim=1, descending=True)[0].contiguous()
+    Y[:, 0] = 2.0
+    before = [p_.detach().clone() for p_ in r.get_parameters()]
+    for _ in range(2):
+        loss, stop = r.train_op(X, Y, epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
+        assert torch.isfinite(loss) and not stop
+    assert any(not torch.equal(a, b) for a, b in zip(before, r.get_parameters()))
+    r.eval_mode()
+    with torch.no_grad():
+        a, b = r.predict(X), r.predict(X)
+    assert torch.equal(a, b)
+
+
+def test_flat_view_adam_rehomes_gradients_that_were_repointed():
+    """module.zero_grad() / a foreign zero_grad(set_to_none=True) detach the stack's .grad views from the flat gradient
+    buffer; FlatViewAdam.step() re-homes them instead of silently stepping on zeros."""
+    import ptranking_amd as pa
+    sf = {"sf_id": "pointsf", "opt": "Adam", "lr": 1e-3,
+          "pointsf": dict(num_features=136, num_layers=2, AF='GE', TL_AF='S', apply_tl_af=False, BN=False, bn_type=None, bn_affine=False,
+                          dropout=0.0)}
+    r = pa.LambdaRank(sf_para_dict=sf, model_para_dict={"sigma": 1.0}, gpu=True, device="cuda:0")
+    r.init(); r.train_mode()
+    opt = r.optimizer
+    assert type(opt).__name__ == "FlatViewAdam"
+    X = torch.randn(4, 16, 136, device="cuda")
+    r.point_sf.zero_grad(set_to_none=True)               # every .grad is None now
+    (r.forward(X) ** 2).sum().backward()                 # autograd allocates fresh .grad tensors outside the flat buffer
+    want = torch.cat([p_.grad.reshape(-1) for p_ in r.point_sf.parameters()]).clone()
+    before = opt.flat_param.detach().clone()
+    opt.step()
+    got = torch.cat([opt.flat_param.grad[o:o + n] for o, n in _slices(r.point_sf)])
+    assert torch.equal(got, want) and not torch.equal(before, opt.flat_param)
+    assert r.point_sf.reattach_grads() == 0
+
+
+def _slices(stack):
+    off = 0
+    for p_ in stack.parameters():
+        yield off, p_.numel()
+        off += (p_.numel() + 3) // 4 * 4
