@@ -270,6 +270,100 @@ __device__ __forceinline__ float dpp_rol1(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), PTR_RING_DPP /* wave_rol:1 */, 0xF, 0xF, false));
 }
 
+// Pair loop of the ring kernel for DPT >= 2 documents per lane.  Own records stay put; every slot t has TWO travelling copies packed
+// in one register pair, {copy A, copy B} = the records of the lanes r and r + 16 ahead: 16 ring steps (v_mov_b32_dpp wave_rol:1 on
+// both copies) cover the lane offsets 1..16 (A) and 17..32 (B), i.e. the circulant half ring, and one packed instruction stream per
+// step handles the WHOLE block (own slot k, travelling slot t) at two offsets — so a block is either evaluated or skipped as a unit.
+// Z > 0: the last Z slots hold equal-label documents only; the blocks among them (k >= DPT - Z and t >= DPT - Z) are not evaluated
+// (compile-time: each Z is its own straight-line loop, selected by a wave-uniform switch).
+// Orientation-free pair form: with dDn = D_T - D_own (< 0: own is ranked first) and un = sigma*(G_own-G_T)*dDn,
+//   target 1 <=> un < 0;   own gradient += -un * m,  partner's += un * m,   m = sign(dDn) * (t1 ? q : fract(p))
+// (fract(p) = p for p in [0.5, 1) and 0 at p == 1: the factor that vanishes once p(1-p) underflows).
+// tot[k] = dLoss/ds of document lane + 64k; lacc = sum |un| * max(log2(.), clamp) (scaled by -ln2/sigma by the caller).
+template <int DPT, int Z>
+__device__ __forceinline__ void ring_pairs(const float (&si)[DPT], const float (&Gi)[DPT], const float (&Di)[DPT], float sigma, float c2,
+                                           float kClamp, int lane, float (&tot)[DPT], float &lacc) {
+    constexpr int ZB = DPT - Z;                                   // slots ZB..DPT-1 are mutually weight-free
+    auto active = [](int k, int t) constexpr { return !(k >= ZB && t >= ZB); };
+    f32x2 so2[DPT], go2[DPT], Do2[DPT], ga2[DPT];                 // own records, broadcast pairs {v, v}
+    f32x2 Ts[DPT], Tg[DPT], Td[DPT], Ta[DPT];                     // travelling {copy A, copy B} of slot t
+    const int ahead16 = (lane + 16) & 63;
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) {
+        const float s_ = si[k], g_ = Gi[k], d_ = Di[k] * sigma;   // un = sigma*dG*dD: sigma rides on D (signs unchanged)
+        so2[k] = f32x2{s_, s_}; go2[k] = f32x2{g_, g_}; Do2[k] = f32x2{d_, d_};
+        ga2[k] = f32x2{0.f, 0.f};
+        Ts[k] = f32x2{s_, __shfl(s_, ahead16, 64)}; Tg[k] = f32x2{g_, __shfl(g_, ahead16, 64)}; Td[k] = f32x2{d_, __shfl(d_, ahead16, 64)};
+        Ta[k] = f32x2{0.f, 0.f};
+    }
+    const f32x2 c22 = {c2, c2}, one2 = {1.0f, 1.0f}, half2 = {0.5f, 0.5f};
+    auto pair2 = [&](int k, int t, f32x2 mask, bool use_mask) {
+        const f32x2 x = (so2[k] - Ts[t]) * c22;
+        const f32x2 e = {__builtin_amdgcn_exp2f(-fabsf(x.x)), __builtin_amdgcn_exp2f(-fabsf(x.y))};
+        const f32x2 dd = one2 + e;
+        f32x2 p = {__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y)};
+        p = __builtin_elementwise_fma(p, __builtin_elementwise_fma(-dd, p, one2), p);
+        const f32x2 dDn = Td[t] - Do2[k];                        // D carries sigma
+        f32x2 un = (go2[k] - Tg[t]) * dDn;
+        if (use_mask) un = un * mask;
+        // a = probability of the target's outcome (t1 ? p : 1-p), r = 1 - a the gradient factor, without compare/select:
+        // with h = p - 1/2 (exact for p in [0.5, 1]) and c = copysign(h, un):  a = 1/2 - c,  r = 1/2 + c  (both exact:
+        // un < 0 <=> target 1 gives a = p, r = 1-p; otherwise a = 1-p, r = p).  fract() sends r = 1 (p has rounded to 1 on a
+        // target-0 pair) to 0, where the reference's p(1-p) factor vanishes.
+        const f32x2 hh = pk_sub(p, half2);
+        f32x2 c;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) c[h] = __builtin_copysignf(hh[h], un[h]);
+        const f32x2 a = pk_sub(half2, c), r = pk_add(half2, c);
+        f32x2 m;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            lacc = fmaf(fabsf(un[h]), fmaxf(__builtin_amdgcn_logf(a[h]), kClamp), lacc);
+            m[h] = __builtin_copysignf(__builtin_amdgcn_fractf(r[h]), dDn[h]);      // one v_bfi_b32
+        }
+        ga2[k] = __builtin_elementwise_fma(-un, m, ga2[k]);
+        Ta[t] = __builtin_elementwise_fma(un, m, Ta[t]);
+    };
+    auto rotate = [&]() {
+#pragma unroll
+        for (int t = 0; t < DPT; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                Ts[t][h] = dpp_rol1(Ts[t][h]); Tg[t][h] = dpp_rol1(Tg[t][h]); Td[t][h] = dpp_rol1(Td[t][h]); Ta[t][h] = dpp_rol1(Ta[t][h]);
+            }
+    };
+    // offset 0: pairs inside a lane (travelling slot t > own slot k), copy A only (copy B at offset 16 is visited at step 16)
+#pragma unroll
+    for (int k = 0; k < DPT; ++k)
+#pragma unroll
+        for (int t = k + 1; t < DPT; ++t)
+            if (active(k, t)) pair2(k, t, f32x2{1.0f, 0.0f}, true);
+    // steps 1..15: offsets r (copy A) and r + 16 (copy B)
+    for (int r = 1; r < 16; ++r) {
+        rotate();
+#pragma unroll
+        for (int k = 0; k < DPT; ++k) {
+#pragma unroll
+            for (int t = 0; t < DPT; ++t)
+                if (active(k, t)) pair2(k, t, one2, false);
+        }
+    }
+    // step 16: offset 16 (A) and the half step 32 (B), where lanes a and a+32 see each other from both ends — the lower half keeps them
+    {
+        rotate();
+        const float lm = lane < 32 ? 1.0f : 0.0f;
+#pragma unroll
+        for (int k = 0; k < DPT; ++k)
+#pragma unroll
+            for (int t = 0; t < DPT; ++t)
+                if (active(k, t)) pair2(k, t, f32x2{1.0f, lm}, true);
+    }
+    // the travelling accumulators sit 16 (copy A) / 32 (copy B) lanes behind their owners
+    const int behind16 = (lane - 16) & 63;
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) tot[k] = (ga2[k].x + ga2[k].y) + (__shfl(Ta[k].x, behind16, 64) + __shfl(Ta[k].y, lane ^ 32, 64));
+}
+
 // The waves of a block are independent (one query each, wave-local LDS hand-overs), so the block size is a launch-time choice:
 // up to 16 waves per workgroup.  256 workgroups of 16 waves spread evenly over the 256 CUs; 1024 workgroups of 4 do not (the
 // dispatcher fills some CUs deeper than others: 33.7 us vs 29.9 us for 4096 queries of 128 documents).
@@ -397,84 +491,64 @@ lambdarank_ring_kernel(const float *__restrict__ preds, const float *__restrict_
             Tacc[0] = fmaf(un, m, Tacc[0]);
         }
     } else {
-        // DPT >= 2: two pairs per instruction with packed fp32 (v_pk_add/mul/fma_f32) — the kernel is VALU-issue bound and a plain
-        // wave64 VALU instruction occupies the SIMD as long as a packed one.  Outer loop: the travelling slots move r lanes; inner:
-        // own slot k against the travelling pair (2j, 2j+1), all register indices static, the own value broadcast by op_sel.
-        // Orientation-free form: with dDn = D_T - D_own (< 0: own is ranked first) and un = sigma*(G_own-G_T)*dDn,
-        //   target 1 <=> un < 0;   own gradient += -un * m,  partner's += un * m,   m = sign(dDn) * (t1 ? q : fract(p))
-        // (fract(p) = p for p in [0.5, 1) and 0 at p == 1: the factor that vanishes once p(1-p) underflows).
-        f32x2 so2[DPT], go2[DPT], Do2[DPT];                  // own records, broadcast pairs {v, v}
-        f32x2 Ts[DPT / 2], Tg[DPT / 2], Td[DPT / 2], Ta[DPT / 2], ga2[DPT];
+        // DPT >= 2: see ring_pairs() — two pairs per instruction with packed fp32, whole (own slot, travelling slot) blocks of
+        // equal-label documents skipped.  Slot k holds documents 64k..64k+63 of the label-sorted list (lambdarank.py:36), so the tail
+        // of the list — the run of grade-0 documents, 51 % of MSLR-WEB30K — fills whole slots: Z = number of trailing slots whose real
+        // documents all carry one and the same label (empty slots count).  Every pair inside those Z slots has |G_i - G_j| = 0
+        // exactly (metric_utils.py:43) and contributes exactly 0 to loss and gradients; purity is CHECKED here (wave-uniform
+        // compares), not inferred from sortedness.
+        int Z = 0;
+        {
+            float zlab = 0.0f;
+            bool have = false, open = true;
+#pragma unroll
+            for (int k = DPT - 1; k >= 0; --k) {
+                const bool in = lane + 64 * k < n;
+                const float first = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, li[k])));   // document 64k
+                const bool empty = 64 * k >= n;
+                const bool pure = __all(!in || li[k] == first);
+                const bool ok = open && (empty || (pure && (!have || first == zlab)));
+                if (ok && !empty) { zlab = first; have = true; }
+                Z += ok ? 1 : 0;
+                open = ok;
+            }
+            Z = __builtin_amdgcn_readfirstlane(Z);
+        }
+        float tot[DPT];
+#pragma unroll
+        for (int k = 0; k < DPT; ++k) tot[k] = 0.0f;
+        auto run = [&](auto z_) { ring_pairs<DPT, decltype(z_)::value>(si, Gi, Di, sigma, c2, kClamp, lane, tot, lacc); };
+        // all labels equal: every weight is 0 — unless no document is relevant at all (IDCG = 0: G = 0 * inf), where the reference's
+        // loss and gradients are NaN (edge behaviours)
+        auto degenerate = [&]() {
+            const float bad = ridcg - ridcg;                 // 0 for a finite 1 / IDCG, NaN otherwise
+            lacc = bad;
+#pragma unroll
+            for (int k = 0; k < DPT; ++k) tot[k] = bad;
+        };
+        if constexpr (DPT == 2) {
+            switch (Z) {
+                case 0: run(std::integral_constant<int, 0>{}); break;
+                case 1: run(std::integral_constant<int, 1>{}); break;
+                default: degenerate(); break;                // every label equal: loss and gradients are exactly 0
+            }
+        } else {
+            switch (Z) {
+                case 0: run(std::integral_constant<int, 0>{}); break;
+                case 1: run(std::integral_constant<int, 1>{}); break;
+                case 2: run(std::integral_constant<int, 2>{}); break;
+                case 3: run(std::integral_constant<int, 3>{}); break;
+                default: degenerate(); break;
+            }
+        }
+        const float loss = wave_sum_dpp(lacc) * (-0.6931471805599453f / sigma);
 #pragma unroll
         for (int k = 0; k < DPT; ++k) {
-            const float s_ = si[k], g_ = Gi[k], d_ = Di[k] * sigma;     // un = sigma*dG*dD: sigma rides on D (signs unchanged)
-            so2[k] = f32x2{s_, s_}; go2[k] = f32x2{g_, g_}; Do2[k] = f32x2{d_, d_};
-            ga2[k] = f32x2{0.f, 0.f};
-            Ts[k / 2][k & 1] = s_; Tg[k / 2][k & 1] = g_; Td[k / 2][k & 1] = d_; Ta[k / 2][k & 1] = 0.0f;
+            const int i = lane + 64 * k;
+            if (valid && i < L) grad[(size_t)q * L + i] = i < n ? tot[k] : 0.0f;
         }
-        const f32x2 c22 = {c2, c2}, one2 = {1.0f, 1.0f}, half2 = {0.5f, 0.5f};
-        auto pair2 = [&](int k, int j, f32x2 mask, bool use_mask) {
-            const f32x2 x = (so2[k] - Ts[j]) * c22;
-            const f32x2 e = {__builtin_amdgcn_exp2f(-fabsf(x.x)), __builtin_amdgcn_exp2f(-fabsf(x.y))};
-            const f32x2 dd = one2 + e;
-            f32x2 p = {__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y)};
-            p = __builtin_elementwise_fma(p, __builtin_elementwise_fma(-dd, p, one2), p);
-            const f32x2 dDn = Td[j] - Do2[k];                        // D carries sigma
-            f32x2 un = (go2[k] - Tg[j]) * dDn;
-            if (use_mask) un = un * mask;
-            // a = probability of the target's outcome (t1 ? p : 1-p), r = 1 - a the gradient factor, without compare/select:
-            // with h = p - 1/2 (exact for p in [0.5, 1]) and c = copysign(h, un):  a = 1/2 - c,  r = 1/2 + c  (both exact:
-            // un < 0 <=> target 1 gives a = p, r = 1-p; otherwise a = 1-p, r = p).  fract() sends r = 1 (p has rounded to 1 on a
-            // target-0 pair) to 0, where the reference's p(1-p) factor vanishes.
-            const f32x2 hh = pk_sub(p, half2);
-            f32x2 c;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) c[h] = __builtin_copysignf(hh[h], un[h]);
-            const f32x2 a = pk_sub(half2, c), r = pk_add(half2, c);
-            f32x2 m;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                lacc = fmaf(fabsf(un[h]), fmaxf(__builtin_amdgcn_logf(a[h]), kClamp), lacc);
-                m[h] = __builtin_copysignf(__builtin_amdgcn_fractf(r[h]), dDn[h]);      // one v_bfi_b32
-            }
-            ga2[k] = __builtin_elementwise_fma(-un, m, ga2[k]);
-            Ta[j] = __builtin_elementwise_fma(un, m, Ta[j]);
-        };
-        // r = 0: pairs inside a lane (travelling slot t > own slot k)
-#pragma unroll
-        for (int k = 0; k < DPT; ++k)
-#pragma unroll
-            for (int j = 0; j < DPT / 2; ++j)
-                if (2 * j + 1 > k) pair2(k, j, f32x2{2 * j > k ? 1.0f : 0.0f, 1.0f}, !(2 * j > k));
-        // r = 1..31: every own slot against every travelling slot
-        for (int r = 1; r < 32; ++r) {
-#pragma unroll
-            for (int j = 0; j < DPT / 2; ++j)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    Ts[j][h] = dpp_rol1(Ts[j][h]); Tg[j][h] = dpp_rol1(Tg[j][h]); Td[j][h] = dpp_rol1(Td[j][h]); Ta[j][h] = dpp_rol1(Ta[j][h]);
-                }
-#pragma unroll
-            for (int k = 0; k < DPT; ++k)
-#pragma unroll
-                for (int j = 0; j < DPT / 2; ++j) pair2(k, j, one2, false);
-        }
-        // r = 32: lanes a and a+32 see each other from both ends — the lower half keeps the pairs
-        {
-#pragma unroll
-            for (int j = 0; j < DPT / 2; ++j)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    Ts[j][h] = dpp_rol1(Ts[j][h]); Tg[j][h] = dpp_rol1(Tg[j][h]); Td[j][h] = dpp_rol1(Td[j][h]); Ta[j][h] = dpp_rol1(Ta[j][h]);
-                }
-            const float lm = lane < 32 ? 1.0f : 0.0f;
-#pragma unroll
-            for (int k = 0; k < DPT; ++k)
-#pragma unroll
-                for (int j = 0; j < DPT / 2; ++j) pair2(k, j, f32x2{lm, lm}, true);
-        }
-#pragma unroll
-        for (int k = 0; k < DPT; ++k) { ga[k] = ga2[k].x + ga2[k].y; Tacc[k] = Ta[k / 2][k & 1]; }
+        if (valid && lane == 0) loss_q[q] = loss;
+        return;
     }
     // the travelling accumulators are half a ring (32 lanes) away from their owners; gradients leave in input order, coalesced
     const float loss = wave_sum_dpp(lacc) * (-0.6931471805599453f / sigma);
