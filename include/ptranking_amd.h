@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PTR_ABI_VERSION 1
+#define PTR_ABI_VERSION 2
 #define PTR_MAX_LIST_LEN 4096
 #define PTR_MAX_CUTOFFS 32
 #define PTR_MLP_ACT_LD 112
@@ -215,14 +215,21 @@ int ptr_relu_gate(const float *dy, const float *y, int64_t n, float *out, void *
 #define PTR_AF_TANH 7      /* 'T'  */
 /* group_rows: 0 = statistics over all R rows (LTRBatchNorm 'BN'); L > 0 = per group of L consecutive rows, i.e. per query (LTRBatchNorm2
  * 'BN2', utils.py:227-286; R % L == 0) — mean / rstd then are [R / L][N]. */
+/* lens / rows_per_query (ABI v2; lens nullable): PADDED query batches.  Row r of the [B * rows_per_query] rows is a
+ * real document iff (r % rows_per_query) < lens[r / rows_per_query]; only real rows enter the statistics (mean / variance, and the two
+ * column sums of the backward, divided by the number of REAL rows — of the batch for 'BN', of the query for 'BN2'), and a padded row's dz
+ * is 0, so a padded batch scores and trains exactly like the unpadded lists (the reference batches equal-length lists only,
+ * data_utils.py:683-742, so its LTRBatchNorm never sees a padded row).  group_rows > 0 requires group_rows == rows_per_query. */
 size_t ptr_bn_ws_floats(int R, int N, int group_rows);
-int ptr_bn_stats(const float *z, int ld, int R, int N, int group_rows, float eps, float *ws, float *mean, float *rstd, void *stream);
-int ptr_bnact_forward(const float *z, int ld, int R, int N, int group_rows, const float *mean, const float *rstd, const float *gamma,
-                      const float *beta, int af, float p_drop, uint64_t seed, int site, float *out, void *stream);
-/* ws: ptr_bn_ws_floats(R, N, group_rows) + 2 * N floats (only read / written with batch norm); dgamma / dbeta: sums over ALL rows */
-int ptr_bnact_backward(const float *z, const float *da, int ld, int R, int N, int group_rows, const float *mean, const float *rstd,
-                       const float *gamma, const float *beta, int af, float p_drop, uint64_t seed, int site, float *ws, float *dz,
-                       float *dgamma, float *dbeta, void *stream);
+int ptr_bn_stats(const float *z, int ld, int R, int N, int group_rows, const int32_t *lens, int rows_per_query, float eps, float *ws,
+                 float *mean, float *rstd, void *stream);
+int ptr_bnact_forward(const float *z, int ld, int R, int N, int group_rows, const int32_t *lens, int rows_per_query, const float *mean,
+                      const float *rstd, const float *gamma, const float *beta, int af, float p_drop, uint64_t seed, int site, float *out,
+                      void *stream);
+/* ws: ptr_bn_ws_floats(R, N, group_rows) floats (only read / written with batch norm); dgamma / dbeta: sums over all REAL rows */
+int ptr_bnact_backward(const float *z, const float *da, int ld, int R, int N, int group_rows, const int32_t *lens, int rows_per_query,
+                       const float *mean, const float *rstd, const float *gamma, const float *beta, int af, float p_drop, uint64_t seed,
+                       int site, float *ws, float *dz, float *dgamma, float *dbeta, void *stream);
 
 /* ---- listsf: the permutation-equivariant scorer's fused pieces (fp32 MFMA attention core, the reference's LayerNorm) ----
  * ptr_mhsa_forward replaces ptranking/base/list_ranker.py:216-240 (Q K^T / sqrt(d_h) -> softmax -> Dropout -> . V, heads = column

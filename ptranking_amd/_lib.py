@@ -11,7 +11,7 @@ import torch  # noqa: F401  — must be imported first so that OUR .so binds to 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PTR_LIB") or os.path.join(_PKG, "libptranking_amd.so")   # PTR_LIB: an experiment build (build.py --variant)
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_LIST_LEN = 4096
 MAX_CUTOFFS = 32
 
@@ -48,9 +48,9 @@ SIGNATURES = {
     "ptr_linear_backward_weight_ws_floats": [_i, _i, _i],
     "ptr_linear_backward_weight": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "ptr_bn_ws_floats": [_i, _i, _i],
-    "ptr_bn_stats": [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
-    "ptr_bnact_forward": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _u64, _i, _vp, _vp],
-    "ptr_bnact_backward": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _u64, _i, _vp, _vp, _vp, _vp, _vp],
+    "ptr_bn_stats": [_vp, _i, _i, _i, _i, _vp, _i, _f, _vp, _vp, _vp, _vp],
+    "ptr_bnact_forward": [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _f, _u64, _i, _vp, _vp],
+    "ptr_bnact_backward": [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _f, _u64, _i, _vp, _vp, _vp, _vp, _vp],
     "ptr_dropout_apply": [_vp, _i, _i, _i, _f, _u64, _i, _vp, _i, _vp],
     "ptr_relu_gate": [_vp, _vp, C.c_int64, _vp, _vp],
     "ptr_mhsa_forward": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _u64, _i, _vp, _vp, _vp],

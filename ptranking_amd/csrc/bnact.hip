@@ -49,7 +49,25 @@ struct BnActArgs {
     float p_drop;
     uint32_t seed_lo, seed_hi;
     int site;
+    const int32_t *lens;         // padded query batches: row r is a real document iff (r % L) < lens[r / L]; NULL: all rows
+    int L;                       // rows per query (only read when lens != NULL)
 };
+
+// real (non-padding) rows of [r0, r1)
+__device__ __forceinline__ int real_rows(const BnActArgs &a, int r0, int r1) {
+    if (!a.lens) return max(r1 - r0, 0);
+    int cnt = 0;
+    for (int q = r0 / a.L; q * a.L < r1; ++q) {
+        const int n = min(max(a.lens[q], 0), a.L);
+        cnt += max(0, min(r1, q * a.L + n) - max(r0, q * a.L));
+    }
+    return cnt;
+}
+__device__ __forceinline__ bool row_is_real(const BnActArgs &a, int r) {
+    if (!a.lens) return true;
+    const int q = r / a.L;
+    return r - q * a.L < a.lens[q];
+}
 
 // keep / (1 - p) factor of element (row, col) of dropout site `site` (1 when p == 0)
 __device__ __forceinline__ float drop_factor(const BnActArgs &a, int row, int col, uint32_t thr, float inv_keep) {
@@ -75,7 +93,8 @@ __device__ __forceinline__ f32x4 drop_factor4(const BnActArgs &a, int row, int c
 template <int MODE, int W>
 __global__ void __launch_bounds__(256)
 colsum2_kernel(const float *__restrict__ z, const float *__restrict__ da, const float *__restrict__ mean, const float *__restrict__ rstd,
-               const float *__restrict__ gamma, const float *__restrict__ beta, BnActArgs a, float *__restrict__ partial) {
+               const float *__restrict__ gamma, const float *__restrict__ beta, BnActArgs a, float *__restrict__ partial,
+               float *__restrict__ counts /* [gridDim.x] real rows per chunk, or NULL */) {
     using vec = float __attribute__((ext_vector_type(W)));
     __shared__ float red[2 * W][256];
     const int N = a.N, R = a.R, NG = N / W;                  // W == 4 only when N % 4 == 0
@@ -105,11 +124,13 @@ colsum2_kernel(const float *__restrict__ z, const float *__restrict__ da, const 
                 if (beta) be = ldv(beta + c);
             }
             auto acc = [&](int r, vec zv, vec dv) {
+                const float real = row_is_real(a, r) ? 1.0f : 0.0f;      // padded rows: loaded (finite) and multiplied away, no branch
                 if constexpr (MODE == 0) {
-                    const vec d = zv - kv;
+                    const vec d = (zv - kv) * real;
                     s1 += d;
                     for (int e = 0; e < W; ++e) s2[e] = fmaf(d[e], d[e], s2[e]);
                 } else {
+                    dv = dv * real;
                     vec keep;
                     if constexpr (W == 4) keep = drop_factor4(a, r, cg, thr, inv_keep);
                     else keep[0] = drop_factor(a, r, c, thr, inv_keep);
@@ -148,7 +169,7 @@ colsum2_kernel(const float *__restrict__ z, const float *__restrict__ da, const 
             for (int k = 0; k < rsub; ++k)
                 for (int e = 0; e < W; ++e) { t1[e] += red[e][k * groups_per_pass + c_in]; t2[e] += red[W + e][k * groups_per_pass + c_in]; }
             if constexpr (MODE == 0) {
-                const float nrows = (float)max(r_end - r_begin, 1);
+                const float nrows = (float)max(real_rows(a, r_begin, r_end), 1);
                 for (int e = 0; e < W; ++e) {
                     const float m1 = t1[e] / nrows;
                     t2[e] = fmaxf(t2[e] - t1[e] * m1, 0.0f);      // M2 around the chunk mean
@@ -162,6 +183,7 @@ colsum2_kernel(const float *__restrict__ z, const float *__restrict__ da, const 
         }
         __syncthreads();
     }
+    if (counts && tid == 0) counts[blockIdx.x] = (float)real_rows(a, r_begin, r_end);
 }
 
 // Fixed-order combination of the chunk partials by 8 columns x 32 partial lanes per workgroup (lane bl sums the partials bl, bl + 32, ...
@@ -169,16 +191,31 @@ colsum2_kernel(const float *__restrict__ z, const float *__restrict__ da, const 
 //   FINISH 0: out1 = sum partial[.][0], out2 = sum partial[.][1]
 //   FINISH 1: partials are (chunk mean, chunk M2) over `chunk` rows each (the last one shorter): out1 = mean, out2 = 1 / sqrt(var + eps),
 //             var = (sum M2_b + n_b (mean_b - mean)^2) / R   (biased, as BatchNorm normalises)
+// counts != NULL (padded batches): chunk b holds counts[b] real rows; their total replaces R and is also written to total_out[0]
 template <int FINISH>
 __global__ void __launch_bounds__(256)
 colsum2_reduce_kernel(const float *__restrict__ partial, int nblk, int N, int R, int chunk, float eps, float *__restrict__ out1,
-                      float *__restrict__ out2) {
+                      float *__restrict__ out2, const float *__restrict__ counts, float *__restrict__ total_out) {
     constexpr int CL = 8, BL = 32;
     __shared__ float red[2][BL][CL + 1];
+    __shared__ float cnt_red[256];
     const int cl = threadIdx.x & (CL - 1), bl = threadIdx.x / CL;
     const int c = blockIdx.x * CL + cl;
     const bool on = c < N;
-    auto rows_of = [&](int b) { return (float)(min(R, (b + 1) * chunk) - b * chunk); };
+    float Rf = (float)R;
+    if (counts) {                                            // fixed-order total of the chunk counts (integers: exact in fp32 up to 2^24)
+        float t = 0.0f;
+        for (int b = threadIdx.x; b < nblk; b += 256) t += counts[b];
+        cnt_red[threadIdx.x] = t;
+        __syncthreads();
+        for (int s_ = 128; s_ > 0; s_ >>= 1) {
+            if ((int)threadIdx.x < s_) cnt_red[threadIdx.x] += cnt_red[threadIdx.x + s_];
+            __syncthreads();
+        }
+        Rf = fmaxf(cnt_red[0], 1.0f);
+        if (total_out && blockIdx.x == 0 && threadIdx.x == 0) total_out[0] = Rf;
+    }
+    auto rows_of = [&](int b) { return counts ? counts[b] : (float)(min(R, (b + 1) * chunk) - b * chunk); };
     auto p0 = [&](int b) { return b < nblk ? partial[((size_t)b * 2 + 0) * N + c] : 0.0f; };
     auto p1 = [&](int b) { return b < nblk ? partial[((size_t)b * 2 + 1) * N + c] : 0.0f; };
     float s1 = 0.0f, s2 = 0.0f;
@@ -202,7 +239,7 @@ colsum2_reduce_kernel(const float *__restrict__ partial, int nblk, int N, int R,
         if (on && bl == 0) { out1[c] = t1; out2[c] = t2; }
         return;
     }
-    const float mean_tot = t1 / (float)R;
+    const float mean_tot = t1 / Rf;
     float m2 = 0.0f;
     if (on)
         for (int b = bl; b < nblk; b += 4 * BL) {
@@ -223,19 +260,21 @@ colsum2_reduce_kernel(const float *__restrict__ partial, int nblk, int N, int R,
         float v = 0.0f;
         for (int k = 0; k < BL; ++k) v += red[0][k][cl];
         out1[c] = mean_tot;
-        out2[c] = 1.0f / sqrtf(v / (float)R + eps);
+        out2[c] = 1.0f / sqrtf(v / Rf + eps);
     }
 }
 
 // grouped statistics: the per-group partial IS the group's (mean, M2): mean = partial[g][0], rstd = 1 / sqrt(M2 / L + eps)
 __global__ void __launch_bounds__(256)
-group_finish_kernel(const float *__restrict__ partial, size_t G, int N, int L, float eps, float *__restrict__ mean, float *__restrict__ rstd) {
+group_finish_kernel(const float *__restrict__ partial, size_t G, int N, int L, float eps, float *__restrict__ mean, float *__restrict__ rstd,
+                    const int32_t *__restrict__ lens) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= G * N) return;
     const size_t gidx = i / N;
     const int c = (int)(i - gidx * N);
+    const int n = lens ? max(min(max(lens[gidx], 0), L), 1) : L;          // a query's own documents (an empty query: mean 0, var 0)
     mean[i] = partial[(gidx * 2 + 0) * N + c];
-    rstd[i] = 1.0f / sqrtf(partial[(gidx * 2 + 1) * N + c] / (float)L + eps);
+    rstd[i] = 1.0f / sqrtf(partial[(gidx * 2 + 1) * N + c] / (float)n + eps);
 }
 
 // a_out = dropout(AF(BN(z))), W columns per thread
@@ -278,7 +317,7 @@ template <int W>
 __global__ void __launch_bounds__(256)
 bnact_bwd_kernel(const float *__restrict__ z, const float *__restrict__ da, const float *__restrict__ mean, const float *__restrict__ rstd,
                  const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ sum_dy,
-                 const float *__restrict__ sum_dyx, BnActArgs a, float *__restrict__ dz) {
+                 const float *__restrict__ sum_dyx, BnActArgs a, float *__restrict__ dz, const float *__restrict__ total_real) {
     using vec = float __attribute__((ext_vector_type(W)));
     const int NG = a.N / W;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -303,12 +342,15 @@ bnact_bwd_kernel(const float *__restrict__ z, const float *__restrict__ da, cons
         for (int e = 0; e < W; ++e) { ga[e] = 1.0f; be[e] = 0.0f; }
         if (gamma) ga = ldv(gamma + c);
         if (beta) be = ldv(beta + c);
-        const float invR = 1.0f / (float)(a.group > 0 ? a.group : a.R);
+        float cnt = (float)(a.group > 0 ? a.group : a.R);
+        if (a.lens) cnt = a.group > 0 ? (float)max(min(max(a.lens[r / a.group], 0), a.L), 1) : total_real[0];
+        const float invR = 1.0f / cnt;
+        const float real = row_is_real(a, r) ? 1.0f : 0.0f;      // a padded row takes no part in the statistics: its dz is 0
         for (int e = 0; e < W; ++e) {
             const float xh = (zv[e] - mu[e]) * rs[e];
             const float y = fmaf(ga[e], xh, be[e]);
             const float dy = dv[e] * keep[e] * af_bwd(a.af, y);
-            o[e] = (ga[e] * rs[e]) * (dy - sdy[e] * invR - xh * (sdyx[e] * invR));
+            o[e] = real * ((ga[e] * rs[e]) * (dy - sdy[e] * invR - xh * (sdyx[e] * invR)));
         }
     } else {
         for (int e = 0; e < W; ++e) o[e] = dv[e] * keep[e] * af_bwd(a.af, zv[e]);
@@ -339,35 +381,53 @@ static int check_bnact(const char *who, int R, int N, int ld, int af, float p) {
 }  // namespace ptr
 
 // group_rows: 0 = statistics over all R rows (LTRBatchNorm); L > 0 = per group of L consecutive rows (per query, LTRBatchNorm2; R % L == 0)
+// layout: [blocks][2][N] partials | [2][N] totals (backward) | [blocks] real rows per chunk | [4] total real rows (padded batches)
 extern "C" size_t ptr_bn_ws_floats(int R, int N, int group_rows) {
     const size_t blocks = group_rows > 0 ? (size_t)(R / group_rows) : (size_t)ptr::bn_blocks(R);
-    return blocks * 2 * (size_t)N;
+    return blocks * 2 * (size_t)N + 2 * (size_t)N + blocks + 4;
 }
 
+namespace ptr {
+static int check_lens(const char *who, const int32_t *lens, int rows_per_query, int R, int group_rows) {
+    if (!lens) return 0;
+    if (rows_per_query <= 0 || R % rows_per_query) { set_error("%s: lens given but R=%d is not a multiple of rows_per_query=%d", who, R, rows_per_query); return PTR_ERR_INVALID_ARG; }
+    if (group_rows > 0 && group_rows != rows_per_query) { set_error("%s: per-query statistics need group_rows == rows_per_query (%d vs %d)", who, group_rows, rows_per_query); return PTR_ERR_INVALID_ARG; }
+    return 0;
+}
+}  // namespace ptr
+
 // mean / rstd ([N], or [R / group_rows][N]) of the columns of z (biased variance, rstd = 1 / sqrt(var + eps), two-pass)
-extern "C" int ptr_bn_stats(const float *z, int ld, int R, int N, int group_rows, float eps, float *ws, float *mean, float *rstd, void *stream) {
+// lens / rows_per_query (nullable / ignored): padded query batches — only the rows (r % rows_per_query) < lens[r / rows_per_query] enter
+// the statistics (the reference never pads: data_utils.py:683-742 batches equal-length lists; a padded batch must score and train
+// like the per-length batches it replaces)
+extern "C" int ptr_bn_stats(const float *z, int ld, int R, int N, int group_rows, const int32_t *lens, int rows_per_query, float eps, float *ws,
+                            float *mean, float *rstd, void *stream) {
     using namespace ptr;
     const char *who = "ptr_bn_stats";
     if (int rc = check_bnact(who, R, N, ld, 0, 0.0f)) return rc;
     if (R == 0 || !z || !ws || !mean || !rstd) { set_error("%s: NULL pointer / empty batch", who); return PTR_ERR_INVALID_ARG; }
     if (group_rows < 0 || (group_rows > 0 && R % group_rows)) { set_error("%s: R=%d is not a multiple of group_rows=%d", who, R, group_rows); return PTR_ERR_INVALID_ARG; }
+    if (int rc = check_lens(who, lens, rows_per_query, R, group_rows)) return rc;
     hipStream_t st = as_stream(stream);
-    BnActArgs a{group_rows, R, N, ld, 0, 0, 0.0f, 0, 0, 0};
+    BnActArgs a{group_rows, R, N, ld, 0, 0, 0.0f, 0, 0, 0, lens, lens ? rows_per_query : 0};
     const bool v4 = vec4_ok(N, ld, z, ws, mean, rstd);
     const int nb = group_rows > 0 ? R / group_rows : bn_blocks(R);
-    if (v4) hipLaunchKernelGGL((colsum2_kernel<0, 4>), dim3(nb), dim3(256), 0, st, z, nullptr, nullptr, nullptr, nullptr, nullptr, a, ws);
-    else hipLaunchKernelGGL((colsum2_kernel<0, 1>), dim3(nb), dim3(256), 0, st, z, nullptr, nullptr, nullptr, nullptr, nullptr, a, ws);
+    float *counts = (lens && group_rows == 0) ? ws + (size_t)nb * 2 * N + 2 * (size_t)N : nullptr;
+    if (v4) hipLaunchKernelGGL((colsum2_kernel<0, 4>), dim3(nb), dim3(256), 0, st, z, nullptr, nullptr, nullptr, nullptr, nullptr, a, ws, counts);
+    else hipLaunchKernelGGL((colsum2_kernel<0, 1>), dim3(nb), dim3(256), 0, st, z, nullptr, nullptr, nullptr, nullptr, nullptr, a, ws, counts);
     if (group_rows > 0) {
         const unsigned fin = (unsigned)(((size_t)nb * N + 255) / 256);
-        hipLaunchKernelGGL(group_finish_kernel, dim3(fin), dim3(256), 0, st, ws, (size_t)nb, N, group_rows, eps, mean, rstd);
+        hipLaunchKernelGGL(group_finish_kernel, dim3(fin), dim3(256), 0, st, ws, (size_t)nb, N, group_rows, eps, mean, rstd, lens);
     } else {
-        hipLaunchKernelGGL(colsum2_reduce_kernel<1>, dim3((N + 7) / 8), dim3(256), 0, st, ws, nb, N, R, (R + nb - 1) / nb, eps, mean, rstd);
+        hipLaunchKernelGGL(colsum2_reduce_kernel<1>, dim3((N + 7) / 8), dim3(256), 0, st, ws, nb, N, R, (R + nb - 1) / nb, eps, mean, rstd, counts,
+                           (float *)nullptr);
     }
     return check_hip(hipGetLastError(), who);
 }
 
 // out = dropout(AF(gamma * (z - mean) * rstd + beta))   (mean == NULL: no batch norm; gamma / beta NULL: no affine)
-extern "C" int ptr_bnact_forward(const float *z, int ld, int R, int N, int group_rows, const float *mean, const float *rstd, const float *gamma,
+extern "C" int ptr_bnact_forward(const float *z, int ld, int R, int N, int group_rows, const int32_t *lens, int rows_per_query, const float *mean,
+                                 const float *rstd, const float *gamma,
                                  const float *beta, int af, float p_drop, uint64_t seed, int site, float *out, void *stream) {
     using namespace ptr;
     const char *who = "ptr_bnact_forward";
@@ -375,7 +435,8 @@ extern "C" int ptr_bnact_forward(const float *z, int ld, int R, int N, int group
     if (R == 0) return 0;
     if (!z || !out || (mean && !rstd)) { set_error("%s: NULL pointer", who); return PTR_ERR_INVALID_ARG; }
     if (group_rows < 0 || (group_rows > 0 && R % group_rows)) { set_error("%s: R=%d is not a multiple of group_rows=%d", who, R, group_rows); return PTR_ERR_INVALID_ARG; }
-    BnActArgs a{mean ? group_rows : 0, R, N, ld, af, mean ? 1 : 0, p_drop, (uint32_t)seed, (uint32_t)(seed >> 32), site};
+    (void)lens; (void)rows_per_query;      // padded rows are normalised like the others (finite, never read back into a statistic or a gradient)
+    BnActArgs a{mean ? group_rows : 0, R, N, ld, af, mean ? 1 : 0, p_drop, (uint32_t)seed, (uint32_t)(seed >> 32), site, nullptr, 0};
     if (vec4_ok(N, ld, z, out, mean, rstd, gamma, beta)) {
         const size_t n = (size_t)R * (N / 4);
         hipLaunchKernelGGL(bnact_fwd_kernel<4>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), z, mean, rstd, gamma, beta, a, out);
@@ -388,8 +449,8 @@ extern "C" int ptr_bnact_forward(const float *z, int ld, int R, int N, int group
 
 // da -> dz (and, with batch norm, dgamma[N] = sum dy * xhat, dbeta[N] = sum dy over ALL rows; either may be NULL).
 // ws: ptr_bn_ws_floats(R, N, group_rows) + 2 * N floats.
-extern "C" int ptr_bnact_backward(const float *z, const float *da, int ld, int R, int N, int group_rows, const float *mean, const float *rstd,
-                                  const float *gamma, const float *beta, int af, float p_drop, uint64_t seed, int site, float *ws,
+extern "C" int ptr_bnact_backward(const float *z, const float *da, int ld, int R, int N, int group_rows, const int32_t *lens, int rows_per_query,
+                                  const float *mean, const float *rstd, const float *gamma, const float *beta, int af, float p_drop, uint64_t seed, int site, float *ws,
                                   float *dz, float *dgamma, float *dbeta, void *stream) {
     using namespace ptr;
     const char *who = "ptr_bnact_backward";
@@ -397,27 +458,34 @@ extern "C" int ptr_bnact_backward(const float *z, const float *da, int ld, int R
     if (R == 0) return 0;
     if (!z || !da || !dz || (mean && (!rstd || !ws))) { set_error("%s: NULL pointer", who); return PTR_ERR_INVALID_ARG; }
     if (group_rows < 0 || (group_rows > 0 && R % group_rows)) { set_error("%s: R=%d is not a multiple of group_rows=%d", who, R, group_rows); return PTR_ERR_INVALID_ARG; }
+    if (!mean) lens = nullptr;             // without batch norm a padded row's dz only depends on its own da (0 from the loss kernels)
+    if (int rc = check_lens(who, lens, rows_per_query, R, mean ? group_rows : 0)) return rc;
     hipStream_t st = as_stream(stream);
-    BnActArgs a{mean ? group_rows : 0, R, N, ld, af, mean ? 1 : 0, p_drop, (uint32_t)seed, (uint32_t)(seed >> 32), site};
+    BnActArgs a{mean ? group_rows : 0, R, N, ld, af, mean ? 1 : 0, p_drop, (uint32_t)seed, (uint32_t)(seed >> 32), site, lens, lens ? rows_per_query : 0};
     const float *sum_dy = nullptr, *sum_dyx = nullptr;
     const bool v4 = vec4_ok(N, ld, z, da, dz, ws, mean, rstd, gamma, beta, dgamma, dbeta);
+    float *total_real = nullptr;
     if (mean) {
         const int nb = a.group > 0 ? R / a.group : bn_blocks(R);
         // totals over all rows: straight into dbeta / dgamma when the caller wants them
         float *tot_dy = dbeta ? dbeta : ws + (size_t)nb * 2 * N, *tot_dyx = dgamma ? dgamma : ws + (size_t)nb * 2 * N + N;
-        if (v4) hipLaunchKernelGGL((colsum2_kernel<1, 4>), dim3(nb), dim3(256), 0, st, z, da, mean, rstd, gamma, beta, a, ws);
-        else hipLaunchKernelGGL((colsum2_kernel<1, 1>), dim3(nb), dim3(256), 0, st, z, da, mean, rstd, gamma, beta, a, ws);
+        float *counts = (lens && a.group == 0) ? ws + (size_t)nb * 2 * N + 2 * (size_t)N : nullptr;
+        total_real = counts ? counts + nb : nullptr;
+        if (v4) hipLaunchKernelGGL((colsum2_kernel<1, 4>), dim3(nb), dim3(256), 0, st, z, da, mean, rstd, gamma, beta, a, ws, counts);
+        else hipLaunchKernelGGL((colsum2_kernel<1, 1>), dim3(nb), dim3(256), 0, st, z, da, mean, rstd, gamma, beta, a, ws, counts);
         if (a.group == 0 || dbeta || dgamma)
-            hipLaunchKernelGGL(colsum2_reduce_kernel<0>, dim3((N + 7) / 8), dim3(256), 0, st, ws, nb, N, R, 0, 0.0f, tot_dy, tot_dyx);
+            hipLaunchKernelGGL(colsum2_reduce_kernel<0>, dim3((N + 7) / 8), dim3(256), 0, st, ws, nb, N, R, 0, 0.0f, tot_dy, tot_dyx, counts, total_real);
         sum_dy = a.group > 0 ? ws : tot_dy;                 // grouped: the per-group partials themselves
         sum_dyx = a.group > 0 ? ws + N : tot_dyx;
     }
     if (v4) {
         const size_t n = (size_t)R * (N / 4);
-        hipLaunchKernelGGL(bnact_bwd_kernel<4>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, z, da, mean, rstd, gamma, beta, sum_dy, sum_dyx, a, dz);
+        hipLaunchKernelGGL(bnact_bwd_kernel<4>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, z, da, mean, rstd, gamma, beta, sum_dy, sum_dyx, a, dz,
+                           total_real);
     } else {
         const size_t n = (size_t)R * N;
-        hipLaunchKernelGGL(bnact_bwd_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, z, da, mean, rstd, gamma, beta, sum_dy, sum_dyx, a, dz);
+        hipLaunchKernelGGL(bnact_bwd_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, z, da, mean, rstd, gamma, beta, sum_dy, sum_dyx, a, dz,
+                           total_real);
     }
     return check_hip(hipGetLastError(), who);
 }

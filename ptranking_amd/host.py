@@ -65,10 +65,13 @@ class DeviceEvaluator:
             if min_len is not None and lens is None and batch_std_labels.size(1) < min_len:
                 continue  # skip if the number of documents is smaller than k (ranker.py:41-42)
             lens_d = None if lens is None else self._to_dev(lens).to(torch.int32)
-            _reject_padding_with_batchnorm(self, lens_d)
             self._batch_lens = lens_d
-            batch_preds = self.predict(self._to_dev(batch_q_doc_vectors))
-            self._batch_lens = None
+            Xd = self._to_dev(batch_q_doc_vectors)
+            try:
+                with scorer_lens(self, lens_d, Xd):
+                    batch_preds = self.predict(Xd)
+            finally:
+                self._batch_lens = None
             out = F_.metrics_at_ks(batch_preds.detach(), self._to_dev(batch_std_labels).float(), ks, presort=presort,
                                    max_label=max_label, which=which, lens=lens_d, permutation_labels=permutation_labels)
             if sums is None:
@@ -159,25 +162,72 @@ class DeviceEvaluator:
         return avg["ndcg"], avg["nerr"], avg["ap"], avg["p"]
 
 
-def _reject_padding_with_batchnorm(ranker, lens):
-    """Padded batches (`lens` given) and batch normalisation do not mix: zero-padded rows would enter the 'BN' (batch x docs) and
-    'BN2' (per-query) statistics and change the scores of real documents — the reference never pads (data_utils.py:683-742
-    batches equal-length lists only).  Fails loudly instead of silently training on different statistics."""
-    if lens is None:
-        return
-    has_bn = getattr(ranker, "_scorer_has_bn", None)
-    if has_bn is None:
-        mods = []
-        for name in ("point_sf", "list_sf"):
-            sf = getattr(ranker, name, None)
-            if isinstance(sf, nn.Module):
-                mods += list(sf.modules())
-        has_bn = any(type(m).__name__ in ("_BatchNormOverDocs", "_BatchNormPerQuery", "LTRBatchNorm", "LTRBatchNorm2", "BatchNorm1d")
-                     for m in mods)
-        ranker._scorer_has_bn = has_bn
-    if has_bn:
-        raise NotImplementedError("padded query batches (lens) cannot be scored by a scoring function with batch normalisation: the "
-                                  "padded rows would enter the BN statistics; batch equal-length lists or build the scorer with BN=False")
+_BN_NAMES = ("_BatchNormOverDocs", "_BatchNormPerQuery", "LTRBatchNorm", "LTRBatchNorm2", "BatchNorm1d")
+
+
+def _scorer_modules(ranker):
+    mods = []
+    for name in ("point_sf", "list_sf"):
+        sf = getattr(ranker, name, None)
+        if isinstance(sf, nn.Module):
+            mods.append(sf)
+        elif isinstance(sf, dict):                          # listsf: {"head_ffnns": ..., "encoder": ..., "tail_ffnns": ...}
+            mods += [m for m in sf.values() if isinstance(m, nn.Module)]
+    return mods
+
+
+class scorer_lens:
+    """Context around a scorer forward on a PADDED query batch (`lens` given).  Zero-padded rows must not enter batch-norm statistics —
+    the reference never pads (data_utils.py:683-742 batches equal-length lists only), and BN=True is its DEFAULT scorer
+    (eval/parameter.py:145-146).  The fused stacks (linear.FusedStack on the GPU) take `batch_lens` and keep padded rows out of the 'BN'
+    (batch x docs) and 'BN2' (per-query) statistics and their backward (csrc/bnact.hip), so a padded batch scores and trains like the
+    unpadded lists.  A batch-norm scorer that is NOT on that path (CPU tensors, module-by-module fallbacks) fails loudly instead of
+    silently training on different statistics."""
+
+    def __init__(self, ranker, lens, X=None):
+        self.ranker, self.lens, self.X, self.stacks = ranker, lens, X, []
+
+    def __enter__(self):
+        if self.lens is None:
+            return self
+        from .linear import FusedStack
+
+        def walk(m):
+            if isinstance(m, FusedStack):
+                has_bn = any(type(c).__name__ in _BN_NAMES for c in m.children())
+                probe = self.X if (self.X is not None and self.X.dim() == 3) else None
+                if probe is None:       # only the device and the rank matter for stacks that do not see the raw features
+                    probe = torch.zeros((1, 1, 4), device=self.lens.device)
+                if has_bn and not m.handles_padding(probe):
+                    self._refuse()
+                m.batch_lens = self.lens
+                self.stacks.append(m)
+            elif type(m).__name__ in _BN_NAMES:
+                self._refuse()
+            else:
+                for c in m.children():
+                    walk(c)
+
+        for top in _scorer_modules(self.ranker):
+            walk(top)
+        return self
+
+    @staticmethod
+    def _refuse():
+        raise NotImplementedError("padded query batches (lens) cannot be scored by a scoring function with batch normalisation on this "
+                                  "path (CPU tensors / unfused modules): the padded rows would enter the BN statistics; score on the GPU, "
+                                  "batch equal-length lists or build the scorer with BN=False")
+
+    def __exit__(self, *exc):
+        for m in self.stacks:
+            m.batch_lens = None
+        return False
+
+
+def _reject_padding_with_batchnorm(ranker, lens, X=None):
+    """Raises when a padded batch would reach batch-norm statistics unmasked (see scorer_lens)."""
+    with scorer_lens(ranker, lens, X):
+        pass
 
 
 # ------------------------------------------------------------------------------------------------ training loop
@@ -213,10 +263,12 @@ class DeviceTrainLoop:
             if out is not None:
                 return out
         stop_training = False
-        self._batch_lens = kwargs.get('lens')          # padded batches: the listwise scorer masks padded documents as keys
-        _reject_padding_with_batchnorm(self, self._batch_lens)
-        batch_preds = self.forward(batch_q_doc_vectors)
-        self._batch_lens = None
+        self._batch_lens = kwargs.get('lens')          # padded batches: the listwise scorer masks padded documents as keys,
+        try:                                           # batch norm keeps padded rows out of its statistics (scorer_lens)
+            with scorer_lens(self, self._batch_lens, batch_q_doc_vectors):
+                batch_preds = self.forward(batch_q_doc_vectors)
+        finally:
+            self._batch_lens = None
         if 'epoch_k' in kwargs and kwargs['epoch_k'] % self.stop_check_freq == 0:
             stop_training = self.stop_training(batch_preds)
         return self.custom_loss_function(batch_preds, batch_std_labels, **kwargs), stop_training

@@ -177,7 +177,8 @@ def _af_code(m):
     return code
 
 
-def _bn_stats(z, group=0):
+def _bn_stats(z, group=0, lens=None, L=0):
+    """lens / L: padded query batches — int32 [B] real lengths and the padded list length; only real rows enter the statistics."""
     R, N = z.shape
     dev = z.device
     G = R // group if group else 1
@@ -185,34 +186,36 @@ def _bn_stats(z, group=0):
     mean = torch.empty(G * N, device=dev, dtype=torch.float32)
     rstd = torch.empty(G * N, device=dev, dtype=torch.float32)
     with torch.cuda.device(dev):
-        _lib.call("ptr_bn_stats", _lib.ptr(z), N, R, N, group, C.c_float(BN_EPS), _lib.ptr(ws), _lib.ptr(mean), _lib.ptr(rstd), _lib.current_stream(dev))
+        _lib.call("ptr_bn_stats", _lib.ptr(z), N, R, N, group, _lib.ptr(lens), L, C.c_float(BN_EPS), _lib.ptr(ws), _lib.ptr(mean), _lib.ptr(rstd),
+                  _lib.current_stream(dev))
     return mean, rstd
 
 
-def _bnact_fwd(z, group, mean, rstd, gamma, beta, af, p, seed, site):
+def _bnact_fwd(z, group, mean, rstd, gamma, beta, af, p, seed, site, lens=None, L=0):
     R, N = z.shape
     out = torch.empty_like(z)
     with torch.cuda.device(z.device):
-        _lib.call("ptr_bnact_forward", _lib.ptr(z), N, R, N, group, _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(beta), af, C.c_float(p),
-                  C.c_uint64(seed), site, _lib.ptr(out), _lib.current_stream(z.device))
+        _lib.call("ptr_bnact_forward", _lib.ptr(z), N, R, N, group, _lib.ptr(lens), L, _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(beta),
+                  af, C.c_float(p), C.c_uint64(seed), site, _lib.ptr(out), _lib.current_stream(z.device))
     return out
 
 
-def _bnact_bwd(z, da, group, mean, rstd, gamma, beta, af, p, seed, site, dg_out=None, db_out=None):
+def _bnact_bwd(z, da, group, mean, rstd, gamma, beta, af, p, seed, site, dg_out=None, db_out=None, lens=None, L=0):
     R, N = z.shape
     dev = z.device
     has_bn = mean is not None
-    ws = torch.empty(_lib.query("ptr_bn_ws_floats", R, N, group) + 2 * N, device=dev, dtype=torch.float32) if has_bn else None
+    ws = torch.empty(_lib.query("ptr_bn_ws_floats", R, N, group), device=dev, dtype=torch.float32) if has_bn else None
     dz = torch.empty_like(z)
     dg = (dg_out if dg_out is not None else torch.empty(N, device=dev, dtype=torch.float32)) if (has_bn and gamma is not None) else None
     db = (db_out if db_out is not None else torch.empty(N, device=dev, dtype=torch.float32)) if (has_bn and beta is not None) else None
     with torch.cuda.device(dev):
-        _lib.call("ptr_bnact_backward", _lib.ptr(z), _lib.ptr(da), N, R, N, group, _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(beta), af,
-                  C.c_float(p), C.c_uint64(seed), site, _lib.ptr(ws), _lib.ptr(dz), _lib.ptr(dg), _lib.ptr(db), _lib.current_stream(dev))
+        _lib.call("ptr_bnact_backward", _lib.ptr(z), _lib.ptr(da), N, R, N, group, _lib.ptr(lens), L, _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma),
+                  _lib.ptr(beta), af, C.c_float(p), C.c_uint64(seed), site, _lib.ptr(ws), _lib.ptr(dz), _lib.ptr(dg), _lib.ptr(db),
+                  _lib.current_stream(dev))
     return dz, dg, db
 
 
-def _stack_forward(x, p, seed, spec, params, fixed_stats=None, sink=None):
+def _stack_forward(x, p, seed, spec, params, fixed_stats=None, sink=None, lens=None, L=0):
     """Forward of the general stack.  spec = (n_linear, hidden af codes, tail af or 0, has_bn, group): group = 0 — statistics over the
     whole batch ('BN'), L — per query ('BN2').  fixed_stats: per-layer (mean, rstd) to use instead of the batch statistics (BN2 under
     torch.no_grad(): its moving statistics).  sink: list receiving (layer, mean, rstd) of the statistics computed here."""
@@ -248,11 +251,11 @@ def _stack_forward(x, p, seed, spec, params, fixed_stats=None, sink=None):
         elif fixed_stats is not None:
             (mean, rstd), gi = fixed_stats[i], 0
         else:
-            mean, rstd = _bn_stats(z, group)
+            mean, rstd = _bn_stats(z, group, lens, L)
             if sink is not None:
                 sink.append((i, mean, rstd))
         pd = p if (hidden and i < n - 2) else 0.0          # the dropout in front of the NEXT hidden Linear
-        a = _bnact_fwd(z, gi, mean, rstd, gamma, beta, af, pd, seed, i + 1)
+        a = _bnact_fwd(z, gi, mean, rstd, gamma, beta, af, pd, seed, i + 1, lens, L)
         zs.append(z); stats.append((mean, rstd))
         if hidden:
             ins.append(a)
@@ -267,11 +270,13 @@ class _StackFn(torch.autograd.Function):
     and the layer inputs are kept for backward."""
 
     @staticmethod
-    def forward(ctx, x, p, seed, spec, sink, gsinks, *params):
-        out, ins, zs, stats, lda = _stack_forward(x, p, seed, spec, params, sink=sink)
+    def forward(ctx, x, p, seed, spec, sink, gsinks, lens, *params):
+        L = x.shape[-2] if (lens is not None and x.dim() == 3) else 0
+        out, ins, zs, stats, lda = _stack_forward(x, p, seed, spec, params, sink=sink, lens=lens, L=L)
         flat_stats = [t for ms in stats for t in ms]
         ctx.save_for_backward(*ins, *zs, *flat_stats, *params)
         ctx.meta = (spec[0], p, seed, spec, lda)
+        ctx.lens, ctx.L = lens, L
         ctx.gsinks = gsinks            # per parameter: the tensor its gradient is WRITTEN into (flattened stack), or None
         return out.view(*x.shape[:-1], out.shape[1])
 
@@ -297,7 +302,7 @@ class _StackFn(torch.autograd.Function):
             if hidden or af != 0:
                 pd = p if (hidden and i < n - 2) else 0.0
                 d, dg, dbt = _bnact_bwd(zs[i], d, group, fs[2 * i], fs[2 * i + 1], gamma, beta, af, pd, seed, i + 1,
-                                        gs[per * i + 2] if has_bn else None, gs[per * i + 3] if has_bn else None)
+                                        gs[per * i + 2] if has_bn else None, gs[per * i + 3] if has_bn else None, ctx.lens, ctx.L)
                 if has_bn:
                     grads[per * i + 2], grads[per * i + 3] = ret(dg, per * i + 2), ret(dbt, per * i + 3)
             a_in = ins[i]
@@ -313,8 +318,8 @@ class _StackFn(torch.autograd.Function):
                         _lib.call("ptr_dropout_apply", _lib.ptr(dx), dx.shape[1], dx.shape[0], dx.shape[1], C.c_float(p), C.c_uint64(seed), 0,
                                   _lib.ptr(dxd), dx.shape[1], _lib.current_stream(dev))
                     dx = dxd
-                return (dx.view(*dout.shape[:-1], W.shape[1]), None, None, None, None, None, *grads)
-        return (None, None, None, None, None, None, *grads)
+                return (dx.view(*dout.shape[:-1], W.shape[1]), None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, *grads)
 
 
 class FusedStack(nn.Sequential):
@@ -330,6 +335,24 @@ class FusedStack(nn.Sequential):
     _plan = None
     _flat = None             # (flat parameter buffer, flat gradient buffer) once flatten_parameters() has re-homed the parameters
     _grads_fresh = False     # set by the owning optimiser's zero_grad(): the next backward may WRITE the gradients (no accumulation)
+    batch_lens = None        # padded query batch: int32 [B] real list lengths, set by the ranker around forward (host.scorer_lens)
+
+    def handles_padding(self, x):
+        """True when a padded batch (batch_lens) is scored exactly like the unpadded lists on this input: the fused GPU path masks the
+        padded rows out of the batch-norm statistics; the module-by-module fallbacks (CPU tensors, unrecognised structures) do not."""
+        if not x.is_cuda:
+            return False
+        if self._plan is None:
+            self._plan = self._make_plan() or False
+        plan = self._plan
+        if plan is False:
+            return False
+        if plan["kind"] is None:
+            return True                                   # no batch norm: rows are independent
+        if x.dim() != 3:
+            return False
+        p = plan["p"] if self.training else 0.0
+        return not (p > 0.0 and len(plan["lins"]) > 1 and x.shape[-1] % 4)
 
     def flatten_parameters(self):
         """Re-home every parameter in ONE flat fp32 buffer and its gradient in one flat gradient buffer (parameters and `.grad`s
@@ -486,7 +509,10 @@ class FusedStack(nn.Sequential):
             out = _stack_forward(x, float(p), seed, spec, [t.detach() if t is not None else None for t in params], fixed_stats=fixed)[0]
             return out.view(*x.shape[:-1], out.shape[1])
         sink = [] if kind == "bn2" else None
-        out = _StackFn.apply(x, float(p), seed, spec, sink, self._claim_sinks(params), *params)
+        lens = self.batch_lens if (has_bn and x.dim() == 3) else None       # padded batch: real rows only in the statistics
+        if lens is not None and not (lens.is_cuda and lens.dtype == torch.int32 and lens.is_contiguous() and lens.shape == (x.shape[0],)):
+            raise ValueError("batch_lens must be a contiguous CUDA int32 tensor [B]")
+        out = _StackFn.apply(x, float(p), seed, spec, sink, self._claim_sinks(params), lens, *params)
         if sink:                                   # moving statistics, averaged over the queries of the batch (utils.py:242-245)
             with torch.no_grad():
                 for i, mean, rstd in sink:
