@@ -12,7 +12,7 @@ Rank 0 prints ONE JSON line (contract in the task statement).  `value` is measur
 queries per GPU (1024 is the survey's headline batch) measured the same way with fewer steps.  Extra objects:
   roofline      the dominant kernel of the step by time (the fused single-pass scorer backward, fp32 MFMA): algorithmic flops per
                 launch / its average launch duration measured with HIP events on the launch stream during the timed region (every 4th step), vs
-                the 157.3 TFLOP/s fp32 MFMA peak; `traffic` = PMC HBM bytes (profiles/r02_pmc_traffic.json), `algorithmic_bytes_*`
+                the 157.3 TFLOP/s fp32 MFMA peak; `traffic` = PMC HBM bytes (profiles/r03_pmc_traffic.json, trusted only when its kernel-source hash matches the built sources), `algorithmic_bytes_*`
                 = SURVEY 8(d)'s definition (features + scores), `design_bytes_*` = what the design additionally moves (stored
                 activations, partial gradients)
   kernels       the other kernels of the step: scorer forward (MFMA roofline), the north-star LambdaRank loss kernel against the
@@ -53,6 +53,12 @@ RING_INSTR_PER_PAIR = {1: 25.0, 2: 16.75, 4: 15.5625}
 RING_TRANS_PER_PAIR = 3.0
 VALU_CYCLES_PER_INSTR = 4.0
 TRANS_CYCLES_PER_INSTR = 8.0
+# MINIMAL op count of one LambdaRank pair, independent of our ISA: 3 transcendentals (exp2, rcp, log2) + 16 FMA-class
+# scalar ops — ds, |ds|*c, 1+e, dG, dD, dG*dD, target select (sub, bfi, sub, add), max(log, clamp), loss fma, gradient factor (fract, bfi),
+# two gradient fmas — of which all 16 pack two pairs per v_pk_* instruction: 8 packed + 3 transcendental issue slots per pair.  (Our
+# kernel spends 2 more on a Newton step that reproduces the reference's correctly rounded 1/(1+e), and op_sel / mask overheads.)
+RING_MIN_FMA_OPS_PER_PAIR = 16.0
+RING_MIN_ISSUE_CYCLES_PER_PAIR = RING_MIN_FMA_OPS_PER_PAIR / 2.0 * VALU_CYCLES_PER_INSTR + RING_TRANS_PER_PAIR * TRANS_CYCLES_PER_INSTR   # 56
 
 
 def synth_batch(gen, B, L, F, device):
@@ -131,15 +137,57 @@ def cpu_baseline(L, F, budget_s):
             "thread_sweep": sweep, "by_batch": by_batch, "loss_only_queries_per_s": lq}
 
 
+PMC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
+
+
+def kernel_source_hash():
+    """sha256 over the HIP sources + headers the .so is built from (ptranking_amd/build.py SOURCES / HEADERS): identifies the kernels a
+    PMC traffic file was collected on."""
+    import hashlib
+    from ptranking_amd import build as _b
+    h = hashlib.sha256()
+    for name in sorted(_b.SOURCES) + sorted(_b.HEADERS):
+        with open(os.path.join(_b.CSRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def ring_pair_statistics(Y):
+    """What the ring kernel skips on a label batch [B, L] (L <= 256, sorted descending): slot k = documents 64k..64k+63; the trailing Z
+    slots whose documents all carry one label are mutually weight-free, so Z^2 of the S^2 (own slot, travelling slot) blocks are not
+    evaluated.  Also the share of pairs whose weight is exactly 0 (equal labels, metric_utils.py:43)."""
+    B, L = Y.shape
+    S = (L + 63) // 64
+    Yp = torch.nn.functional.pad(Y, (0, S * 64 - L), value=float("nan")).view(B, S, 64)
+    real = ~torch.isnan(Yp)
+    hi = torch.where(real, Yp, torch.full_like(Yp, -1e9)).max(dim=2)[0]
+    lo = torch.where(real, Yp, torch.full_like(Yp, 1e9)).min(dim=2)[0]
+    pure = hi == lo
+    z = torch.zeros(B, device=Y.device)
+    run = torch.ones(B, dtype=torch.bool, device=Y.device)
+    last = hi[:, -1]
+    for k in range(S - 1, -1, -1):
+        run = run & pure[:, k] & (hi[:, k] == last)
+        z += run.float()
+    eq = (Y[:, :, None] == Y[:, None, :]).float().sum(dim=(1, 2)) - L          # ordered pairs i != j with equal labels
+    return {"slots": S, "mean_trailing_pure_slots": float(z.mean()), "blocks_skipped_frac": float((z * z).mean()) / (S * S),
+            "zero_weight_pairs_frac": float(eq.mean()) / (L * (L - 1))}
+
+
 def load_pmc(B, L, F):
+    """HBM bytes per launch from the committed rocprofv3 PMC collection (profiles/pmc_traffic.py).  PMC passes cannot run inside the timed
+    process, so the file is only trusted when it was collected on EXACTLY these kernels (source hash) at this shape; otherwise `traffic`
+    is null rather than a stale number."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
             j = json.load(f)
-        if j["config"] == {"queries_per_gpu_per_step": B, "list_len": L, "features": F}:
-            return {k: v["hbm_bytes_per_launch"] for k, v in j["kernels"].items()}
-    except (OSError, KeyError, ValueError):
-        pass
-    return {}
+        if j["config"] != {"queries_per_gpu_per_step": B, "list_len": L, "features": F}:
+            return {}, "shape mismatch"
+        if j.get("kernel_source_hash") != kernel_source_hash():
+            return {}, f"stale: {PMC_FILE} was collected on sources {j.get('kernel_source_hash')}, built {kernel_source_hash()}"
+        return {k: v["hbm_bytes_per_launch"] for k, v in j["kernels"].items()}, f"{PMC_FILE} (source hash {j['kernel_source_hash']})"
+    except (OSError, KeyError, ValueError) as e:
+        return {}, f"unavailable: {type(e).__name__}"
 
 
 def main():
@@ -154,6 +202,7 @@ def main():
     ap.add_argument("--list-len", type=int, default=128)
     ap.add_argument("--features", type=int, default=136)
     ap.add_argument("--nbatches", type=int, default=4, help="distinct HBM-resident batches cycled through (> L3 capacity)")
+    ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps: the first is the contract's, all are reported")
     ap.add_argument("--cpu-seconds", type=float, default=14.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--loss", default="LambdaRank", choices=["RankNet", "LambdaRank", "LambdaLoss", "ApproxNDCG", "ListNet", "ListMLE"],
@@ -259,6 +308,12 @@ def main():
 
     ranker = build_ranker()
     elapsed, timing, ar_timing, final_loss = measure(ranker, B, args.steps, args.warmup, 5)
+    # The contract's window is the one above (`steps`, `ms_per_step`, `value`).  It is tens of ms long, so its spread is reported too:
+    # args.windows - 1 further windows of the same K steps, each bracketed the same way
+    window_ms = [1e3 * elapsed / args.steps]
+    for _ in range(max(0, args.windows - 1)):
+        el, _, _, _ = measure(ranker, B, args.steps, 1, 0)
+        window_ms.append(1e3 * el / args.steps)
 
     by_batch = {}
     if args.sweep and world == 1 and args.scorer == "pointsf":
@@ -274,7 +329,7 @@ def main():
     # the loss kernel alone, at the headline list length and at the north-star's stated one (BASELINE.json: list_len=256), same
     # number of queries: 40 launches of the C entry back to back (no loss_out: the kernel only, no slot sum) inside ONE HIP-event
     # pair on the launch stream — the per-call event bracket of the timed step also holds the slot-sum kernel and two event gaps
-    ring_alone = {}
+    ring_alone, ring_stats = {}, {}
     if rank == 0 and args.loss == "LambdaRank" and args.scorer == "pointsf":
         import ctypes as C
         gen = torch.Generator(device=device).manual_seed(SEED + 7)
@@ -283,6 +338,7 @@ def main():
                 continue
             pk = torch.randn((B, Lk), generator=gen, device=device)
             _, Yk = synth_batch(gen, B, Lk, 1, device)
+            ring_stats[Lk] = ring_pair_statistics(Yk)
             lq = torch.empty(B, device=device); gk = torch.empty_like(pk)
             st = _lib.current_stream(device)
             def go():
@@ -299,6 +355,22 @@ def main():
             ring_alone[Lk] = e0.elapsed_time(e1) / 40
     l256 = ring_alone.get(256)
 
+    # facts of the parallel run, gathered from every rank: backend, device, and that one all-reduce per step ran on all of them
+    facts = {"rank": rank, "device": torch.cuda.get_device_name(local), "device_index": local,
+             "allreduce_calls": len(ar_timing), "dropout_seed_row_offset": rank * B * L}
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, facts)
+        backend = dist.get_backend()
+    else:
+        gathered, backend = [facts], None
+    parallel_facts = {"world_size": world, "backend": backend, "rccl": backend == "nccl", "ranks": gathered,
+                      "rccl_ranks": world if backend == "nccl" else 0}
+    if world > 1:
+        assert len({g["allreduce_calls"] for g in gathered}) == 1 and gathered[0]["allreduce_calls"] > 0, gathered
+        if backend == "nccl":
+            assert len({g["device_index"] for g in gathered}) == world, f"RCCL ranks must own distinct GPUs: {gathered}"
+            assert parallel_facts["rccl_ranks"] == world
     if rank == 0:
         def avg_ms(name):
             ev = timing.get(name, [])
@@ -314,7 +386,7 @@ def main():
                       "ApproxNDCG": "ptr_approxndcg_fwd_bwd", "ListNet": "ptr_listnet_fwd_bwd", "ListMLE": "ptr_listmle_fwd_bwd"}[args.loss]
         t_fwd, t_loss, t_bwd, t_adam, t_sum = (avg_ms(n) for n in ("ptr_mlp_forward", loss_entry, "ptr_mlp_backward", "ptr_adam_step",
                                                                     "ptr_sum_f32"))
-        pmc = load_pmc(B, L, F)
+        pmc, pmc_source = load_pmc(B, L, F)
 
         def pmc_bytes(prefix):
             for k, v in pmc.items():
@@ -327,20 +399,31 @@ def main():
             pairs = B * (Lk * (Lk - 1) // 2)
             gbps = bytes_ / (t_ms * 1e-3) / 1e9
             dpt = 1 if Lk <= 64 else 2 if Lk <= 128 else 4
-            cyc = (RING_INSTR_PER_PAIR[dpt] - RING_TRANS_PER_PAIR) * VALU_CYCLES_PER_INSTR + RING_TRANS_PER_PAIR * TRANS_CYCLES_PER_INSTR
-            bound = NUM_SIMD * PEAK_CLOCK_HZ * 64.0 / cyc
-            return {"kernel": f"lambdarank_ring_kernel<{dpt}> (fused LambdaRank dNDCG loss + gradient, one wavefront per query, register/DPP ring)",
+            st = ring_stats.get(Lk, {})
+            evaluated = pairs * (1.0 - st.get("blocks_skipped_frac", 0.0))
+            cyc_own = (RING_INSTR_PER_PAIR[dpt] - RING_TRANS_PER_PAIR) * VALU_CYCLES_PER_INSTR + RING_TRANS_PER_PAIR * TRANS_CYCLES_PER_INSTR
+            bound = NUM_SIMD * PEAK_CLOCK_HZ * 64.0 / RING_MIN_ISSUE_CYCLES_PER_PAIR
+            return {"kernel": f"lambdarank_ring_kernel<{dpt}> (fused LambdaRank dNDCG loss + gradient, one wavefront per query, register/DPP ring, "
+                              "equal-label slot blocks skipped)",
                     "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
-                    "traffic": traffic, "avg_launch_ms": t_ms, "algorithmic_bytes_per_launch": bytes_, "pairs_per_s": pairs / (t_ms * 1e-3),
-                    "valu_roofline": {"bound": "valu-issue", "achieved": pairs / (t_ms * 1e-3), "unit": "pairs/s", "peak": bound,
-                                      "frac": pairs / (t_ms * 1e-3) / bound, "instr_per_pair": RING_INSTR_PER_PAIR[dpt],
-                                      "cycles_per_wave64_valu_instr": VALU_CYCLES_PER_INSTR, "transcendentals_per_pair": RING_TRANS_PER_PAIR,
-                                      "cycles_per_transcendental": TRANS_CYCLES_PER_INSTR, "issue_cycles_per_pair": cyc,
-                                      "note": "peak = 1024 SIMDs x 2.4 GHz x 64 lanes / pair-loop issue cycles per pair (4 per VALU "
-                                              "instruction, 8 per transcendental); the shader clock sustained under this kernel is ~2.1 GHz; "
-                                              "avg_launch_ms = 40 back-to-back launches of the kernel inside one HIP-event pair / 40 (rocprofv3 kernel "
-                                              "time: profiles/r02_*kernel_stats.csv); SQ counters: profiles/r02_sq_c2.txt"},
-                    "note": "O(L^2) pair work per 12L+4 bytes: VALU-bound by construction (DESIGN.md 3.1)"}
+                    "traffic": traffic, "avg_launch_ms": t_ms, "algorithmic_bytes_per_launch": bytes_,
+                    "pairs_per_s": pairs / (t_ms * 1e-3), "evaluated_pairs_per_s": evaluated / (t_ms * 1e-3),
+                    "effective_pairs_per_s": pairs * (1.0 - st.get("zero_weight_pairs_frac", 0.0)) / (t_ms * 1e-3),
+                    "pair_statistics": st,
+                    "valu_roofline": {"bound": "valu-issue", "achieved": evaluated / (t_ms * 1e-3), "unit": "evaluated pairs/s", "peak": bound,
+                                      "frac": evaluated / (t_ms * 1e-3) / bound,
+                                      "min_fma_class_ops_per_pair": RING_MIN_FMA_OPS_PER_PAIR, "transcendentals_per_pair": RING_TRANS_PER_PAIR,
+                                      "cycles_per_wave64_valu_instr": VALU_CYCLES_PER_INSTR, "cycles_per_transcendental": TRANS_CYCLES_PER_INSTR,
+                                      "min_issue_cycles_per_pair": RING_MIN_ISSUE_CYCLES_PER_PAIR,
+                                      "kernel_issue_cycles_per_pair": cyc_own, "kernel_instr_per_pair": RING_INSTR_PER_PAIR[dpt],
+                                      "note": "peak = 1024 SIMDs x 2.4 GHz x 64 lanes / MINIMAL issue cycles per pair: 16 FMA-class ops packed two "
+                                              "pairs per instruction (8 x 4 cycles) + exp2, rcp, log2 (3 x 8 cycles) = 56 — a count of the "
+                                              "arithmetic, not of our ISA (our pair loop issues kernel_issue_cycles_per_pair); achieved counts "
+                                              "the pairs the kernel EVALUATES (equal-label blocks are skipped, pair_statistics); the shader "
+                                              "clock sustained under this kernel is ~2.1 GHz; avg_launch_ms = 40 back-to-back launches inside "
+                                              "one HIP-event pair / 40"},
+                    "note": "O(L^2) pair work per 12L+4 bytes: VALU-bound by construction (DESIGN.md 3.1); pairs_per_s counts all L(L-1)/2 "
+                            "pairs per query, effective_pairs_per_s the pairs with a non-zero weight"}
 
         kernels = {}
         if t_loss:
@@ -380,7 +463,7 @@ def main():
                         "note": "dominant kernel of the step by time; avg_launch_ms brackets the whole ptr_mlp_backward entry point (fused kernel + "
                                 "the 136 KB partial reduction); algorithmic bytes = SURVEY 8(d) (features read once more for dW1 + dLoss/dscore), "
                                 "design bytes = the stored activations read back (3 x 448 B / document) + one partial gradient per workgroup; "
-                                "traffic = PMC FETCH_SIZE(x2 on gfx950)+WRITE_SIZE from profiles/r02_pmc_traffic.json"}
+                                "traffic = PMC FETCH_SIZE(x2 on gfx950)+WRITE_SIZE from " + pmc_source}
         elif args.scorer == "listsf" and avg_ms("ptr_mhsa_forward"):
             t_af, t_ab = avg_ms("ptr_mhsa_forward"), avg_ms("ptr_mhsa_backward")
             att_flop = 4.0 * B * L * L * F                         # QK^T and PV, 2 flop per MAC, all heads (H * d_h = F)
@@ -410,6 +493,10 @@ def main():
         else:   # scorer configuration not fusable: the loss kernel is the only kernel of ours in the step
             roofline = dict(kernels.get("lambdarank_loss_grad", kernels.get("loss_grad", {})))
         qps = world * B * args.steps / elapsed
+        ws = sorted(window_ms)
+        windows = {"n": len(ws), "steps_each": args.steps, "ms_per_step": window_ms, "median_ms_per_step": float(np.median(ws)),
+                   "min_ms_per_step": ws[0], "max_ms_per_step": ws[-1], "median_queries_per_s": world * B / (float(np.median(ws)) * 1e-3),
+                   "note": "window 0 is the contract's timed region (`value`, `ms_per_step`); the others repeat it"}
         step_alg_bytes = B * (2 * 4 * L * F + 12 * L + 4)
         out = {
             "metric": ("queries/sec fwd+bwd LambdaRank, MSLR-WEB30K-shaped list_len=128" if headline
@@ -431,8 +518,14 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
             "by_batch": by_batch,
+            "windows": windows,
             "final_epoch_loss": final_loss,
+            "pmc_traffic_source": pmc_source,
+            "parallel": parallel_facts,
         }
+        if "1024" in by_batch:     # SURVEY 8(d)'s headline batch, next to `value` (measured at --batch queries per GPU)
+            out["value_at_1024"] = by_batch["1024"]["queries_per_s_per_gpu"]
+            out["ms_per_step_at_1024"] = by_batch["1024"]["ms_per_step"]
         if world == 1 and not args.no_cpu_baseline and args.scorer == "pointsf":
             out["cpu_baseline"] = cpu_baseline(L, F, args.cpu_seconds)
         print(json.dumps(out), flush=True)

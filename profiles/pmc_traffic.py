@@ -22,6 +22,14 @@ def per_kernel(path, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
+def source_hash():
+    """The hash bench.py checks before trusting this file: sha256 over the HIP sources the .so was built from."""
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    return bench.kernel_source_hash()
+
+
 def main(fetch_csv, write_csv, B, L, F, out):
     f, w = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
     kernels = {}
@@ -32,7 +40,8 @@ def main(fetch_csv, write_csv, B, L, F, out):
     doc = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (bench.py --steps 6 --warmup 2 --no-cpu-baseline, 1xMI355X). "
                    "Counter unit is KiB. On gfx950 FETCH_SIZE counts 128-B requests as 64 B, so the read side is doubled "
                    "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE is taken as is.",
-           "config": {"queries_per_gpu_per_step": int(B), "list_len": int(L), "features": int(F)}, "kernels": kernels}
+           "config": {"queries_per_gpu_per_step": int(B), "list_len": int(L), "features": int(F)},
+           "kernel_source_hash": source_hash(), "kernels": kernels}
     json.dump(doc, open(out, "w"), indent=1)
     print(f"{out}: {len(kernels)} kernels")
 
