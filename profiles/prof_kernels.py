@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Stand-alone launches of every non-headline kernel of the path, for rocprofv3 (missing item 4 / next-round item 6).
+
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --kernel-trace --stats -d OUT --output-format csv -- python profiles/prof_kernels.py run [B]
+    python profiles/prof_kernels.py summarise OUT/**/_kernel_stats.csv profiles/r03_kernels_B65536.json [B]
+    (PMC passes, each on its own:  rocprofv3 --pmc FETCH_SIZE -d OUT2 ... ;  rocprofv3 --pmc WRITE_SIZE -d OUT3 ...)
+
+`run` launches each entry point ITERS times at B queries (default 65 536; inputs far larger than the 256 MB Infinity Cache) on the MSLR label
+mix.  `summarise` joins the rocprofv3 kernel averages with the ALGORITHMIC bytes of SURVEY.md 8(d) — 12L+4 per query for the fused loss
+kernels (16L+4 for ListMLE with its int32 permutation), 8L+4*len(ks) for the metric kernel, 16L for the sort (4L in, 4L values + 8L int64
+indices out) — and prints achieved GB/s against the 8 TB/s HBM peak.
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+KS = [1, 3, 5, 10, 20, 50]
+ITERS = 6
+# (label, kernel-name substring, list length, algorithmic bytes per query)
+CASES = [
+    ("ranknet L=32", "pairwise_bce_kernel", 32, lambda L: 12 * L + 4),
+    ("lambdarank L=128", "lambdarank_ring_kernel<2>", 128, lambda L: 12 * L + 4),
+    ("lambdarank L=256", "lambdarank_ring_kernel<4>", 256, lambda L: 12 * L + 4),
+    ("listnet L=256", "listnet_kernel", 256, lambda L: 12 * L + 4),
+    ("listmle L=256", "listmle_kernel", 256, lambda L: 16 * L + 4),
+    ("lambdaloss L=256 k=5", "lambdaloss_kernel", 256, lambda L: 12 * L + 4),
+    ("approxndcg L=512", "approxndcg", 512, lambda L: 12 * L + 4),
+    ("metrics L=256", "metrics_kernel", 256, lambda L: 8 * L + 4 * len(KS) * 4),
+    ("sort_desc L=256", "sort_desc_kernel", 256, lambda L: 16 * L),
+    ("shuffle_ties L=256", "shuffle_ties", 256, lambda L: 8 * L),
+]
+
+
+def run(B):
+    import torch
+    import ptranking_amd as pa
+    F = pa.functional
+    torch.manual_seed(137)
+    probs = torch.tensor([0.5147, 0.3250, 0.1339, 0.0183, 0.0081], device="cuda")
+    data = {}
+    for L in (32, 128, 256, 512):
+        Bq = B if L <= 256 else B // 2
+        preds = torch.randn(Bq, L, device="cuda")
+        Y = torch.multinomial(probs.expand(Bq, -1), L, replacement=True).float()
+        Y[:, 0].clamp_(min=1.0)
+        Y = torch.sort(Y, dim=1, descending=True)[0].contiguous()
+        data[L] = (preds, Y)
+
+    def lg(fn, preds, *a, **k):
+        p = preds.detach().requires_grad_(True)
+        fn(p, *a, **k)          # forward launches the fused loss + gradient kernel; no backward pass needed
+
+    for it in range(ITERS + 2):
+        p, y = data[32]; lg(F.ranknet_loss, p, y, sigma=1.0)
+        p, y = data[128]; lg(F.lambdarank_loss, p, y, sigma=1.0)
+        p, y = data[256]
+        lg(F.lambdarank_loss, p, y, sigma=1.0)
+        lg(F.listnet_loss, p, y)
+        perm = F.shuffle_ties_order(y, seed=11 + it)
+        lg(F.listmle_loss, p, perm)
+        lg(F.lambdaloss_loss, p, y, k=5, sigma=1.0, mu=5.0, loss_type="NDCG_Loss2", presort=True)
+        F.metrics_at_ks(p, y, KS, presort=True)
+        F.sort_desc(p)
+        p, y = data[512]; lg(F.approxndcg_loss, p, y, alpha=10.0, presort=True)
+    torch.cuda.synchronize()
+
+
+def summarise(stats_csv, out_json, B, fetch_csv=None, write_csv=None):
+    import csv
+    rows = list(csv.DictReader(open(stats_csv)))
+    traffic = {}
+    if fetch_csv and write_csv:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import pmc_traffic
+        f, w = pmc_traffic.per_kernel(fetch_csv, "FETCH_SIZE"), pmc_traffic.per_kernel(write_csv, "WRITE_SIZE")
+        for k in set(f) | set(w):
+            traffic[k] = int(round((2.0 * f.get(k, 0.0) + w.get(k, 0.0)) * 1024))
+    out = {"note": "rocprofv3 --kernel-trace --stats averages of stand-alone launches (profiles/prof_kernels.py run), MSLR label mix, 1xMI355X; "
+                   "achieved = SURVEY 8(d) algorithmic bytes / average kernel time; peak = 8000 GB/s (HBM3E spec); traffic = PMC "
+                   "FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch when collected",
+           "queries": B, "kernels": {}}
+    for label, sub, L, bytes_per_q in CASES:
+        Bq = B if L <= 256 else B // 2
+        match = [r for r in rows if sub in r["Name"] and "ptr::" in r["Name"]]
+        if not match:
+            continue
+        r = max(match, key=lambda r: float(r["TotalDurationNs"]))
+        avg_us = float(r["AverageNs"]) / 1e3
+        bytes_ = Bq * bytes_per_q(L)
+        gbps = bytes_ / (avg_us * 1e-6) / 1e9
+        tr = next((v for k, v in traffic.items() if sub.split("<")[0] in k and (("<" not in sub) or sub in k)), None)
+        out["kernels"][label] = {"kernel": r["Name"].split("(")[0], "calls": int(r["Calls"]), "avg_us": avg_us, "queries": Bq, "list_len": L,
+                                 "algorithmic_bytes": bytes_, "achieved_GBps": gbps, "frac_of_hbm_peak": gbps / 8000.0,
+                                 "traffic_bytes": tr}
+        print(f"{label:24s} {avg_us:9.1f} us  {gbps:8.1f} GB/s  {gbps / 80:5.1f} % of HBM peak" + (f"  traffic {tr / 1e6:.1f} MB vs {bytes_ / 1e6:.1f} MB" if tr else ""))
+    json.dump(out, open(out_json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "run":
+        run(int(sys.argv[2]) if len(sys.argv) > 2 else 65536)
+    else:
+        summarise(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 65536, *(sys.argv[5:7] if len(sys.argv) > 6 else []))

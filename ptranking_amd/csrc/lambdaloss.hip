@@ -60,7 +60,7 @@ lambdaloss_kernel(const float *__restrict__ preds, const float *__restrict__ lab
         yp[m] = p < Lp ? Y_id[p] : 0.0f;
         if (p < n) part += gain_of(yp[m]) / log2f((float)p + 2.0f);     // adhoc_metric.py:205-217 on the ideal ranking
     }
-    count_ranks<G, DPT>(S_id, n, t, sp, rk);                              // lambdaloss.py:89
+    count_ranks_fast<G, DPT>(S_id, reinterpret_cast<int *>(pk), n, t, sp, rk);   // lambdaloss.py:89 (pk, filled below, is the check scratch)
     const float idcg = group_sum<G>(part, red, t);
 #pragma unroll
     for (int m = 0; m < DPT; ++m) {

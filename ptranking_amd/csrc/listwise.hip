@@ -308,7 +308,7 @@ shuffle_ties_kernel(const float *__restrict__ labels, const int32_t *__restrict_
     __syncthreads();
     int rk[DPT];
     if (fast) {
-        count_ranks<G, DPT>(keys, n, t, key, rk);
+        count_ranks_fast<G, DPT>(keys, out, n, t, key, rk);      // integer keys below 2^24: differences >= 1; field collisions recount
     } else {
 #pragma unroll
         for (int m = 0; m < DPT; ++m) {

@@ -63,7 +63,7 @@ pairwise_bce_kernel(const float *__restrict__ preds, const float *__restrict__ l
     // ---- phase B: rank positions, IDCG, per-position tile
     int rk[DPT];
     if constexpr (WEIGHTED) {
-        count_ranks<G, DPT>(keys, n, t, si, rk);
+        count_ranks_fast<G, DPT>(keys, reinterpret_cast<int *>(pk), n, t, si, rk);      // pk (filled below) is the check scratch
         float part = 0.0f;
 #pragma unroll
         for (int m = 0; m < DPT; ++m) {
@@ -218,13 +218,7 @@ pairwise_bce_kernel(const float *__restrict__ preds, const float *__restrict__ l
 //   * the loss is accumulated as sum |wsg| * max(log2(.), -100/ln2) and scaled by ln2/sigma once per query.
 // Arithmetic per pair is otherwise the reference's (see the header): p = fl(1/(1+e^-x)), q = fl(1-p), BCE's -100 clamp, and a
 // gradient that is exactly 0 once p rounds to 1.
-using f32x2 = __attribute__((ext_vector_type(2))) float;
-// v_pk_fma_f32 with the clamp modifier: {clamp(a.x*b.x+c.x, 0, 1), clamp(a.y*b.y+c.y, 0, 1)}
-__device__ __forceinline__ f32x2 pk_fma_clamp(f32x2 a, f32x2 b, f32x2 c) {
-    f32x2 d;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
+// (f32x2 / pk_fma_clamp: ptr_device.h)
 // a - b as ONE packed instruction (the compiler splits a v2f32 subtraction whose lanes are consumed separately)
 __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
     f32x2 d;

@@ -107,23 +107,32 @@ template <int G> __device__ __forceinline__ float group_max(float v, float *red,
     }
 }
 
-// Inclusive prefix scans over one wavefront (lane order).
+// Inclusive prefix scans over one wavefront (lane order) out of the VALU alone: DPP row shifts inside the 16-lane rows, then the row
+// totals carried across rows by row_bcast:15 / :31 — 6 instructions per scan (the __shfl_up form goes through the LDS crossbar six
+// times and needs a select per step).  Lanes without a source (row_shr beyond the row start, unwritten rows) take the identity.
+#define PTR_DPP_SRC(v, ident, ctrl, rows) \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(ident)), __builtin_bit_cast(int, (v)), (ctrl), (rows), 0xF, false))
 __device__ __forceinline__ float wave_incl_sum(float v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        float o = __shfl_up(v, d, 64);
-        if (lane >= d) v += o;
-    }
+    (void)lane;
+    v += PTR_DPP_SRC(v, 0.0f, 0x111, 0xF);      // row_shr:1
+    v += PTR_DPP_SRC(v, 0.0f, 0x112, 0xF);      // row_shr:2
+    v += PTR_DPP_SRC(v, 0.0f, 0x114, 0xF);      // row_shr:4
+    v += PTR_DPP_SRC(v, 0.0f, 0x118, 0xF);      // row_shr:8: every lane holds the prefix inside its row
+    v += PTR_DPP_SRC(v, 0.0f, 0x142, 0xA);      // row_bcast:15 into rows 1 and 3
+    v += PTR_DPP_SRC(v, 0.0f, 0x143, 0xC);      // row_bcast:31 into rows 2 and 3
     return v;
 }
 __device__ __forceinline__ float wave_incl_prod(float v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        float o = __shfl_up(v, d, 64);
-        if (lane >= d) v *= o;
-    }
+    (void)lane;
+    v *= PTR_DPP_SRC(v, 1.0f, 0x111, 0xF);
+    v *= PTR_DPP_SRC(v, 1.0f, 0x112, 0xF);
+    v *= PTR_DPP_SRC(v, 1.0f, 0x114, 0xF);
+    v *= PTR_DPP_SRC(v, 1.0f, 0x118, 0xF);
+    v *= PTR_DPP_SRC(v, 1.0f, 0x142, 0xA);
+    v *= PTR_DPP_SRC(v, 1.0f, 0x143, 0xC);
     return v;
 }
+#undef PTR_DPP_SRC
 // Inclusive SUFFIX sum over one wavefront (lane i gets sum of lanes i..63).
 __device__ __forceinline__ float wave_incl_suffix_sum(float v, int lane) {
 #pragma unroll
@@ -177,6 +186,74 @@ __device__ __forceinline__ void count_ranks(const float *keys, int n, int t, con
             }
         }
     }
+}
+
+// ---- packed rank counting (scores: tie-free in the common case)
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+// v_pk_fma_f32 with the clamp modifier: {clamp(a.x*b.x+c.x, 0, 1), clamp(a.y*b.y+c.y, 0, 1)}
+__device__ __forceinline__ f32x2 pk_fma_clamp(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// count_ranks() at ONE VALU slot per compare instead of four: t = clamp(BIG*k_j - BIG*k_i, 0, 1) is exactly 1 for k_j > k_i and 0 otherwise
+// (the fma is exact up to its final rounding, so the sign is right and 0 means equal; two compares per v_pk_fma_f32), summed in fp32
+// (exact up to 2^24).  BIG = 2^100: t is fractional only for 0 < k_j - k_i < 2^-100, and BIG*k overflows only for |k| >= 2^28 (inf - inf
+// = NaN clamps to 0) — then the sums are not all integers, or two documents share a rank, as they do for TIES (equal keys: rank =
+// original index order).  Both are detected (integrality + a scatter / gather permutation check through `mark`, n ints of LDS), and
+// the whole group recounts with count_ranks().  keys[] as for count_ranks (padded with -inf to a multiple of 4).  Contains group-wide
+// barriers: every thread of the group (G == 256: of the block) must call it.
+template <int G, int DPT>
+__device__ __forceinline__ void count_ranks_fast(const float *keys, int *mark, int n, int t, const float (&own)[DPT], int (&rk)[DPT]) {
+    const float big = 0x1p100f;
+    const f32x2 big2 = {big, big};
+    f32x2 nsb[DPT], cnt[DPT];
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const float v = t + m * G < n ? -own[m] * big : 0.0f;
+        nsb[m] = f32x2{v, v}; cnt[m] = f32x2{0.0f, 0.0f};
+    }
+    const float4 *k4 = reinterpret_cast<const float4 *>(keys);
+    // n is the same for every thread of the group: a scalar trip count (no exec-mask loop), 16 keys per trip with their LDS reads
+    // issued ahead of the arithmetic, two accumulator chains per document
+    const int n4 = __builtin_amdgcn_readfirstlane((n + 3) >> 2);
+    f32x2 cnt2[DPT];
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) cnt2[m] = f32x2{0.0f, 0.0f};
+    auto body = [&](const float4 v) {
+        const f32x2 u0 = {v.x, v.y}, u1 = {v.z, v.w};
+#pragma unroll
+        for (int m = 0; m < DPT; ++m) {
+            cnt[m] += pk_fma_clamp(u0, big2, nsb[m]);
+            cnt2[m] += pk_fma_clamp(u1, big2, nsb[m]);
+        }
+    };
+    int j4 = 0;
+    for (; j4 + 4 <= n4; j4 += 4) {
+        const float4 v0 = k4[j4], v1 = k4[j4 + 1], v2 = k4[j4 + 2], v3 = k4[j4 + 3];
+        body(v0); body(v1); body(v2); body(v3);
+    }
+    for (; j4 < n4; ++j4) body(k4[j4]);
+    bool redo = false;
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int i = t + m * G;
+        const float c = (cnt[m].x + cnt[m].y) + (cnt2[m].x + cnt2[m].y);
+        rk[m] = (int)c;
+        redo |= i < n && ((float)rk[m] != c || rk[m] >= n || rk[m] < 0);
+        if (i < n && rk[m] >= 0 && rk[m] < n) mark[rk[m]] = i;
+    }
+    if constexpr (G == kWave) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    else __syncthreads();
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int i = t + m * G;
+        redo |= i < n && rk[m] >= 0 && rk[m] < n && mark[rk[m]] != i;
+    }
+    bool any;
+    if constexpr (G == kWave) any = __any(redo);
+    else any = __syncthreads_or(redo);
+    if (any) count_ranks<G, DPT>(keys, n, t, own, rk);
 }
 
 // Ideal-order staging shared by LambdaLoss / ApproxNDCG / the metric kernel.
