@@ -75,6 +75,26 @@ def test_train_forward_backward_match_torch_with_same_masks(F, NL, R, monkeypatc
         close(got[name], prm.grad, tol=5e-5)
 
 
+@pytest.mark.parametrize("F,R", [(136, 2048 + 37), (8, 333), (132, 900), (24, 100), (4, 77)])
+def test_layer1_k_tail_form_matches_torch(F, R, monkeypatch):
+    """PTR_FWD_TQ=1: the first layer's contraction tail (F mod 16 = 4 or 8) in 1 / 2 MFMAs per output tile instead of a zero-padded
+    super-step (opt-in: it costs registers in the 16-wave form).  Training and eval forward against the CPU modules."""
+    monkeypatch.setenv("PTR_FWD_TQ", "1")
+    p = 0.1
+    fused, ref = make_pair(F, 3, dropout=p)
+    fused.train()
+    X = torch.randn(R, F, device="cuda")
+    seed = 55 + R
+    monkeypatch.setattr(torch, "randint", lambda *a, **k: torch.tensor([seed]))
+    out = fused(X)
+    monkeypatch.setattr(torch, "randint", torch.randint) if False else None
+    exp = _train_reference(ref, fused, X, seed, p, 3)
+    close(out, exp)
+    fused.eval(); ref.eval()
+    with torch.no_grad():
+        close(fused(X), ref(X.cpu()))
+
+
 def test_gradients_without_dropout_and_in_eval_mode():
     fused, ref = make_pair(136, 3, dropout=0.0)
     fused.train(); ref.train()
