@@ -165,6 +165,13 @@ int ptr_mlp_backward(const float *X, const float *params, const float *acts, con
 /* torch.optim.Adam step (L2 weight decay added to the gradient, bias correction with `step` >= 1) on flat buffers. */
 int ptr_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, void *stream);
+/* torch.optim.Adagrad (clr = lr / (1 + (step - 1) lr_decay); sum += g^2; p -= clr g / (sqrt(sum) + eps)) and torch.optim.RMSprop
+ * (sq = alpha sq + (1 - alpha) g^2; p -= lr g / (sqrt(sq) + eps); no momentum, not centered) on flat buffers, g = grad + weight_decay p:
+ * the 'Adagrad' / 'RMS' choices of ptranking/base/ranker.py:518-521. */
+int ptr_adagrad_step(float *param, const float *grad, float *state_sum, int64_t n, float lr, float lr_decay, float eps,
+                     float weight_decay, int step, void *stream);
+int ptr_rmsprop_step(float *param, const float *grad, float *square_avg, int64_t n, float lr, float alpha, float eps,
+                     float weight_decay, void *stream);
 /* Test helper: the dropout keep-mask (1.0 / 0.0) of dropout site `site` for an [R][n_feat] activation. */
 int ptr_mlp_dropout_mask(int R, int n_feat, int site, float p_drop, uint64_t seed, float *out, void *stream);
 

@@ -1113,6 +1113,52 @@ extern "C" int ptr_mlp_backward(const float *X, const float *params, const float
     return check_hip(hipGetLastError(), who);
 }
 
+namespace ptr {
+// torch.optim.Adagrad (lr_decay, eps; initial accumulator 0) and torch.optim.RMSprop (alpha, eps; no momentum, not centered) on flat
+// buffers — the other two optimisers the reference configures (ptranking/base/ranker.py:518-521), L2 weight decay added to the gradient
+__global__ void __launch_bounds__(256)
+adagrad_kernel(float *__restrict__ p, const float *__restrict__ grad, float *__restrict__ sum, size_t n, float clr, float eps, float wd) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float pi = p[i];
+    const float gi = grad[i] + wd * pi;
+    const float si = sum[i] + gi * gi;
+    sum[i] = si;
+    p[i] = pi - clr * (gi / (sqrtf(si) + eps));
+}
+__global__ void __launch_bounds__(256)
+rmsprop_kernel(float *__restrict__ p, const float *__restrict__ grad, float *__restrict__ sq, size_t n, float lr, float alpha, float eps, float wd) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float pi = p[i];
+    const float gi = grad[i] + wd * pi;
+    const float si = alpha * sq[i] + (1.0f - alpha) * gi * gi;
+    sq[i] = si;
+    p[i] = pi - lr * (gi / (sqrtf(si) + eps));
+}
+}  // namespace ptr
+
+extern "C" int ptr_adagrad_step(float *param, const float *grad, float *state_sum, int64_t n, float lr, float lr_decay, float eps,
+                                float weight_decay, int step, void *stream) {
+    using namespace ptr;
+    if (n < 0 || step < 1 || (n > 0 && (!param || !grad || !state_sum))) { set_error("ptr_adagrad_step: bad arguments"); return PTR_ERR_INVALID_ARG; }
+    if (n == 0) return 0;
+    const float clr = lr / (1.0f + (float)(step - 1) * lr_decay);
+    hipLaunchKernelGGL(adagrad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), param, grad, state_sum, (size_t)n, clr, eps,
+                       weight_decay);
+    return check_hip(hipGetLastError(), "ptr_adagrad_step");
+}
+
+extern "C" int ptr_rmsprop_step(float *param, const float *grad, float *square_avg, int64_t n, float lr, float alpha, float eps,
+                                float weight_decay, void *stream) {
+    using namespace ptr;
+    if (n < 0 || (n > 0 && (!param || !grad || !square_avg))) { set_error("ptr_rmsprop_step: bad arguments"); return PTR_ERR_INVALID_ARG; }
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), param, grad, square_avg, (size_t)n, lr, alpha,
+                       eps, weight_decay);
+    return check_hip(hipGetLastError(), "ptr_rmsprop_step");
+}
+
 extern "C" int ptr_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
                              float beta2, float eps, float weight_decay, int step, void *stream) {
     using namespace ptr;

@@ -357,13 +357,14 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
             // One OPAQUE base address per LDS image (lane part included): every read below is base + a small constant that fits the
             // ds_read offset field.  Without it each read address (image offset > 64 KB + constant) is a loop-invariant VGPR of its
             // own, hoisted out of the slab loop by the hundred and spilled to scratch.
-            uint32_t zb[NL], ab[NL];
+            uint32_t zb[NL], ab[NL], zb6[NL];
 #pragma unroll
             for (int l = 0; l < NL; ++l) {
                 zb[l] = lds_byte_addr(l == NL - 1 ? cur + (NL - 1) * kSlabF : Zb + l * kSlabF) + (uint32_t)((g * kAL + j) * 4);
                 ab[l] = l == 0 ? lds_byte_addr(XS) + (uint32_t)((g * LDX + j) * 4)
                                : lds_byte_addr(cur + (l - 1) * kSlabF) + (uint32_t)((g * kAL + j) * 4);
-                asm volatile("" : "+v"(zb[l]), "+v"(ab[l]));
+                zb6[l] = zb[l] - (uint32_t)((j - (j & 3)) * 4);       // out-feature tile 6 as 4x4 blocks: lane j reads feature 96 + (j & 3)
+                asm volatile("" : "+v"(zb[l]), "+v"(ab[l]), "+v"(zb6[l]));
             }
             auto rd = [&](int ks, auto set_) {
                 constexpr int set = set_;
@@ -371,7 +372,7 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
                     constexpr int t = kTM<NL, NT1>.lst[WV][PH][k_];
                     constexpr int l = kTM<NL, NT1>.tl[t], n = kTM<NL, NT1>.tn[t], m = kTM<NL, NT1>.tm[t];
                     if constexpr (kTM<NL, NT1>.first_a(WV, PH, k_))
-                        av[set][l][m] = *reinterpret_cast<lds_f *>((uintptr_t)(zb[l] + (uint32_t)((4 * ks * kAL + 16 * m) * 4)));
+                        av[set][l][m] = *reinterpret_cast<lds_f *>((uintptr_t)((m == kMT - 1 ? zb6[l] : zb[l]) + (uint32_t)((4 * ks * kAL + 16 * m) * 4)));
                     if constexpr (kTM<NL, NT1>.first_b(WV, PH, k_))
                         bv[set][l][n] = *reinterpret_cast<lds_f *>((uintptr_t)(ab[l] + (uint32_t)((4 * ks * (l == 0 ? LDX : kAL) + 16 * n) * 4)));
                 });
@@ -381,7 +382,13 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
                 static_for<CNT>([&](auto k_) {
                     constexpr int t = kTM<NL, NT1>.lst[WV][PH][k_];
                     constexpr int l = kTM<NL, NT1>.tl[t], n = kTM<NL, NT1>.tn[t], m = kTM<NL, NT1>.tm[t], s = kTM<NL, NT1>.slot[t];
-                    acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][l][m], bv[set][l][n], acc[s], 0, 0, 0);
+                    // Out-feature tile 6 holds features 96..99 only: v_mfma_f32_4x4x1_16b_f32 — 16 independent 4 x 4 x 1 blocks, block
+                    // b = 4 g + j / 4 = (document row 4 ks + g) x (in-features 16 n + 4 (j / 4) .. + 3), A = dZ[row][96 + i], B = the SAME
+                    // fragment the 16x16 tiles of column n use — multiplies exactly the 4 x 16 x 4 useful products of the tile in 1/2..1/3 of
+                    // a 16x16x4's issue time (scratch/mfma4: 12-16 cycles vs 32).  Lane (j, g) accumulates dW[96 + c][16 n + j] over the rows
+                    // = g (mod 4); the four lane groups are added in the epilogue.
+                    if constexpr (m == kMT - 1) acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[set][l][m], bv[set][l][n], acc[s], 0, 0, 0);
+                    else acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][l][m], bv[set][l][n], acc[s], 0, 0, 0);
                 });
             };
             using S0 = std::integral_constant<int, 0>;
@@ -500,11 +507,23 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
                 const int K = l == 0 ? F : kH;
                 const int k = 16 * n + j;
                 float *o = out + off_W(l, F);
+                if constexpr (m == kMT - 1) {
+                    // 4x4 form: element c = out-feature 96 + c, partial over the document rows = g (mod 4): fixed-order sum over the lane groups
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int of = 16 * m + 4 * g + c;
-                    if (of < kH && k < K) o[(size_t)of * K + k] = acc[s][c];
-                    if (of < kH && k == K) out[off_b(l, F) + of] = acc[s][c];        // the ones column of the A image
+                    for (int c = 0; c < 4; ++c) {
+                        float v = acc[s][c];
+                        v += __shfl_xor(v, 16, 64);
+                        v += __shfl_xor(v, 32, 64);
+                        if (g == 0 && k < K) o[(size_t)(96 + c) * K + k] = v;
+                        if (g == 0 && k == K) out[off_b(l, F) + 96 + c] = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int of = 16 * m + 4 * g + c;
+                        if (of < kH && k < K) o[(size_t)of * K + k] = acc[s][c];
+                        if (of < kH && k == K) out[off_b(l, F) + of] = acc[s][c];        // the ones column of the A image
+                    }
                 }
             });
         });

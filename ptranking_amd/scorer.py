@@ -206,18 +206,59 @@ class FlatAdam(torch.optim.Optimizer):
         self._opt_called = True           # what torch.optim.lr_scheduler's wrapper of step() records
 
 
-class FlatViewAdam(FlatAdam):
-    """FlatAdam over the ONE flat buffer a FusedStack's parameters are views of (linear.FusedStack.flatten_parameters): one Adam
-    kernel for the whole scoring function instead of torch.optim's multi-tensor update (0.34 ms of host time per step for the
-    22 tensors of the default pointsf), zero_grad() = one memset that also tells the stack that its next backward may write the
-    gradients in place."""
+class FlatAdagrad(FlatAdam):
+    """torch.optim.Adagrad (lr_decay 0, eps 1e-10, accumulator from 0) as one kernel per flat parameter tensor (ranker.py:520-521)."""
 
-    def __init__(self, stack, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params, lr=1e-2, lr_decay=0.0, eps=1e-10, weight_decay=0.0):
+        torch.optim.Optimizer.__init__(self, params, dict(lr=lr, lr_decay=lr_decay, eps=eps, weight_decay=weight_decay))
+
+    def _step_param(self, p, group):
+        if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()):
+            raise RuntimeError("FlatAdagrad needs contiguous CUDA float32 parameters / gradients")
+        st = self.state[p]
+        if not st:
+            st["step"] = 0
+            st["sum"] = torch.zeros_like(p)
+        st["step"] += 1
+        with torch.cuda.device(p.device):
+            _lib.call("ptr_adagrad_step", _lib.ptr(p), _lib.ptr(p.grad), _lib.ptr(st["sum"]), C.c_int64(p.numel()), C.c_float(group["lr"]),
+                      C.c_float(group["lr_decay"]), C.c_float(group["eps"]), C.c_float(group["weight_decay"]), int(st["step"]),
+                      _lib.current_stream(p.device))
+
+
+class FlatRMSprop(FlatAdam):
+    """torch.optim.RMSprop (alpha 0.99, eps 1e-8, no momentum, not centered) as one kernel per flat parameter tensor (ranker.py:518-519)."""
+
+    def __init__(self, params, lr=1e-2, alpha=0.99, eps=1e-8, weight_decay=0.0):
+        torch.optim.Optimizer.__init__(self, params, dict(lr=lr, alpha=alpha, eps=eps, weight_decay=weight_decay))
+
+    def _step_param(self, p, group):
+        if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()):
+            raise RuntimeError("FlatRMSprop needs contiguous CUDA float32 parameters / gradients")
+        st = self.state[p]
+        if not st:
+            st["step"] = 0
+            st["square_avg"] = torch.zeros_like(p)
+        st["step"] += 1
+        with torch.cuda.device(p.device):
+            _lib.call("ptr_rmsprop_step", _lib.ptr(p), _lib.ptr(p.grad), _lib.ptr(st["square_avg"]), C.c_int64(p.numel()), C.c_float(group["lr"]),
+                      C.c_float(group["alpha"]), C.c_float(group["eps"]), C.c_float(group["weight_decay"]), _lib.current_stream(p.device))
+
+
+FLAT_OPTIMIZERS = {'Adam': FlatAdam, 'Adagrad': FlatAdagrad, 'RMS': FlatRMSprop}      # the `opt` strings of ranker.py:516-521
+
+
+class _FlatViewMixin:
+    """A flat optimiser over the ONE flat buffer a FusedStack's parameters are views of (linear.FusedStack.flatten_parameters): one
+    kernel for the whole scoring function instead of torch.optim's multi-tensor update (0.34 ms of host time per step for the 22 tensors
+    of the default pointsf), zero_grad() = one memset that also tells the stack that its next backward may write the gradients in place."""
+
+    def __init__(self, stack, **kw):
         flat, gflat = stack.flatten_parameters()
         self.stack = stack
         self.flat_param = torch.nn.Parameter(flat)          # shares the storage the module's parameters view
         self.flat_param.grad = gflat
-        super().__init__([self.flat_param], lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__([self.flat_param], **kw)
 
     def zero_grad(self, set_to_none=True):
         self.flat_param.grad.zero_()
@@ -235,6 +276,24 @@ class FlatViewAdam(FlatAdam):
         all-reduce of a loss that ships scalars with its gradients (ApproxNDCG's batch coupling, RankMSE's batch mean)."""
         n = self.flat_param.numel()
         return dp.ViewGradBucket(self.stack._gbuf, n, extra, self.zero_grad)
+
+
+class FlatViewAdam(_FlatViewMixin, FlatAdam):
+    def __init__(self, stack, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(stack, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+
+
+class FlatViewAdagrad(_FlatViewMixin, FlatAdagrad):
+    def __init__(self, stack, lr=1e-2, lr_decay=0.0, eps=1e-10, weight_decay=0.0):
+        super().__init__(stack, lr=lr, lr_decay=lr_decay, eps=eps, weight_decay=weight_decay)
+
+
+class FlatViewRMSprop(_FlatViewMixin, FlatRMSprop):
+    def __init__(self, stack, lr=1e-2, alpha=0.99, eps=1e-8, weight_decay=0.0):
+        super().__init__(stack, lr=lr, alpha=alpha, eps=eps, weight_decay=weight_decay)
+
+
+FLAT_VIEW_OPTIMIZERS = {'Adam': FlatViewAdam, 'Adagrad': FlatViewAdagrad, 'RMS': FlatViewRMSprop}
 
 
 class FusedScorerMixin:
@@ -257,12 +316,12 @@ class FusedScorerMixin:
 
     def config_optimizer(self):
         sf = getattr(self, "point_sf", None)
-        if isinstance(sf, FusedPointScorer) and self.opt == 'Adam':
-            self.optimizer = FlatAdam(self.get_parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        if isinstance(sf, FusedPointScorer) and self.opt in FLAT_OPTIMIZERS:
+            self.optimizer = FLAT_OPTIMIZERS[self.opt](self.get_parameters(), lr=self.lr, weight_decay=self.weight_decay)
             self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=20, gamma=0.5)   # ranker.py:525
-        elif (self.opt == 'Adam' and type(sf).__name__ == 'FusedStack' and self.use_flat_stack_optimizer
+        elif (self.opt in FLAT_VIEW_OPTIMIZERS and type(sf).__name__ == 'FusedStack' and self.use_flat_stack_optimizer
               and all(p.is_cuda and p.dtype == torch.float32 for p in sf.parameters())):
-            self.optimizer = FlatViewAdam(sf, lr=self.lr, weight_decay=self.weight_decay)
+            self.optimizer = FLAT_VIEW_OPTIMIZERS[self.opt](sf, lr=self.lr, weight_decay=self.weight_decay)
             self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=20, gamma=0.5)   # ranker.py:525
             self._dp_single = self.optimizer.flat_param     # data parallelism: ONE all-reduce of the flat gradient (rankers.FusedStepMixin)
         else:

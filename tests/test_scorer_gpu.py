@@ -209,3 +209,43 @@ def test_dropout_generator_independence_within_and_across_rows():
         # runs along a row: P(two neighbours dropped) = 0.01
         dd = ((1 - m[:, :-1]) * (1 - m[:, 1:])).mean().item()
         assert abs(dd - 0.01) < 1.5e-3, dd
+
+
+@pytest.mark.parametrize("opt", ["Adagrad", "RMS"])
+def test_flat_adagrad_and_rmsprop_match_torch(opt):
+    """The other two optimisers the reference configures (ptranking/base/ranker.py:518-521) as one kernel on the flat parameter tensor;
+    the ranker picks them for opt = 'Adagrad' / 'RMS' (FusedPointScorer and, as flat views, the layer-wise stack)."""
+    import ptranking_amd as pa
+    from ptranking_amd.scorer import FLAT_OPTIMIZERS, FLAT_VIEW_OPTIMIZERS
+    torch.manual_seed(3)
+    p1 = torch.nn.Parameter(torch.randn(34001, device="cuda"))
+    p2 = torch.nn.Parameter(p1.detach().clone())
+    o1 = FLAT_OPTIMIZERS[opt]([p1], lr=1e-2, weight_decay=1e-3)
+    o2 = (torch.optim.Adagrad if opt == "Adagrad" else torch.optim.RMSprop)([p2], lr=1e-2, weight_decay=1e-3)
+    s1 = torch.optim.lr_scheduler.StepLR(o1, step_size=2, gamma=0.5)
+    s2 = torch.optim.lr_scheduler.StepLR(o2, step_size=2, gamma=0.5)
+    for it in range(6):
+        g = torch.randn(34001, device="cuda") * (10.0 ** (it - 3))
+        p1.grad, p2.grad = g.clone(), g.clone()
+        o1.step(); o2.step(); s1.step(); s2.step()
+        if opt == "Adagrad":
+            assert torch.allclose(p1, p2, rtol=1e-5, atol=1e-7), it
+        else:
+            # RMSprop's first steps are lr * g / (0.1 |g| + eps): a +-10 lr sign function of g that flips within |g| ~ 1e-7, so the few
+            # coordinates whose g = grad + wd * p cancels to ~0 amplify the rounding of that sum by 1e6 — on both sides alike
+            d = (p1 - p2).abs()
+            assert float(d.max()) < 2e-3 and float((d > 1e-6).float().mean()) < 1e-3, (it, float(d.max()))
+            with torch.no_grad():
+                p2.copy_(p1); o2.state[p2]["square_avg"].copy_(o1.state[p1]["square_avg"])       # re-synchronise the ill-conditioned coordinates
+    for sfd, table in ((dict(num_features=136, num_layers=3, AF="R", TL_AF="S", apply_tl_af=False, BN=False, bn_type=None, bn_affine=False), FLAT_OPTIMIZERS),
+                       (dict(num_features=136, num_layers=2, AF="GE", TL_AF="S", apply_tl_af=False, BN=True, bn_type="BN", bn_affine=True), FLAT_VIEW_OPTIMIZERS)):
+        r = pa.LambdaRank(sf_para_dict={"sf_id": "pointsf", "opt": opt, "lr": 1e-3, "pointsf": sfd}, model_para_dict={"sigma": 1.0}, gpu=True,
+                          device="cuda:0")
+        r.init(); r.train_mode()
+        assert type(r.optimizer) is table[opt]
+        X = torch.randn(8, 32, 136, device="cuda")
+        Y = torch.sort(torch.randint(0, 5, (8, 32), device="cuda").float(), dim=1, descending=True)[0]
+        Y[:, 0] = 2.0
+        before = [q.detach().clone() for q in r.get_parameters()]
+        loss, _ = r.train_op(X, Y, epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
+        assert torch.isfinite(loss) and any(not torch.equal(a, b) for a, b in zip(before, r.get_parameters()))
