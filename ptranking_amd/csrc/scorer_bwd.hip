@@ -89,6 +89,12 @@ template <int NL, int NT1> struct TileMap {
             if (!taken[t]) { ++T[tl[t]]; ++rem; }
         const int base = rem / kBW;                  // wave 7 (no chain weights in registers) may end up with more accumulator tiles
         const int quota7 = base;
+        // issue cost of a tile per k-step: a 16x16x4 MFMA 32 cycles, the 4x4x1 16-block form of the strip tiles (out-feature tile 6, and
+        // in-feature tile 6 of the hidden layers) about 14 (scratch/mfma4) — the runs are cut by COST, not by tile count
+        int C[NL] = {}, Ctot = 0;
+        for (int t = 0; t < NT; ++t)
+            if (!taken[t]) { const int c = (tm[t] == 6 || (tl[t] >= 1 && tn[t] == 6)) ? 14 : 32; C[tl[t]] += c; Ctot += c; }
+        const int budget = Ctot / kBW;
         int ksum = 0;
         for (int l = 0; l < NL; ++l) { k[l] = base > 0 ? T[l] / base : 0; ksum += k[l]; }
         while (ksum > kBW - 1) {                       // too many runs: drop one from the layer with the smallest remainder
@@ -104,13 +110,12 @@ template <int NL, int NT1> struct TileMap {
             ++k[best]; ++ksum;
         }
         int L = 0;
-        for (int l = 0; l < NL; ++l) { take[l] = k[l] > 0 ? (T[l] / k[l] < base ? T[l] / k[l] : base) : 0; left[l] = T[l] - k[l] * take[l]; L += left[l]; }
-        for (bool moved = true; moved && L > quota7 + 1;) {   // wave 7 overloaded: lengthen the runs of the layer with the most runs
-            moved = false;
-            int best = -1;
-            for (int l = 0; l < NL; ++l)
-                if (k[l] > 0 && left[l] >= k[l] && (best < 0 || k[l] > k[best])) best = l;
-            if (best >= 0) { ++take[best]; left[best] -= k[best]; L -= k[best]; moved = true; }
+        (void)quota7;
+        for (int l = 0; l < NL; ++l) {
+            // tiles per run so that a run costs about one wave's share of the phase (average tile cost of the layer = C / T)
+            int tk = k[l] > 0 && C[l] > 0 ? (budget * T[l]) / C[l] : 0;
+            if (k[l] > 0 && tk > T[l] / k[l]) tk = T[l] / k[l];
+            take[l] = tk; left[l] = T[l] - k[l] * take[l]; L += left[l];
         }
         {
             int w = 0;
@@ -141,9 +146,18 @@ template <int NL, int NT1> struct TileMap {
         for (int i = 0; i < k; ++i) { const int u = lst[w][ph][i]; if (tl[u] == tl[t] && tm[u] == tm[t]) return false; }
         return true;
     }
+    // hidden-layer tiles (l >= 1, n == 6, m < 6): in-features 96..99 (+ the ones column) against 16 out-features — the "n strip"
+    constexpr bool is_nstrip(int t) const { return tl[t] >= 1 && tn[t] == 6 && tm[t] < 6; }
+    constexpr bool first_nstrip(int w, int ph, int k) const {
+        const int t = lst[w][ph][k];
+        if (!is_nstrip(t)) return false;
+        for (int i = 0; i < k; ++i) { const int u = lst[w][ph][i]; if (tl[u] == tl[t] && is_nstrip(u)) return false; }
+        return true;
+    }
     constexpr bool first_b(int w, int ph, int k) const {
         const int t = lst[w][ph][k];
-        for (int i = 0; i < k; ++i) { const int u = lst[w][ph][i]; if (tl[u] == tl[t] && tn[u] == tn[t]) return false; }
+        if (is_nstrip(t)) return false;                       // the strip form reads its own 4-feature fragment
+        for (int i = 0; i < k; ++i) { const int u = lst[w][ph][i]; if (tl[u] == tl[t] && tn[u] == tn[t] && !is_nstrip(u)) return false; }
         return true;
     }
 };
@@ -309,6 +323,12 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
     // d w_out += h * ds, d b_out += ds
     f32x4 dwo4 = f32x4{0.f, 0.f, 0.f, 0.f};
     float dbo = 0.0f;
+    // Bias gradients of the hidden layers 1..NL-1 are column sums of their dZ images, taken where the images are PRODUCED (the chain
+    // epilogue for dZ_1..dZ_{NL-2}, the top-layer pass for dZ_{NL-1}); only db_0 still comes off the ones column of the X image.
+    f32x4 dbc[CH > 1 ? CH - 1 : 1];
+#pragma unroll
+    for (int i = 0; i < (CH > 1 ? CH - 1 : 1); ++i) dbc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 dbt4 = f32x4{0.f, 0.f, 0.f, 0.f};
     auto top_pass = [&](int buf, int tid_o) {
       if constexpr (!loader) {
         const int t = tid_o - 256;
@@ -336,6 +356,7 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
             for (int c = 0; c < 4; ++c) {
                 d[c] = (ds[h] * w4[c]) * (h4[h][c] > 0.0f ? 1.0f : 0.0f);
                 dwo4[c] = fmaf(h4[h][c], ds[h], dwo4[c]);
+                dbt4[c] += d[c];                                      // db_{NL-1}: column sum of dZ_top
             }
             *reinterpret_cast<f32x4 *>(pa[h]) = d;
             dbo = fmaf(first, ds[h], dbo);
@@ -353,18 +374,19 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
         constexpr int WV = wv_, PH = ph_;
         constexpr int CNT = kTM<NL, NT1>.cnt[WV][PH];
         if constexpr (CNT > 0) {
-            float av[2][NL][kMT], bv[2][NL][NTMAX];
+            float av[2][NL][kMT], bv[2][NL][NTMAX], bv6[2][NL];
             // One OPAQUE base address per LDS image (lane part included): every read below is base + a small constant that fits the
             // ds_read offset field.  Without it each read address (image offset > 64 KB + constant) is a loop-invariant VGPR of its
             // own, hoisted out of the slab loop by the hundred and spilled to scratch.
-            uint32_t zb[NL], ab[NL], zb6[NL];
+            uint32_t zb[NL], ab[NL], zb6[NL], ab6[NL];
 #pragma unroll
             for (int l = 0; l < NL; ++l) {
                 zb[l] = lds_byte_addr(l == NL - 1 ? cur + (NL - 1) * kSlabF : Zb + l * kSlabF) + (uint32_t)((g * kAL + j) * 4);
                 ab[l] = l == 0 ? lds_byte_addr(XS) + (uint32_t)((g * LDX + j) * 4)
                                : lds_byte_addr(cur + (l - 1) * kSlabF) + (uint32_t)((g * kAL + j) * 4);
                 zb6[l] = zb[l] - (uint32_t)((j - (j & 3)) * 4);       // out-feature tile 6 as 4x4 blocks: lane j reads feature 96 + (j & 3)
-                asm volatile("" : "+v"(zb[l]), "+v"(ab[l]), "+v"(zb6[l]));
+                ab6[l] = ab[l] - (uint32_t)((j - (j & 3)) * 4);       // in-feature tile 6 of a hidden layer likewise
+                asm volatile("" : "+v"(zb[l]), "+v"(ab[l]), "+v"(zb6[l]), "+v"(ab6[l]));
             }
             auto rd = [&](int ks, auto set_) {
                 constexpr int set = set_;
@@ -375,6 +397,8 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
                         av[set][l][m] = *reinterpret_cast<lds_f *>((uintptr_t)((m == kMT - 1 ? zb6[l] : zb[l]) + (uint32_t)((4 * ks * kAL + 16 * m) * 4)));
                     if constexpr (kTM<NL, NT1>.first_b(WV, PH, k_))
                         bv[set][l][n] = *reinterpret_cast<lds_f *>((uintptr_t)(ab[l] + (uint32_t)((4 * ks * (l == 0 ? LDX : kAL) + 16 * n) * 4)));
+                    if constexpr (kTM<NL, NT1>.first_nstrip(WV, PH, k_))
+                        bv6[set][l] = *reinterpret_cast<lds_f *>((uintptr_t)(ab6[l] + (uint32_t)((4 * ks * kAL + 16 * 6) * 4)));
                 });
             };
             auto mma = [&](auto set_) {
@@ -387,8 +411,16 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
                     // fragment the 16x16 tiles of column n use — multiplies exactly the 4 x 16 x 4 useful products of the tile in 1/2..1/3 of
                     // a 16x16x4's issue time (scratch/mfma4: 12-16 cycles vs 32).  Lane (j, g) accumulates dW[96 + c][16 n + j] over the rows
                     // = g (mod 4); the four lane groups are added in the epilogue.
-                    if constexpr (m == kMT - 1) acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[set][l][m], bv[set][l][n], acc[s], 0, 0, 0);
-                    else acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][l][m], bv[set][l][n], acc[s], 0, 0, 0);
+                    if constexpr (m == kMT - 1) {
+                        acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[set][l][m], bv[set][l][n], acc[s], 0, 0, 0);
+                    } else if constexpr (kTM<NL, NT1>.is_nstrip(t)) {
+                        // In-feature tile 6 of a hidden layer holds features 96..99 and the ones column: the same 4x4 form with the roles
+                        // swapped — A = the 4 in-features, B = the dZ fragment of the tile — lane (j, g) accumulates dW[16 m + j][96 + c] (the
+                        // bias gradient does not need the ones column: see dbc / dbt4)
+                        acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(bv6[set][l], av[set][l][m], acc[s], 0, 0, 0);
+                    } else {
+                        acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][l][m], bv[set][l][n], acc[s], 0, 0, 0);
+                    }
                 });
             };
             using S0 = std::integral_constant<int, 0>;
@@ -466,6 +498,7 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
 #pragma unroll
                     for (int e = 0; e < 4; ++e) d[e] = (ac0[e] + ac1[e]) * (gt[e] > 0.0f ? inv_keep : 0.0f);
                     *reinterpret_cast<f32x4 *>(dst + row * kAL + 16 * W + 4 * g) = d;
+                    if constexpr (c < CH - 1) dbc[c] += d;            // db_{l-1}: column sum of the dZ image just produced (rows >= R are 0)
                 }
             } else {
                 dw_phase(std::integral_constant<int, 7>{}, c_, cur, XSb + p * kSR * LDX);
@@ -515,14 +548,24 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
                         v += __shfl_xor(v, 16, 64);
                         v += __shfl_xor(v, 32, 64);
                         if (g == 0 && k < K) o[(size_t)(96 + c) * K + k] = v;
-                        if (g == 0 && k == K) out[off_b(l, F) + 96 + c] = v;
+                        if (l == 0 && g == 0 && k == K) out[off_b(l, F) + 96 + c] = v;      // db_0: the ones column of the X image
+                    }
+                } else if constexpr (kTM<NL, NT1>.is_nstrip(t)) {
+                    // element c = in-feature 96 + c of out-feature 16 m + j, partial over the document rows = g (mod 4)
+                    const int of = 16 * m + j;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float v = acc[s][c];
+                        v += __shfl_xor(v, 16, 64);
+                        v += __shfl_xor(v, 32, 64);
+                        if (g == 0) o[(size_t)of * K + 96 + c] = v;
                     }
                 } else {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const int of = 16 * m + 4 * g + c;
                         if (of < kH && k < K) o[(size_t)of * K + k] = acc[s][c];
-                        if (of < kH && k == K) out[off_b(l, F) + of] = acc[s][c];        // the ones column of the A image
+                        if (l == 0 && of < kH && k == K) out[off_b(l, F) + of] = acc[s][c];        // db_0: the ones column of the X image
                     }
                 }
             });
@@ -534,15 +577,30 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
         const int t = tid - 256, rs = t / 28, f4 = t - rs * 28;
         if (rs < 9) {
             *reinterpret_cast<f32x4 *>(Zb + rs * kAL + 4 * f4) = dwo4;
+            *reinterpret_cast<f32x4 *>(Zb + (9 + rs) * kAL + 4 * f4) = dbt4;
             if (f4 == 0) Zb[18 * kAL + rs] = dbo;
         }
     }
+    // chain waves: db of the layers whose dZ they produced — fixed-order sum over the 16 document lanes of a lane group
+    if constexpr (W < 7) {
+        static_for<(CH > 1 ? CH - 1 : 0)>([&](auto c_) {
+            constexpr int c = c_, lyr = NL - 2 - c;              // chain phase c produced dZ_{NL-2-c}
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = dbc[c][e];
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                const int of = 16 * W + 4 * g + e;
+                if (j == 0 && of < kH) out[off_b(lyr, F) + of] = v;
+            }
+        });
+    }
     wg_barrier();
     if (tid < kH) {
-        float s = 0.0f;
+        float s = 0.0f, sb = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 9; ++r) s += Zb[r * kAL + tid];
+        for (int r = 0; r < 9; ++r) { s += Zb[r * kAL + tid]; sb += Zb[(9 + r) * kAL + tid]; }
         out[off_wout(NL, F) + tid] = s;
+        out[off_b(NL - 1, F) + tid] = sb;
     } else if (tid == kH) {
         float s = 0.0f;
 #pragma unroll
