@@ -9,7 +9,7 @@
 `run` launches each entry point ITERS times at B queries (default 65 536; inputs far larger than the 256 MB Infinity Cache) on the MSLR label
 mix.  `summarise` joins the rocprofv3 kernel averages with the ALGORITHMIC bytes of SURVEY.md 8(d) — 12L+4 per query for the fused loss
 kernels (16L+4 for ListMLE with its int32 permutation), 8L+4*len(ks) for the metric kernel, 16L for the sort (4L in, 4L values + 8L int64
-indices out) — and prints achieved GB/s against the 8 TB/s HBM peak.
+indices out), 12L for the tie shuffle (4L labels in, 8L int64 order out) — and prints achieved GB/s against the 8 TB/s HBM peak.
 """
 import json
 import os
@@ -30,7 +30,7 @@ CASES = [
     ("approxndcg L=512", "approxndcg", 512, lambda L: 12 * L + 4),
     ("metrics L=256", "metrics_kernel", 256, lambda L: 8 * L + 4 * len(KS) * 4),
     ("sort_desc L=256", "sort_desc_kernel", 256, lambda L: 16 * L),
-    ("shuffle_ties L=256", "shuffle_ties", 256, lambda L: 8 * L),
+    ("shuffle_ties L=256", "shuffle_ties", 256, lambda L: 12 * L),
 ]
 
 

@@ -361,9 +361,13 @@ __device__ __forceinline__ void ring_pairs(const float (&si)[DPT], const float (
 // The waves of a block are independent (one query each, wave-local LDS hand-overs), so the block size is a launch-time choice:
 // up to 16 waves per workgroup.  256 workgroups of 16 waves spread evenly over the 256 CUs; 1024 workgroups of 4 do not (the
 // dispatcher fills some CUs deeper than others: 33.7 us vs 29.9 us for 4096 queries of 128 documents).
+// DPT = 4 (list lengths 129..256): 8 waves at most — the two-copy pair loop with its Z variants needs ~150 registers, and under the
+// 128-register cap of a 16-wave block it spilled 25 of them to scratch (PMC: 348 MB of HBM traffic per 65 536 queries against 202 MB
+// algorithmic); 3 waves per SIMD without spills run as fast as 4 with them.
 constexpr int kRingBlock = 1024;
+template <int DPT> constexpr int ring_block() { return DPT >= 4 ? 512 : kRingBlock; }
 template <int DPT>
-__global__ void __launch_bounds__(kRingBlock)
+__global__ void __launch_bounds__(ring_block<DPT>())
 lambdarank_ring_kernel(const float *__restrict__ preds, const float *__restrict__ labels, const int32_t *__restrict__ lens,
                        int B, int L, float sigma, float *__restrict__ loss_q, float *__restrict__ grad) {
     constexpr int RS = 64 * DPT;
@@ -581,6 +585,7 @@ static int launch_pairwise(const float *preds, const float *labels, const int32_
         auto go = [&](auto kern, int dpt) -> int {
             int QPB = ring_waves();
             if (!QPB) { QPB = kRingBlock / kWave; while (QPB > 1 && B < QPB * ring_num_cus()) QPB >>= 1; }
+            if (dpt >= 4 && QPB > 8) QPB = 8;
             const size_t lds = (size_t)QPB * 2 * 64 * dpt * sizeof(float);
             hipLaunchKernelGGL(kern, dim3((B + QPB - 1) / QPB), dim3(QPB * kWave), lds, st, preds, labels, lens, B, L, sigma, loss_q, grad);
             return check_hip(hipGetLastError(), who);

@@ -1,0 +1,50 @@
+#!/bin/bash
+# Round-3 measurement set on one MI355X (run from the repo root through gpurun): bench lines, rocprofv3 kernel stats, PMC HBM traffic
+# (FETCH_SIZE / WRITE_SIZE in separate passes, no trace domains beside --pmc), SQ counters, the BASELINE configs, the stand-alone kernel
+# profile.  Everything lands under gpurun_out/r03/; the summaries that are kept are copied into profiles/ by hand.
+ROOT=$(pwd); OUT=$ROOT/gpurun_out/r03; mkdir -p $OUT
+python bench.py > $OUT/r03_bench_B4096.json 2> $OUT/bench.err
+tail -c 300 $OUT/bench.err
+python bench.py --batch 1024 --steps 100 --no-cpu-baseline --sweep= > $OUT/r03_bench_B1024.json 2>/dev/null
+BENCH="python $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --sweep= --windows 1"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $OUT/stats --output-format csv -- python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --sweep= --windows 1 > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/stats1024 --output-format csv -- python $ROOT/bench.py --batch 1024 --steps 20 --warmup 3 --no-cpu-baseline --sweep= --windows 1 > $OUT/stats1024.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c -d $OUT/pmc_$c --output-format csv -- $BENCH > $OUT/pmc_$c.log 2>&1
+done
+cd $ROOT
+python profiles/pmc_traffic.py $(find $OUT/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1) $(find $OUT/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1) 4096 128 136 $OUT/r03_pmc_traffic.json
+scratch/prof_sq.sh gpurun_out/r03/sq $BENCH
+cp $(find $OUT/stats -name '*kernel_stats.csv' | head -1) $OUT/r03_bench_B4096_kernel_stats.csv
+cp $(find $OUT/stats1024 -name '*kernel_stats.csv' | head -1) $OUT/r03_bench_B1024_kernel_stats.csv
+cp $OUT/sq/sq_summary.txt $OUT/r03_sq_c2.txt
+# BASELINE configs
+python bench.py --loss RankNet --list-len 32 --batch 4096 --steps 50 --no-cpu-baseline --sweep= > $OUT/r03_bench_c1_ranknet_L32.json 2>/dev/null
+python bench.py --loss ListNet --list-len 256 --batch 4096 --steps 30 --no-cpu-baseline --sweep= > $OUT/r03_bench_c3_listnet_L256.json 2>/dev/null
+python bench.py --loss ListMLE --list-len 256 --batch 4096 --steps 30 --no-cpu-baseline --sweep= > $OUT/r03_bench_c3_listmle_L256.json 2>/dev/null
+python bench.py --loss ApproxNDCG --list-len 512 --features 700 --batch 1024 --steps 20 --nbatches 2 --no-cpu-baseline --sweep= > $OUT/r03_bench_c4_approxndcg_L512_F700.json 2>/dev/null
+python bench.py --loss LambdaRank --list-len 256 --batch 4096 --steps 30 --no-cpu-baseline --sweep= > $OUT/r03_bench_northstar_lambdarank_L256.json 2>/dev/null
+python bench.py --scorer pointsf_default --batch 1024 --steps 30 --warmup 5 --no-cpu-baseline --sweep= > $OUT/r03_bench_default_pointsf_B1024.json 2>/dev/null
+python bench.py --scorer listsf --loss LambdaLoss --list-len 256 --batch 1024 --steps 10 --warmup 2 --windows 2 > $OUT/r03_bench_c5_listsf_lambdaloss_L256.json 2>/dev/null
+# stand-alone kernels at 65 536 queries
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $OUT/kstats --output-format csv -- python $ROOT/profiles/prof_kernels.py run 65536 > $OUT/kstats.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c -d $OUT/kpmc_$c --output-format csv -- python $ROOT/profiles/prof_kernels.py run 65536 > $OUT/kpmc_$c.log 2>&1
+done
+cd $ROOT
+cp $(find $OUT/kstats -name '*kernel_stats.csv' | head -1) $OUT/r03_kernels_B65536_kernel_stats.csv
+python profiles/prof_kernels.py summarise $OUT/r03_kernels_B65536_kernel_stats.csv $OUT/r03_kernels_B65536.json 65536 $(find $OUT/kpmc_FETCH_SIZE -name '*counter_collection.csv' | head -1) $(find $OUT/kpmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)
+find $OUT -name '*.db' -delete; find $OUT -name '*kernel_trace.csv' -delete; find $OUT -name '*counter_collection.csv' -size +1M -delete; find $OUT -name '*_agent_info.csv' -delete
+for f in $OUT/r03_bench_*.json; do python - "$f" <<'PY'
+import json,sys
+try:
+    j=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(sys.argv[1].split('/')[-1], round(j["value"]), "q/s", round(j["ms_per_step"],3), "ms/step", "roofline", round(j["roofline"].get("frac",0),3))
+except Exception as e:
+    print(sys.argv[1], "FAILED", e)
+PY
+done
+head -8 $OUT/r03_bench_B4096_kernel_stats.csv | cut -c1-140
+cat $OUT/r03_sq_c2.txt | head -30
