@@ -386,6 +386,9 @@ def main():
                       "ApproxNDCG": "ptr_approxndcg_fwd_bwd", "ListNet": "ptr_listnet_fwd_bwd", "ListMLE": "ptr_listmle_fwd_bwd"}[args.loss]
         t_fwd, t_loss, t_bwd, t_adam, t_sum = (avg_ms(n) for n in ("ptr_mlp_forward", loss_entry, "ptr_mlp_backward", "ptr_adam_step",
                                                                     "ptr_sum_f32"))
+        bwd_fused_step = t_bwd is None and avg_ms("ptr_mlp_backward_step") is not None
+        if bwd_fused_step:       # single device: backward + optimiser step + loss-slot sum in one entry point (rankers._direct_train_op)
+            t_bwd = avg_ms("ptr_mlp_backward_step")
         pmc, pmc_source = load_pmc(B, L, F)
 
         def pmc_bytes(prefix):
@@ -460,8 +463,9 @@ def main():
                         "traffic": pmc_bytes("ptr::mlp_bwd_fused_kernel"), "avg_launch_ms": t_bwd, "algorithmic_flop_per_launch": bwd_flop,
                         "algorithmic_bytes_per_launch": R * (4 * F + 4),
                         "design_bytes_per_launch": NL * R * 448 + 256 * 4 * (100 * F + 100 + (NL - 1) * 10100 + 101),
-                        "note": "dominant kernel of the step by time; avg_launch_ms brackets the whole ptr_mlp_backward entry point (fused kernel + "
-                                "the 136 KB partial reduction); algorithmic bytes = SURVEY 8(d) (features read once more for dW1 + dLoss/dscore), "
+                        "entry_point": "ptr_mlp_backward_step" if bwd_fused_step else "ptr_mlp_backward",
+                        "note": "dominant kernel of the step by time; avg_launch_ms brackets the whole entry point (fused backward kernel + "
+                                "the 136 KB partial reduction, which on one device also applies the Adam step and sums the loss slots); algorithmic bytes = SURVEY 8(d) (features read once more for dW1 + dLoss/dscore), "
                                 "design bytes = the stored activations read back (3 x 448 B / document) + one partial gradient per workgroup; "
                                 "traffic = PMC FETCH_SIZE(x2 on gfx950)+WRITE_SIZE from " + pmc_source}
         elif args.scorer == "listsf" and avg_ms("ptr_mhsa_forward"):

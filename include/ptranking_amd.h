@@ -162,6 +162,21 @@ int ptr_mlp_forward(const float *X, const float *params, int R, int F, int NL, i
                     float *preds, float *acts, void *stream);
 int ptr_mlp_backward(const float *X, const float *params, const float *acts, const float *dpreds, int R, int F, int NL,
                      float p_drop, uint64_t seed, float *dz, float *ws, float *grad, void *stream);
+/* ptr_mlp_backward + the optimiser step + the loss-slot sum in the SAME launches (ABI v2): the partial-gradient reduction applies the
+ * update to each element it has just reduced, and one extra block sums loss_q[nq] into loss_out (nullable) exactly like ptr_sum_f32 — for
+ * single-device training, where no all-reduce sits between the gradient and the step (ptranking/base/ranker.py:589-603 does
+ * backward -> optimizer.step back to back).  `grad` still receives the gradient.  opt_kind / hyper-parameters:
+ *   PTR_OPT_ADAM     hyper1 = beta1, hyper2 = beta2, state1 = exp_avg, state2 = exp_avg_sq      (arithmetic of ptr_adam_step)
+ *   PTR_OPT_ADAGRAD  hyper1 = lr_decay, state1 = sum, state2 unused                             (ptr_adagrad_step)
+ *   PTR_OPT_RMSPROP  hyper1 = alpha, state1 = square_avg, state2 unused                          (ptr_rmsprop_step)
+ * Results are bit-identical to the separate calls. */
+#define PTR_OPT_ADAM 1
+#define PTR_OPT_ADAGRAD 2
+#define PTR_OPT_RMSPROP 3
+int ptr_mlp_backward_step(const float *X, float *params, const float *acts, const float *dpreds, int R, int F, int NL, float p_drop,
+                          uint64_t seed, float *dz, float *ws, float *grad, int opt_kind, float lr, float hyper1, float hyper2, float eps,
+                          float weight_decay, int step, float *state1, float *state2, const float *loss_q, int nq, float *loss_out,
+                          void *stream);
 /* torch.optim.Adam step (L2 weight decay added to the gradient, bias correction with `step` >= 1) on flat buffers. */
 int ptr_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, void *stream);

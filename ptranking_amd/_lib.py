@@ -41,6 +41,7 @@ SIGNATURES = {
     "ptr_mlp_backward_dz_floats": [_i, _i, _i],
     "ptr_mlp_forward": [_vp, _vp, _i, _i, _i, _i, _f, _u64, _vp, _vp, _vp],
     "ptr_mlp_backward": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _vp, _vp, _vp, _vp],
+    "ptr_mlp_backward_step": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "ptr_adam_step": [_vp, _vp, _vp, _vp, C.c_int64, _f, _f, _f, _f, _f, _i, _vp],
     "ptr_adagrad_step": [_vp, _vp, _vp, C.c_int64, _f, _f, _f, _f, _i, _vp],
     "ptr_rmsprop_step": [_vp, _vp, _vp, C.c_int64, _f, _f, _f, _f, _vp],

@@ -905,11 +905,31 @@ __host__ __device__ constexpr size_t dw_lds_bytes(int NTW, int RB) { return (siz
 // grad[i] = sum_b ws[b][i], fixed order.  A 1024-thread workgroup owns 64 consecutive i: wave w sums the partials
 // b = w, w+16, ... (4 independent accumulators keep 4 loads in flight), then one wave adds the 16 wave totals in order.
 // Entries i >= tail_begin (d w_out, d b_out: written by the dZ kernel's smaller grid) only have nblk_tail partials.
+// Optional epilogue of the partial reduction: the optimiser step on the element just reduced (single-device training: no all-reduce sits
+// between gradient and step) and the sum of the loss slots of the batch — three launches fewer per train step.
+struct OptStep {
+    int kind;                      // 0 = none, PTR_OPT_ADAM / _ADAGRAD / _RMSPROP
+    float lr, h1, h2, eps, wd, bc1, bc2_sqrt;
+    float *param, *s1, *s2;
+    const float *loss_q; int nq; float *loss_out;
+};
 __global__ void __launch_bounds__(1024)
 reduce_partials_kernel(const float *__restrict__ ws, int nblk, int nblk_tail, size_t tail_begin, size_t stride, size_t n,
-                       float *__restrict__ grad) {
+                       float *__restrict__ grad, OptStep o) {
     __shared__ float part[16][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (o.loss_out && blockIdx.x == gridDim.x - 1) {
+        // one extra block: the loss slots of the batch, summed EXACTLY like sum_f32_kernel (256 threads, strided, wave butterflies, the four
+        // wave sums in order) so that the fused step returns the same bits as the separate call
+        float acc = 0.0f;
+        if (threadIdx.x < kBlock)
+            for (int i = threadIdx.x; i < o.nq; i += kBlock) acc += o.loss_q[i];
+        acc = wave_sum(acc);
+        if (lane == 0) part[0][w] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) o.loss_out[0] = ((part[0][0] + part[0][1]) + part[0][2]) + part[0][3];
+        return;
+    }
     const size_t i = (size_t)blockIdx.x * 64 + lane;
     const bool ok = i < n;
     const size_t ic = ok ? i : n - 1;
@@ -930,6 +950,28 @@ reduce_partials_kernel(const float *__restrict__ ws, int nblk, int nblk_tail, si
 #pragma unroll
         for (int k = 1; k < 16; ++k) s += part[k][lane];
         grad[i] = s;
+        // fused optimiser step on the element just reduced: the arithmetic of adam_kernel / adagrad_kernel / rmsprop_kernel, bit for bit
+        if (o.kind == PTR_OPT_ADAM) {
+            const float pi = o.param[i];
+            const float gi = s + o.wd * pi;
+            const float mi = o.h1 * o.s1[i] + (1.0f - o.h1) * gi;
+            const float vi = o.h2 * o.s2[i] + (1.0f - o.h2) * gi * gi;
+            o.s1[i] = mi; o.s2[i] = vi;
+            const float denom = sqrtf(vi) / o.bc2_sqrt + o.eps;
+            o.param[i] = pi - (o.lr / o.bc1) * (mi / denom);
+        } else if (o.kind == PTR_OPT_ADAGRAD) {
+            const float pi = o.param[i];
+            const float gi = s + o.wd * pi;
+            const float si = o.s1[i] + gi * gi;
+            o.s1[i] = si;
+            o.param[i] = pi - o.lr * (gi / (sqrtf(si) + o.eps));          // o.lr = the decayed clr
+        } else if (o.kind == PTR_OPT_RMSPROP) {
+            const float pi = o.param[i];
+            const float gi = s + o.wd * pi;
+            const float si = o.h1 * o.s1[i] + (1.0f - o.h1) * gi * gi;
+            o.s1[i] = si;
+            o.param[i] = pi - o.lr * (gi / (sqrtf(si) + o.eps));
+        }
     }
 }
 
@@ -1061,10 +1103,42 @@ extern "C" int ptr_mlp_forward(const float *X, const float *params, int R, int F
     return train ? pick(I2{}, N512{}, std::true_type{}) : pick(I2{}, N512{}, std::false_type{});
 }
 
+namespace ptr {
+int mlp_backward_impl(const char *who, const float *X, const float *params, const float *acts, const float *dpreds, int R, int F, int NL,
+                             float p_drop, uint64_t seed, float *dz, float *ws, float *grad, void *stream, const OptStep &opt);
+}
 extern "C" int ptr_mlp_backward(const float *X, const float *params, const float *acts, const float *dpreds, int R, int F, int NL,
                                 float p_drop, uint64_t seed, float *dz, float *ws, float *grad, void *stream) {
+    return ptr::mlp_backward_impl("ptr_mlp_backward", X, params, acts, dpreds, R, F, NL, p_drop, seed, dz, ws, grad, stream, ptr::OptStep{});
+}
+
+extern "C" int ptr_mlp_backward_step(const float *X, float *params, const float *acts, const float *dpreds, int R, int F, int NL, float p_drop,
+                                     uint64_t seed, float *dz, float *ws, float *grad, int opt_kind, float lr, float hyper1, float hyper2,
+                                     float eps, float weight_decay, int step, float *state1, float *state2, const float *loss_q, int nq,
+                                     float *loss_out, void *stream) {
     using namespace ptr;
-    const char *who = "ptr_mlp_backward";
+    const char *who = "ptr_mlp_backward_step";
+    if (opt_kind < PTR_OPT_ADAM || opt_kind > PTR_OPT_RMSPROP) { set_error("%s: unknown optimiser %d", who, opt_kind); return PTR_ERR_INVALID_ARG; }
+    if (step < 1 || !state1 || (opt_kind == PTR_OPT_ADAM && !state2) || (loss_out && nq > 0 && !loss_q) || nq < 0) {
+        set_error("%s: bad optimiser / loss arguments", who);
+        return PTR_ERR_INVALID_ARG;
+    }
+    OptStep o{};
+    o.kind = opt_kind; o.h1 = hyper1; o.h2 = hyper2; o.eps = eps; o.wd = weight_decay;
+    o.param = params; o.s1 = state1; o.s2 = state2; o.loss_q = loss_q; o.nq = nq; o.loss_out = loss_out;
+    if (opt_kind == PTR_OPT_ADAM) {                                  // as ptr_adam_step
+        o.lr = lr; o.bc1 = 1.0f - powf(hyper1, (float)step); o.bc2_sqrt = sqrtf(1.0f - powf(hyper2, (float)step));
+    } else if (opt_kind == PTR_OPT_ADAGRAD) {                        // as ptr_adagrad_step: hyper1 = lr_decay
+        o.lr = lr / (1.0f + (float)(step - 1) * hyper1);
+    } else {
+        o.lr = lr;                                                   // hyper1 = alpha
+    }
+    return mlp_backward_impl(who, X, params, acts, dpreds, R, F, NL, p_drop, seed, dz, ws, grad, stream, o);
+}
+
+int ptr::mlp_backward_impl(const char *who, const float *X, const float *params, const float *acts, const float *dpreds, int R, int F, int NL,
+                                  float p_drop, uint64_t seed, float *dz, float *ws, float *grad, void *stream, const OptStep &opt) {
+    using namespace ptr;
     if (int rc = check_mlp(who, R, F, NL, p_drop)) return rc;
     if (!X || !params || !acts || !dpreds || !ws || !grad) { set_error("%s: NULL pointer", who); return PTR_ERR_INVALID_ARG; }
     hipStream_t st = as_stream(stream);
@@ -1074,7 +1148,8 @@ extern "C" int ptr_mlp_backward(const float *X, const float *params, const float
         if (int e = launch_bwd_fused(X, params, acts, dpreds, a, ws, st, who)) return e;
         const int nb = bwd_fused_grid(R);
         const size_t NPf = n_params(NL, F);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((NPf + 63) / 64)), dim3(1024), 0, st, ws, nb, nb, NPf, NPf, NPf, grad);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((NPf + 63) / 64) + (opt.loss_out ? 1 : 0)), dim3(1024), 0, st, ws, nb, nb, NPf, NPf, NPf,
+                           grad, opt);
         return check_hip(hipGetLastError(), who);
     }
     if (!dz) { set_error("%s: dz scratch is required for this configuration (ptr_mlp_backward_dz_floats)", who); return PTR_ERR_INVALID_ARG; }
@@ -1130,8 +1205,8 @@ extern "C" int ptr_mlp_backward(const float *X, const float *params, const float
         if (e) return e;
     }
     // 3. one deterministic reduction of all partials into the flat gradient
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((NP + 63) / 64)), dim3(1024), 0, st, ws, nblk, grid_dz, off_wout(NL, F), NP, NP,
-                       grad);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((NP + 63) / 64) + (opt.loss_out ? 1 : 0)), dim3(1024), 0, st, ws, nblk, grid_dz,
+                       off_wout(NL, F), NP, NP, grad, opt);
     return check_hip(hipGetLastError(), who);
 }
 

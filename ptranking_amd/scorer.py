@@ -187,6 +187,19 @@ class FlatAdam(torch.optim.Optimizer):
                       C.c_int64(p.numel()), C.c_float(group["lr"]), C.c_float(b1), C.c_float(b2), C.c_float(group["eps"]),
                       C.c_float(group["weight_decay"]), int(st["step"]), _lib.current_stream(p.device))
 
+    def fused_step_args(self, p):
+        """(opt_kind, lr, hyper1, hyper2, eps, weight_decay, step, state1, state2) of THIS step for ptr_mlp_backward_step — the state /
+        step bookkeeping of _step_param without its kernel launch."""
+        group, st = self.param_groups[0], self.state[p]
+        if not st:
+            st["step"] = 0
+            st["exp_avg"] = torch.zeros_like(p)
+            st["exp_avg_sq"] = torch.zeros_like(p)
+        st["step"] += 1
+        b1, b2 = group["betas"]
+        self._opt_called = True
+        return 1, group["lr"], b1, b2, group["eps"], group["weight_decay"], int(st["step"]), st["exp_avg"], st["exp_avg_sq"]
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -226,6 +239,16 @@ class FlatAdagrad(FlatAdam):
                       _lib.current_stream(p.device))
 
 
+    def fused_step_args(self, p):
+        group, st = self.param_groups[0], self.state[p]
+        if not st:
+            st["step"] = 0
+            st["sum"] = torch.zeros_like(p)
+        st["step"] += 1
+        self._opt_called = True
+        return 2, group["lr"], group["lr_decay"], 0.0, group["eps"], group["weight_decay"], int(st["step"]), st["sum"], None
+
+
 class FlatRMSprop(FlatAdam):
     """torch.optim.RMSprop (alpha 0.99, eps 1e-8, no momentum, not centered) as one kernel per flat parameter tensor (ranker.py:518-519)."""
 
@@ -243,6 +266,16 @@ class FlatRMSprop(FlatAdam):
         with torch.cuda.device(p.device):
             _lib.call("ptr_rmsprop_step", _lib.ptr(p), _lib.ptr(p.grad), _lib.ptr(st["square_avg"]), C.c_int64(p.numel()), C.c_float(group["lr"]),
                       C.c_float(group["alpha"]), C.c_float(group["eps"]), C.c_float(group["weight_decay"]), _lib.current_stream(p.device))
+
+
+    def fused_step_args(self, p):
+        group, st = self.param_groups[0], self.state[p]
+        if not st:
+            st["step"] = 0
+            st["square_avg"] = torch.zeros_like(p)
+        st["step"] += 1
+        self._opt_called = True
+        return 3, group["lr"], group["alpha"], 0.0, group["eps"], group["weight_decay"], int(st["step"]), st["square_avg"], None
 
 
 FLAT_OPTIMIZERS = {'Adam': FlatAdam, 'Adagrad': FlatAdagrad, 'RMS': FlatRMSprop}      # the `opt` strings of ranker.py:516-521
