@@ -384,16 +384,22 @@ class FusedStack(nn.Sequential):
         if self._flat is None:
             return 0
         gflat = self._flat[1]
-        off, moved = 0, 0
-        for p in self.parameters():
-            n = p.numel()
-            view = gflat[off:off + n].view(p.shape)
-            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
-                if p.grad is not None:
-                    view.copy_(p.grad)
+        slots = self.__dict__.get("_grad_slots")
+        if slots is None:                       # (parameter, offset, expected address of its gradient slice): built once
+            slots, off, base = [], 0, gflat.data_ptr()
+            for p in self.parameters():
+                slots.append((p, off, base + 4 * off))
+                off += (p.numel() + 3) // 4 * 4
+            self.__dict__["_grad_slots"] = slots
+        moved = 0
+        for p, off, addr in slots:              # the per-step cost is one data_ptr() compare per parameter (no tensor views)
+            g = p.grad
+            if g is None or g.data_ptr() != addr:
+                view = gflat[off:off + p.numel()].view(p.shape)
+                if g is not None:
+                    view.copy_(g)
                 p.grad = view
                 moved += 1
-            off += (n + 3) // 4 * 4
         return moved
 
     def _claim_sinks(self, params):
