@@ -452,7 +452,8 @@ def main():
         if t_sum:
             kernels["loss_slot_sum"] = {"avg_launch_ms": t_sum}
         if world > 1 and ar_timing:
-            kernels["gradient_allreduce"] = {"rccl_ranks": world, "allreduce_ms": float(np.mean([a.elapsed_time(b) for a, b in ar_timing])),
+            kernels["gradient_allreduce"] = {"ranks": world, "backend": dist.get_backend(), "rccl_ranks": world if dist.get_backend() == "nccl" else 0,
+                                             "allreduce_ms": float(np.mean([a.elapsed_time(b) for a, b in ar_timing])),
                                              "bytes": 4 * (100 * F + 100 + (NL - 1) * 10100 + 101), "calls_per_step": len(ar_timing) / timed_steps}
         if t_bwd and args.scorer == "pointsf":
             tf = bwd_flop / (t_bwd * 1e-3) / 1e12
