@@ -268,9 +268,12 @@ int ptr_bnact_backward(const float *z, const float *da, int ld, int R, int N, in
 #define PTR_MHSA_MAX_HEAD_DIM 128
 int ptr_mhsa_forward(const float *Q, const float *K, const float *V, int ld_qkv, const int32_t *lens, int B, int L, int F,
                      int n_heads, float p_drop, uint64_t seed, int site, float *O, float *lse, void *stream);
+/* ds_ws (ABI v2, nullable): B * n_heads * L * L floats of scratch.  When given, the dK / dV kernel stores the scaled dS it forms and the dQ
+ * kernel is ONE GEMM unit dS . K instead of recomputing S = Q K^T and dP = dO V^T (7 -> 5 GEMM units for the backward, at 4 L^2 bytes per
+ * (query, head) through HBM); NULL keeps the recomputing dQ kernel (no L^2 scratch). */
 int ptr_mhsa_backward(const float *Q, const float *K, const float *V, int ld_qkv, const float *O, const float *dO, const float *lse,
                       const int32_t *lens, int B, int L, int F, int n_heads, float p_drop, uint64_t seed, int site, float *dvec,
-                      float *dQ, float *dK, float *dV, void *stream);
+                      float *dQ, float *dK, float *dV, float *ds_ws, void *stream);
 /* Test helper: the attention dropout keep-mask (1.0 / 0.0), out [B][n_heads][L][L]. */
 int ptr_mhsa_dropout_mask(int B, int L, int n_heads, float p_drop, uint64_t seed, int site, float *out, void *stream);
 /* LayerNorm of ptranking/base/list_ranker.py:152-174: y = a_2 * (x - mean) / (std + eps) + b_2 over the last axis of X [R][F],

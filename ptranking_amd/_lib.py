@@ -57,7 +57,7 @@ SIGNATURES = {
     "ptr_dropout_apply": [_vp, _i, _i, _i, _f, _u64, _i, _vp, _i, _vp],
     "ptr_relu_gate": [_vp, _vp, C.c_int64, _vp, _vp],
     "ptr_mhsa_forward": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _u64, _i, _vp, _vp, _vp],
-    "ptr_mhsa_backward": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _i, _vp, _vp, _vp, _vp, _vp],
+    "ptr_mhsa_backward": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "ptr_mhsa_dropout_mask": [_i, _i, _i, _f, _u64, _i, _vp, _vp],
     "ptr_layernorm_forward": [_vp, _vp, _vp, C.c_int64, _i, _f, _vp, _vp, _vp],
     "ptr_layernorm_backward_ws_floats": [_i],

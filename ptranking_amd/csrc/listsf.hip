@@ -415,12 +415,89 @@ mhsa_bwd_dq_kernel(const float *__restrict__ Q, const float *__restrict__ K, con
     }
 }
 
+// ============================================================================================ backward: dQ from stored dS
+// dQ^T[d][row] = sum_key K^T[d][key] * dS^T[key][row] with dS written by mhsa_bwd_dkv_kernel: one GEMM unit instead of three (the
+// recomputing kernel above also forms S = Q K^T and dP = dO V^T).  Lane (j, g) = row j; its dS fragment for key tile kt is the float4
+// dS[row][kc + 16 kt + 4 g ..] — the B operand layout directly.  Keys >= n (padding; columns a non-live key block never wrote) are
+// SELECTED to zero, not multiplied.
+template <int DT, int NW>
+__global__ void __launch_bounds__(NW * 64, PTR_ATTN_MINBLK_BWD)
+mhsa_bwd_dq_ds_kernel(const float *__restrict__ K, const float *__restrict__ dS_ws, const int32_t *__restrict__ lens, AttnArgs a,
+                      float *__restrict__ dQ) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int ld = attn_ld(DT), RPB = 16 * NW, NT = NW * 64, KC = 8 * NW, NKT = KC / 16;
+    float *Ks = smem;
+    const int L = a.L, dh = a.dh, ldi = a.ld;
+    const int nrb = (L + RPB - 1) / RPB;
+    const int lid = xcd_major_block_id();
+    const int rb = lid % nrb, bh = lid / nrb, b = bh / a.H, h = bh - b * a.H;
+    int n = lens ? lens[b] : L;
+    n = n < 0 ? 0 : (n > L ? L : n);
+    const size_t base = (size_t)b * L * ldi + (size_t)h * dh;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int row = rb * RPB + wave * 16 + j;
+    const bool rok = row < L;
+    const float *dsrow = dS_ws + ((size_t)bh * L + (rok ? row : L - 1)) * L;
+    const bool vds = (L & 3) == 0 && (reinterpret_cast<uintptr_t>(dS_ws) & 15) == 0;
+    f32x4 dq[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    RowStage<KC, ld, NT> kst;
+    kst.load(K + base, ldi, dh, 0, n, tid);
+    auto load_ds = [&](int kc, f32x4 (&d)[NKT]) {
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            const int k0 = kc + 16 * kt + 4 * g;
+            if (vds) d[kt] = *reinterpret_cast<const f32x4 *>(dsrow + (k0 + 3 < L ? k0 : 0));
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d[kt][r] = dsrow[k0 + r < L ? k0 + r : 0];
+            }
+        }
+    };
+    f32x4 dsn[NKT];
+    load_ds(0, dsn);
+    for (int kc = 0; kc < n; kc += KC) {
+        __syncthreads();
+        kst.store(Ks, dh, kc, n, tid);
+        __syncthreads();
+        f32x4 ds[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ds[kt][r] = (rok && kc + 16 * kt + 4 * g + r < n) ? dsn[kt][r] : 0.0f;
+        if (kc + KC < n) { kst.load(K + base, ldi, dh, kc + KC, n, tid); load_ds(kc + KC, dsn); }
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float *krow = Ks + (size_t)(16 * kt + 4 * g + r) * ld + j;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) dq[dt] = mfma4(krow[16 * dt], ds[kt][r], dq[dt]);
+            }
+        }
+    }
+    if (!rok) return;
+    const bool vec = ((dh & 3) == 0) && ((ldi & 3) == 0) && ((reinterpret_cast<uintptr_t>(dQ + base) & 15) == 0);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        const int d = 16 * dt + 4 * g;
+        float *dst = dQ + base + (size_t)row * ldi + d;
+        if (vec) { if (d < dh) *reinterpret_cast<f32x4 *>(dst) = dq[dt]; }
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (d + e < dh) dst[e] = dq[dt][e];
+        }
+    }
+}
+
 // ============================================================================================ backward: dK, dV
 template <int DT, int NW>
 __global__ void __launch_bounds__(NW * 64, PTR_ATTN_MINBLK_BWD)
 mhsa_bwd_dkv_kernel(const float *__restrict__ Q, const float *__restrict__ K, const float *__restrict__ V,
                     const float *__restrict__ dO, const float *__restrict__ LSE, const float *__restrict__ Dv,
-                    const int32_t *__restrict__ lens, AttnArgs a, float *__restrict__ dK, float *__restrict__ dV) {
+                    const int32_t *__restrict__ lens, AttnArgs a, float *__restrict__ dK, float *__restrict__ dV,
+                    float *__restrict__ dS_ws /* nullable: [B*H][L][L] scaled dS for mhsa_bwd_dq_ds_kernel */) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int ld = attn_ld(DT), KPB = 16 * NW, NT = NW * 64;
     float *Qs = smem, *Gs = Qs + (size_t)kRC * ld;
@@ -487,6 +564,9 @@ mhsa_bwd_dkv_kernel(const float *__restrict__ Q, const float *__restrict__ K, co
                 if (thr != 0) keep = drop_keep1(a.seed_lo, a.seed_hi, a.site, bh * L + row, key, thr) ? keep_inv : 0.0f;
                 pd[r] = pr * keep;
                 ds[r] = pr * (dp[r] * keep - D_s[lr]) * a.inv_scale;
+                // r3: hand dS to the dQ kernel instead of letting it recompute S and dP (two of its three GEMM units): 4 L^2 bytes per
+                // (query, head) through HBM — 0.54 GB per layer at config 5, cheap against 157 TFLOP/s of fp32 MFMA
+                if (dS_ws && row < L && key < L) dS_ws[((size_t)bh * L + row) * L + key] = ds[r];
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -723,7 +803,7 @@ extern "C" int ptr_mhsa_forward(const float *Q, const float *K, const float *V, 
 
 extern "C" int ptr_mhsa_backward(const float *Q, const float *K, const float *V, int ld_qkv, const float *O, const float *dO,
                                  const float *lse, const int32_t *lens, int B, int L, int F, int n_heads, float p_drop, uint64_t seed,
-                                 int site, float *dvec, float *dQ, float *dK, float *dV, void *stream) {
+                                 int site, float *dvec, float *dQ, float *dK, float *dV, float *ds_ws, void *stream) {
     using namespace ptr;
     const char *who = "ptr_mhsa_backward";
     AttnArgs a;
@@ -752,13 +832,26 @@ extern "C" int ptr_mhsa_backward(const float *Q, const float *K, const float *V,
             const size_t lds = ((size_t)2 * kRC * attn_ld(D) + 2 * kRC) * sizeof(float);
             if (int e = allow_lds(kern, lds)) return e;
             const int nkb = (L + KPB - 1) / KPB;
-            hipLaunchKernelGGL(kern, dim3((unsigned)((size_t)B * n_heads * nkb)), dim3(NW * 64), lds, st, Q, K, V, dO, lse, dvec, lens, a, dK, dV);
+            hipLaunchKernelGGL(kern, dim3((unsigned)((size_t)B * n_heads * nkb)), dim3(NW * 64), lds, st, Q, K, V, dO, lse, dvec, lens, a, dK, dV, ds_ws);
+            return check_hip(hipGetLastError(), who);
+        };
+        auto launch_dq_ds = [&]<int NW>() -> int {
+            constexpr int RPB = 16 * NW;
+            auto kern = mhsa_bwd_dq_ds_kernel<D, NW>;
+            const size_t lds = (size_t)8 * NW * attn_ld(D) * sizeof(float);
+            if (int e = allow_lds(kern, lds)) return e;
+            const int nrb = (L + RPB - 1) / RPB;
+            hipLaunchKernelGGL(kern, dim3((unsigned)((size_t)B * n_heads * nrb)), dim3(NW * 64), lds, st, K, ds_ws, lens, a, dQ);
             return check_hip(hipGetLastError(), who);
         };
         const bool w8 = attn_waves() == 8 && L > 64 && D <= 6;     // the 8-wave variants of the widest heads would spill
+        const bool kv8 = L > 64 && (D >= 7 || attn_waves() == 8);   // 4-wave dK/dV variants of the widest heads spill more
+        if (ds_ws) {   // dK / dV first (it writes dS), then dQ as ONE GEMM unit from the stored dS
+            if (int rc = kv8 ? launch_dkv.template operator()<8>() : launch_dkv.template operator()<4>()) return rc;
+            return w8 ? launch_dq_ds.template operator()<8>() : launch_dq_ds.template operator()<4>();
+        }
         int rc = w8 ? launch_dq.template operator()<8>() : launch_dq.template operator()<4>();
         if (rc) return rc;
-        const bool kv8 = L > 64 && (D >= 7 || attn_waves() == 8);   // 4-wave dK/dV variants of the widest heads spill more
         return kv8 ? launch_dkv.template operator()<8>() : launch_dkv.template operator()<4>();
     });
 }

@@ -32,7 +32,13 @@
 namespace ptr {
 
 constexpr int kSR = 32;            // rows per slab
-constexpr int kBW = 8;             // waves per workgroup
+#ifndef BWD_WAVES
+#define BWD_WAVES 8
+#endif
+// waves per workgroup: 8 (2 per SIMD, <= 256 VGPRs; the kernel uses 245).  -DBWD_WAVES=12 builds the three-waves-per-SIMD form (waves 8..11
+// multiply dW tiles only, <= 168 VGPRs) — measured r3: the chain waves (50 W^T fragment registers + chain operands + accumulators) do not
+// fit, 140 registers spill; an experiment switch, not a product path.
+constexpr int kBW = BWD_WAVES;
 constexpr int kBT = kBW * 64;
 constexpr int kSlabF = kSR * kAL;  // floats of one activation / dZ image
 // The short VALU / LDS / VMEM bursts that prepare the next slab run at raised wave priority: beside a partner wave that streams
@@ -76,10 +82,15 @@ template <int NL, int NT1> struct TileMap {
             for (int n = 0; n < ntl(l); ++n)
                 for (int m = 0; m < 7; ++m) { tl[id] = l; tn[id] = n; tm[id] = m; ++id; }
         bool taken[NT] = {};
+        // chain phase c: the waves without a chain tile (7 .. kBW-1) each multiply a 3 x 2 block of dW_{NL-1-c}, whose dZ is already
+        // available: block e = wave - 7 -> in-tile pair {ntl-2-2(e/2), ntl-1-2(e/2)} x out-tile triple {3(e%2) .. 3(e%2)+2}
         for (int c = 0; c < CH; ++c) {
             const int l = NL - 1 - c;
-            for (int t = 0; t < NT; ++t)
-                if (tl[t] == l && tn[t] >= ntl(l) - 2 && tm[t] < 3) { taken[t] = true; lst[7][c][cnt[7][c]++] = t; }
+            for (int v = 7; v < kBW; ++v) {
+                const int e = v - 7, n0 = ntl(l) - 2 - 2 * (e / 2), m0 = 3 * (e % 2);
+                for (int t = 0; t < NT; ++t)
+                    if (tl[t] == l && tn[t] >= n0 && tn[t] < n0 + 2 && tm[t] >= m0 && tm[t] < m0 + 3 && n0 >= 0) { taken[t] = true; lst[v][c][cnt[v][c]++] = t; }
+            }
         }
         // all-wave phase: waves 0..6 (which also hold the chain weights) get layer-pure runs of `take[l]` tiles in (nt, mt) order
         // (at most 7 dZ fragments + 3-4 A fragments per k-step); wave 7 collects every layer's leftover
@@ -209,7 +220,8 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
     using TMt = TileMap<NL, NT1>;
     constexpr int CH = NL - 1, LDX = ldx_of(NT1), NTMAX = NT1 > 7 ? NT1 : 7;
     constexpr int NACC = kTM<NL, NT1>.ntiles[W];
-    constexpr bool loader = W < 4;                        // X staging + early DMA issue; the others: top-layer pass + late DMA issue
+    constexpr bool loader = W < 4;                        // X staging + early DMA issue; the others: late DMA issue
+    constexpr bool topper = W >= 4 && W < 8;              // top-layer pass (252 threads of waves 4..7)
     const int F = a.F, R = a.R;
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
     float *bufA = smem;                                   // [2][NL][kSlabF]  stored activations (top layer: dZ in place)
@@ -330,7 +342,7 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
     for (int i = 0; i < (CH > 1 ? CH - 1 : 1); ++i) dbc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 dbt4 = f32x4{0.f, 0.f, 0.f, 0.f};
     auto top_pass = [&](int buf, int tid_o) {
-      if constexpr (!loader) {
+      if constexpr (topper) {
         const int t = tid_o - 256;
         const int rs = t / 28, f4 = t - rs * 28;
         const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wo + 4 * f4);
@@ -448,7 +460,7 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
     }
     if (loader) finish_x(slab, 0, tid);
     wg_barrier();
-    if (!loader) top_pass(0, tid);
+    if (topper) top_pass(0, tid);
     wg_barrier();
 
     for (; slab < nslabs; slab += gridDim.x, p ^= 1) {
@@ -501,7 +513,7 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
                     if constexpr (c < CH - 1) dbc[c] += d;            // db_{l-1}: column sum of the dZ image just produced (rows >= R are 0)
                 }
             } else {
-                dw_phase(std::integral_constant<int, 7>{}, c_, cur, XSb + p * kSR * LDX);
+                dw_phase(std::integral_constant<int, W>{}, c_, cur, XSb + p * kSR * LDX);
             }
             if constexpr (c == 0) {
                 if constexpr (!loader) { PREP_BEGIN(); issue_dma(next, p ^ 1, lane_o); load_x(next, tid_o); PREP_END(); }
@@ -521,7 +533,7 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
         BWD_STAMP(1 + 2 * CH);
         dw_phase(std::integral_constant<int, W>{}, std::integral_constant<int, CH>{}, cur, XSb + p * kSR * LDX);
         BWD_STAMP(2 + 2 * CH);
-        if constexpr (!loader) { PREP_BEGIN(); top_pass(p ^ 1, tid_o); PREP_END(); }
+        if constexpr (topper) { PREP_BEGIN(); top_pass(p ^ 1, tid_o); PREP_END(); }
         BWD_STAMP(3 + 2 * CH);
         wg_barrier();
         BWD_STAMP(4 + 2 * CH);
@@ -573,7 +585,7 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
     };
     store_tiles(std::integral_constant<int, W>{});
     // d w_out / d b_out: fixed-order sums over the 9 row slots of the top-layer pass (Zb is free after the last barrier)
-    if (!loader) {
+    if (topper) {
         const int t = tid - 256, rs = t / 28, f4 = t - rs * 28;
         if (rs < 9) {
             *reinterpret_cast<f32x4 *>(Zb + rs * kAL + 4 * f4) = dwo4;
@@ -623,7 +635,15 @@ mlp_bwd_fused_kernel(const float *__restrict__ X, const float *__restrict__ P, c
         case 4: bwd_body<NL, NT1, 4>(X, P, acts, dpreds, a, ws, np_stride, smem); break;
         case 5: bwd_body<NL, NT1, 5>(X, P, acts, dpreds, a, ws, np_stride, smem); break;
         case 6: bwd_body<NL, NT1, 6>(X, P, acts, dpreds, a, ws, np_stride, smem); break;
+#if BWD_WAVES == 12
+        case 7: bwd_body<NL, NT1, 7>(X, P, acts, dpreds, a, ws, np_stride, smem); break;
+        case 8: bwd_body<NL, NT1, 8>(X, P, acts, dpreds, a, ws, np_stride, smem); break;
+        case 9: bwd_body<NL, NT1, 9>(X, P, acts, dpreds, a, ws, np_stride, smem); break;
+        case 10: bwd_body<NL, NT1, 10>(X, P, acts, dpreds, a, ws, np_stride, smem); break;
+        default: bwd_body<NL, NT1, 11>(X, P, acts, dpreds, a, ws, np_stride, smem); break;
+#else
         default: bwd_body<NL, NT1, 7>(X, P, acts, dpreds, a, ws, np_stride, smem); break;
+#endif
     }
 }
 

@@ -38,6 +38,19 @@ def _voff(t, floats):
     return C.c_void_p(t.data_ptr() + 4 * floats)
 
 
+DS_SPILL_MAX_BYTES = 8 << 30     # scaled-dS scratch of the attention backward (4 B H L^2 bytes): 0.54 GB at config 5 — 288 GB of HBM3E has room
+
+
+def _ds_scratch(B, H, L, dev):
+    """[B*H*L*L] scratch that lets the dQ kernel be ONE GEMM unit (dS . K) instead of recomputing S and dP (ptr_mhsa_backward's ds_ws);
+    None for short lists (the recomputation is cheap there), beyond DS_SPILL_MAX_BYTES, or with PTR_ATTN_DS_SPILL=0 (A/B runs)."""
+    import os
+    n = B * H * L * L
+    if L < 128 or 4 * n > DS_SPILL_MAX_BYTES or os.environ.get("PTR_ATTN_DS_SPILL", "1") == "0":
+        return None
+    return torch.empty(n, device=dev, dtype=torch.float32)
+
+
 class _MhsaCoreFn(torch.autograd.Function):
     """Three separate [B, L, F] tensors (row stride F)."""
 
@@ -64,10 +77,11 @@ class _MhsaCoreFn(torch.autograd.Function):
         dO = dO.contiguous()
         dQ, dK, dV = torch.empty_like(Q), torch.empty_like(Q), torch.empty_like(Q)
         dvec = torch.empty_like(lse)
+        ds_ws = _ds_scratch(B, n_heads, L, dev)
         with torch.cuda.device(dev):
             _lib.call("ptr_mhsa_backward", _lib.ptr(Q), _lib.ptr(K), _lib.ptr(V), Fdim, _lib.ptr(O), _lib.ptr(dO), _lib.ptr(lse),
                       _lib.ptr(lens), B, L, Fdim, n_heads, C.c_float(p), C.c_uint64(seed), site, _lib.ptr(dvec), _lib.ptr(dQ),
-                      _lib.ptr(dK), _lib.ptr(dV), _lib.current_stream(dev))
+                      _lib.ptr(dK), _lib.ptr(dV), _lib.ptr(ds_ws), _lib.current_stream(dev))
         return dQ, dK, dV, None, None, None, None, None
 
 
@@ -100,10 +114,11 @@ class _MhsaPackedFn(torch.autograd.Function):
         dO = dO.contiguous()
         dqkv = torch.empty_like(qkv)
         dvec = torch.empty_like(lse)
+        ds_ws = _ds_scratch(B, n_heads, L, dev)
         with torch.cuda.device(dev):
             _lib.call("ptr_mhsa_backward", _voff(qkv, 0), _voff(qkv, Fdim), _voff(qkv, 2 * Fdim), F3, _lib.ptr(O), _lib.ptr(dO),
                       _lib.ptr(lse), _lib.ptr(lens), B, L, Fdim, n_heads, C.c_float(p), C.c_uint64(seed), site, _lib.ptr(dvec),
-                      _voff(dqkv, 0), _voff(dqkv, Fdim), _voff(dqkv, 2 * Fdim), _lib.current_stream(dev))
+                      _voff(dqkv, 0), _voff(dqkv, Fdim), _voff(dqkv, 2 * Fdim), _lib.ptr(ds_ws), _lib.current_stream(dev))
         return dqkv, None, None, None, None, None
 
 

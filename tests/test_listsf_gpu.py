@@ -241,3 +241,26 @@ def test_empty_query_and_extreme_scores(LS):
     assert float(o.detach()[1].abs().max()) == 0.0
     assert float(k.grad[1].abs().max()) == 0.0 and float(v.grad[1].abs().max()) == 0.0 and float(q.grad[1].abs().max()) == 0.0
     assert float(k.grad[2, 5:].abs().max()) == 0.0 and float(v.grad[2, 5:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,L,Fd,H,use_lens", [(3, 256, 136, 2, False), (2, 130, 68, 4, True), (2, 200, 24, 2, True), (1, 512, 136, 2, False)])
+def test_attention_backward_from_stored_dS_equals_the_recomputing_kernels(LS, B, L, Fd, H, use_lens, monkeypatch):
+    """r3: with the dS scratch (lists of >= 128 documents) the dK / dV kernel stores the scaled dS and dQ is ONE GEMM unit dS . K; with
+    PTR_ATTN_DS_SPILL=0 the dQ kernel recomputes S and dP.  dK / dV are bit-identical, dQ agrees to fp32 summation order."""
+    from ptranking_amd.listsf import mhsa_core
+    torch.manual_seed(L)
+    Q, K, V = (torch.randn(B, L, Fd, device=DEV) for _ in range(3))
+    dO = torch.randn(B, L, Fd, device=DEV)
+    lens = torch.tensor([L, max(1, L // 3), 7][:B], dtype=torch.int32, device=DEV) if use_lens else None
+    grads = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PTR_ATTN_DS_SPILL", mode)
+        q, k, v = (t.clone().requires_grad_(True) for t in (Q, K, V))
+        O = mhsa_core(q, k, v, H, p_drop=0.1, seed=77, site=3, lens=lens)
+        (O * dO).sum().backward()
+        grads[mode] = (q.grad.clone(), k.grad.clone(), v.grad.clone())
+    assert torch.equal(grads["1"][1], grads["0"][1]) and torch.equal(grads["1"][2], grads["0"][2])
+    d = (grads["1"][0] - grads["0"][0]).abs().max().item()
+    scale = max(1.0, grads["0"][0].abs().max().item())
+    assert d <= 1e-5 * scale, (d, scale)
+    assert torch.isfinite(grads["1"][0]).all()
