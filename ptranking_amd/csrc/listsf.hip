@@ -27,6 +27,7 @@
 namespace ptr {
 
 constexpr int kRC = 32;                // rows per LDS chunk (dK / dV)
+constexpr int kDsPadLd = 20;           // row stride (floats) of the dS transpose pad: 16-byte aligned rows, 80 B = 20 banks apart
 // workgroups per CU the attention kernels are compiled for (register budget): the backward kernels gain 4 % from a third wave per
 // SIMD (<= 168 VGPRs), the forward loses 10 % (measured at 1024 x 256 x 136, 2 heads: scratch/exp_attn.py)
 #ifndef PTR_ATTN_MINBLK_FWD
@@ -492,8 +493,10 @@ mhsa_bwd_dq_ds_kernel(const float *__restrict__ K, const float *__restrict__ dS_
 }
 
 // ============================================================================================ backward: dK, dV
-template <int DT, int NW>
-__global__ void __launch_bounds__(NW * 64, PTR_ATTN_MINBLK_BWD)
+// STORE_DS: the variant that also hands the scaled dS to mhsa_bwd_dq_ds_kernel; compiled for two workgroups per CU (the transpose of the
+// dS tiles does not fit the 168 registers of three: 49 spills, +280 us per launch at config 5)
+template <int DT, int NW, bool STORE_DS>
+__global__ void __launch_bounds__(NW * 64, STORE_DS ? 2 : PTR_ATTN_MINBLK_BWD)
 mhsa_bwd_dkv_kernel(const float *__restrict__ Q, const float *__restrict__ K, const float *__restrict__ V,
                     const float *__restrict__ dO, const float *__restrict__ LSE, const float *__restrict__ Dv,
                     const int32_t *__restrict__ lens, AttnArgs a, float *__restrict__ dK, float *__restrict__ dV,
@@ -502,6 +505,7 @@ mhsa_bwd_dkv_kernel(const float *__restrict__ Q, const float *__restrict__ K, co
     constexpr int ld = attn_ld(DT), KPB = 16 * NW, NT = NW * 64;
     float *Qs = smem, *Gs = Qs + (size_t)kRC * ld;
     float *lse_s = Gs + (size_t)kRC * ld, *D_s = lse_s + kRC;
+    float *ds_pad = D_s + kRC;                            // [NW][16][kDsPadLd] wave-private transpose pads of the dS tiles
     const int L = a.L, F = a.F, dh = a.dh, ldi = a.ld;
     const int nkb = (L + KPB - 1) / KPB;
     const int lid = xcd_major_block_id();
@@ -564,9 +568,30 @@ mhsa_bwd_dkv_kernel(const float *__restrict__ Q, const float *__restrict__ K, co
                 if (thr != 0) keep = drop_keep1(a.seed_lo, a.seed_hi, a.site, bh * L + row, key, thr) ? keep_inv : 0.0f;
                 pd[r] = pr * keep;
                 ds[r] = pr * (dp[r] * keep - D_s[lr]) * a.inv_scale;
-                // r3: hand dS to the dQ kernel instead of letting it recompute S and dP (two of its three GEMM units): 4 L^2 bytes per
-                // (query, head) through HBM — 0.54 GB per layer at config 5, cheap against 157 TFLOP/s of fp32 MFMA
-                if (dS_ws && row < L && key < L) dS_ws[((size_t)bh * L + row) * L + key] = ds[r];
+            }
+            // r3: hand dS to the dQ kernel instead of letting it recompute S and dP (two of its three GEMM units): 4 L^2 bytes per
+            // (query, head) through HBM — 0.54 GB per layer at config 5, cheap against 157 TFLOP/s of fp32 MFMA.  The tile sits in the
+            // C layout (lane = key, registers = 4 rows); it is transposed through a wave-private LDS pad so that every lane stores ONE
+            // float4 of 4 consecutive keys of its row (16 rows x 64 contiguous bytes per tile; scalar stores took 45 % longer than the
+            // whole rest of the kernel).
+            if constexpr (STORE_DS) {
+                float *T = ds_pad + wave * (16 * kDsPadLd);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) T[(4 * g + r) * kDsPadLd + j] = ds[r];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const f32x4 t4 = *reinterpret_cast<const f32x4 *>(T + j * kDsPadLd + 4 * g);       // row 16 rt + j, keys 4 g .. 4 g + 3 of the tile
+                const int srow = rc + 16 * rt + j, skey = key0 + wkey + 4 * g;
+                if (srow < L) {
+                    float *dst = dS_ws + ((size_t)bh * L + srow) * L + skey;
+                    if (skey + 3 < L && ((L & 3) == 0)) *reinterpret_cast<f32x4 *>(dst) = t4;
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (skey + e < L) dst[e] = t4[e];
+                    }
+                }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -828,12 +853,14 @@ extern "C" int ptr_mhsa_backward(const float *Q, const float *K, const float *V,
         };
         auto launch_dkv = [&]<int NW>() -> int {
             constexpr int KPB = 16 * NW;
-            auto kern = mhsa_bwd_dkv_kernel<D, NW>;
-            const size_t lds = ((size_t)2 * kRC * attn_ld(D) + 2 * kRC) * sizeof(float);
-            if (int e = allow_lds(kern, lds)) return e;
+            const size_t lds = ((size_t)2 * kRC * attn_ld(D) + 2 * kRC + (size_t)NW * 16 * kDsPadLd) * sizeof(float);
             const int nkb = (L + KPB - 1) / KPB;
-            hipLaunchKernelGGL(kern, dim3((unsigned)((size_t)B * n_heads * nkb)), dim3(NW * 64), lds, st, Q, K, V, dO, lse, dvec, lens, a, dK, dV, ds_ws);
-            return check_hip(hipGetLastError(), who);
+            auto go = [&](auto kern) -> int {
+                if (int e = allow_lds(kern, lds)) return e;
+                hipLaunchKernelGGL(kern, dim3((unsigned)((size_t)B * n_heads * nkb)), dim3(NW * 64), lds, st, Q, K, V, dO, lse, dvec, lens, a, dK, dV, ds_ws);
+                return check_hip(hipGetLastError(), who);
+            };
+            return ds_ws ? go(mhsa_bwd_dkv_kernel<D, NW, true>) : go(mhsa_bwd_dkv_kernel<D, NW, false>);
         };
         auto launch_dq_ds = [&]<int NW>() -> int {
             constexpr int RPB = 16 * NW;

@@ -27,6 +27,13 @@ python bench.py --loss ApproxNDCG --list-len 512 --features 700 --batch 1024 --s
 python bench.py --loss LambdaRank --list-len 256 --batch 4096 --steps 30 --no-cpu-baseline --sweep= > $OUT/r03_bench_northstar_lambdarank_L256.json 2>/dev/null
 python bench.py --scorer pointsf_default --batch 1024 --steps 30 --warmup 5 --no-cpu-baseline --sweep= > $OUT/r03_bench_default_pointsf_B1024.json 2>/dev/null
 python bench.py --scorer listsf --loss LambdaLoss --list-len 256 --batch 1024 --steps 10 --warmup 2 --windows 2 > $OUT/r03_bench_c5_listsf_lambdaloss_L256.json 2>/dev/null
+# kernel stats of config 5 and of the default-pointsf step
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $OUT/c5stats --output-format csv -- python $ROOT/bench.py --scorer listsf --loss LambdaLoss --list-len 256 --batch 1024 --steps 6 --warmup 2 --windows 1 --no-cpu-baseline > $OUT/c5stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/dpstats --output-format csv -- python $ROOT/bench.py --scorer pointsf_default --batch 1024 --steps 30 --warmup 5 --no-cpu-baseline --sweep= --windows 1 > $OUT/dpstats.log 2>&1
+cd $ROOT
+cp $(find $OUT/c5stats -name '*kernel_stats.csv' | head -1) $OUT/r03_c5_listsf_step_kernel_stats.csv
+cp $(find $OUT/dpstats -name '*kernel_stats.csv' | head -1) $OUT/r03_default_pointsf_step_kernel_stats.csv
 # stand-alone kernels at 65 536 queries
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/kstats --output-format csv -- python $ROOT/profiles/prof_kernels.py run 65536 > $OUT/kstats.log 2>&1
