@@ -250,6 +250,7 @@ def main():
             assert r.tie_shuffle == "device"     # the product default (the reference's B host-side randperm calls per step would dominate)
         r.init()
         r.train_mode()                           # dropout 0.1 active, exactly like the reference's train()
+        dp.seed_replica(SEED)                    # CPU generator identical on every rank, CUDA generator per rank (dp.py)
         return r
 
     def sync():

@@ -89,6 +89,15 @@ def local_dropout_seed(seed, local_rows):
     return fold_row_offset(seed, row0)
 
 
+def seed_replica(seed):
+    """Seed a data-parallel replica: the CPU generator IDENTICALLY on every rank (model initialisation; the base dropout seeds of our
+    kernels, which local_dropout_seed then shifts to the rank's own global rows) and the CUDA generator DIFFERENTLY per rank, so that the
+    torch.nn.Dropout modules left in a scoring function (listsf sublayers) do not repeat their masks across replicas either."""
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed + 7919 * rank())
+
+
 def shard_queries(num_queries, rank_=None, world_=None):
     """Contiguous slice [lo, hi) of the query dimension owned by this rank (remainder spread over the first ranks)."""
     r = rank() if rank_ is None else rank_

@@ -22,6 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
+from . import dp
 from .host import SplitKLinear, build_stacked_ffnet
 from .linear import linear
 
@@ -228,6 +229,8 @@ class MultiheadAttention(nn.Module):
         qkv = linear(batch_rankings, w, b)
         p = self.do_dropout.p if self.training else 0.0
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0      # CPU generator: no device sync
+        if p > 0.0:     # data-parallel replicas draw the masks of THEIR (query, head, document) rows (dp.py): never shared masks
+            seed = dp.local_dropout_seed(seed, batch_rankings.shape[0] * self.n_heads * batch_rankings.shape[1])
         x = mhsa_core_packed(qkv, self.n_heads, p_drop=p, seed=seed, site=self.site, lens=lens)
         self.last_seed = seed
         return self.fc(x)
