@@ -45,3 +45,42 @@ def test_bench_prints_one_contract_json_line():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert "64" in d["by_batch"] and d["by_batch"]["64"]["queries_per_s_per_gpu"] > 0
+
+
+def test_pmc_traffic_is_refused_when_stale(tmp_path, monkeypatch):
+    """bench.load_pmc only trusts a PMC traffic file collected on EXACTLY the kernel sources that are built."""
+    sys.path.insert(0, ROOT)
+    import bench
+    h = bench.kernel_source_hash()
+    assert len(h) == 16 and h == bench.kernel_source_hash()
+    good = {"config": {"queries_per_gpu_per_step": 4096, "list_len": 128, "features": 136}, "kernel_source_hash": h,
+            "kernels": {"ptr::mlp_bwd_fused_kernel<3, 9>": {"hbm_bytes_per_launch": 123}}}
+    f = tmp_path / "pmc.json"
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "PMC_FILE", "pmc.json")
+    f.write_text(json.dumps(good))
+    got, src = bench.load_pmc(4096, 128, 136)
+    assert got == {"ptr::mlp_bwd_fused_kernel<3, 9>": 123} and h in src
+    assert bench.load_pmc(1024, 128, 136) == ({}, "shape mismatch")
+    f.write_text(json.dumps(dict(good, kernel_source_hash="0" * 16)))
+    got, src = bench.load_pmc(4096, 128, 136)
+    assert got == {} and src.startswith("stale")
+    f.unlink()
+    assert bench.load_pmc(4096, 128, 136)[0] == {}
+
+
+def test_ring_pair_statistics():
+    """What the LambdaRank ring kernel skips, computed on the host for the bench line: trailing slots of 64 documents that hold one label."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    Y = torch.zeros(3, 128)
+    Y[0, :10] = 1.0                       # slot 1 (documents 64..127) all zero -> 1 of 4 blocks skipped
+    Y[1, :70] = 2.0                       # the label run crosses the slot boundary -> nothing skipped
+    Y[2, :] = 1.0                         # all equal -> everything skipped
+    st = bench.ring_pair_statistics(Y)
+    assert st["slots"] == 2
+    assert abs(st["mean_trailing_pure_slots"] - (1 + 0 + 2) / 3) < 1e-6
+    assert abs(st["blocks_skipped_frac"] - ((1 + 0 + 4) / 3) / 4) < 1e-6
+    eq = [(10 * 9 + 118 * 117) / (128 * 127), (70 * 69 + 58 * 57) / (128 * 127), 1.0]
+    assert abs(st["zero_weight_pairs_frac"] - sum(eq) / 3) < 1e-6
