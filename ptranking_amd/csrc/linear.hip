@@ -84,6 +84,7 @@ linear_fwd_kernel(const float *__restrict__ X, const float *__restrict__ W, cons
     const uint32_t thr = drop_thr(a.p_drop);
     const float inv_keep = a.p_drop > 0.0f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
     const bool vecy = ((a.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);
+    const bool vecg = gate && ((a.ldg & 3) == 0) && ((reinterpret_cast<uintptr_t>(gate) & 15) == 0);
 
     for (int tile = blockIdx.x * kLinWaves + wave; tile < ntiles; tile += gridDim.x * kLinWaves) {
         const int row0 = tile * rows_per_tile;
@@ -161,10 +162,17 @@ linear_fwd_kernel(const float *__restrict__ X, const float *__restrict__ W, cons
                     for (int c = 0; c < 4; ++c) h[c] = fmaxf(h[c], 0.0f);
                 } else if (a.act == PTR_LINEAR_GATE) {
                     if (rok[rt]) {
+                        const float *gp = gate + (size_t)row[rt] * a.ldg + nb;
+                        if (vecg && nb + 3 < N) {                  // one 16-byte load per fragment (r2 issued four scalar loads)
+                            const f32x4 gv = *reinterpret_cast<const f32x4 *>(gp);
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const float gv = nb + c < N ? gate[(size_t)row[rt] * a.ldg + nb + c] : 0.0f;
-                            h[c] *= gv > 0.0f ? inv_keep : 0.0f;
+                            for (int c = 0; c < 4; ++c) h[c] *= gv[c] > 0.0f ? inv_keep : 0.0f;
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const float gv = nb + c < N ? gp[c] : 0.0f;
+                                h[c] *= gv > 0.0f ? inv_keep : 0.0f;
+                            }
                         }
                     }
                 }
