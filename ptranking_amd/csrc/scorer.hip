@@ -103,11 +103,19 @@ __device__ __forceinline__ void stage_vector(float *dst, const float *src, int n
 
 // =================================================================================================== forward
 // LDS: W1s [kHP][ld1] | Wh (NL-1) x [kHP][kH] | B NL x [kHP] | Wo [kHP] | bo + pad [16]
-// w1_global: the first-layer weights stay in global memory (L2-resident) when they do not fit next to the hidden weights.
-__host__ __device__ inline size_t fwd_lds_floats(int F, int NL, bool w1_global) {
-    return (w1_global ? 0 : (size_t)kHP * ld_w1(F)) + (size_t)(NL - 1) * kHP * kH + (size_t)NL * kHP + kHP + 16;
+// First-layer weights that do not fit next to the hidden weights (F above ~157) stay in global memory (L2-resident) and reach the MFMAs
+//   w1_mode 2 (slab): through two LDS slabs of 48 k (three super-steps) that the workgroup stages cooperatively one slab ahead — every
+//                     W1 element is fetched from L2 once per workgroup and group of tiles, and the fragment reads have LDS latency;
+//   w1_mode 1 (stream): by per-wave global loads, when not even the slabs fit (four hidden layers).
+constexpr int kSlabK = 48, kSlabLd = kSlabK + 4;      // 52 = 4 * 13: 8 consecutive rows cover the 32 banks with their float4s
+__host__ __device__ inline size_t fwd_lds_floats(int F, int NL, int w1_mode) {
+    const size_t w1 = w1_mode == 0 ? (size_t)kHP * ld_w1(F) : (w1_mode == 2 ? (size_t)2 * kHP * kSlabLd : 0);
+    return w1 + (size_t)(NL - 1) * kHP * kH + (size_t)NL * kHP + kHP + 16;
 }
-__host__ __device__ inline bool fwd_needs_global_w1(int F, int NL) { return fwd_lds_floats(F, NL, false) * sizeof(float) > 160 * 1024; }
+__host__ __device__ inline int fwd_w1_mode(int F, int NL) {
+    if (fwd_lds_floats(F, NL, 0) * sizeof(float) <= 160 * 1024) return 0;
+    return fwd_lds_floats(F, NL, 2) * sizeof(float) <= 160 * 1024 ? 2 : 1;
+}
 
 #ifdef PTR_FWD_TRACE   // experiment builds: shader-clock stamps of workgroup 0's first tiles behind the predictions (preds is over-allocated)
 #define FWD_STAMP(i) do { if (blockIdx.x == 0 && lane == 0 && ntile_done < 8) { unsigned long long *tr_ = reinterpret_cast<unsigned long long *>(preds + ((R + 3) & ~3) + 4) + (ntile_done * 16 + wave) * 8; tr_[(i)] = clock64(); if ((i) == 0) tr_[4] = wall_clock64(); if ((i) == 3) tr_[5] = wall_clock64(); } } while (0)   /* slots 4/5: 100 MHz real-time counter at tile start / end */
@@ -117,20 +125,20 @@ __host__ __device__ inline bool fwd_needs_global_w1(int F, int NL) { return fwd_
 
 // TQ: K tail of layer 1 (see load_raw): 0 = zero-padded last super-step; 1 / 2 = F mod 16 of 4 / 8 features (VEC, W1 in LDS) taken in
 // 1 / 2 MFMAs per output tile
-template <int RT, int NTHR, bool TRAIN, bool VEC, bool W1G, int TQ>
+template <int RT, int NTHR, bool TRAIN, bool VEC, int W1G, int TQ>
 __global__ void __launch_bounds__(NTHR)
 mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs a, float *__restrict__ preds,
                float *__restrict__ acts) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int F = a.F, NL = a.NL, R = a.R, ld1 = ld_w1(F);
     float *W1s = smem;
-    float *Wh = W1s + (W1G ? 0 : (size_t)kHP * ld1);
+    float *Wh = W1s + (W1G == 0 ? (size_t)kHP * ld1 : (W1G == 2 ? (size_t)2 * kHP * kSlabLd : 0));
     float *Bs = Wh + (size_t)(NL - 1) * kHP * kH;
     float *Wo = Bs + (size_t)NL * kHP;
     const int tid = threadIdx.x, nthr = blockDim.x;
     // output features 96..99: replicated over rows 96..111 of the weight matrices (4x4 MFMA blocks of M tile 6), spread over elements
     // 96 / 100 / 104 / 108 of w_out (lane group g ends up with feature 96 + g), natural in the biases
-    if constexpr (!W1G) stage_matrix(W1s, ld1, P + off_W(0, F), kH, F, false, tid, nthr, kTailReplicate);
+    if constexpr (W1G == 0) stage_matrix(W1s, ld1, P + off_W(0, F), kH, F, false, tid, nthr, kTailReplicate);
     for (int l = 1; l < NL; ++l) stage_matrix(Wh + (size_t)(l - 1) * kHP * kH, kH, P + off_W(l, F), kH, kH, false, tid, nthr, kTailReplicate);
     for (int l = 0; l < NL; ++l) stage_vector(Bs + (size_t)l * kHP, P + off_b(l, F), kH, tid, nthr);
     stage_vector(Wo, P + off_wout(NL, F), kH, tid, nthr, kTailSpread);
@@ -172,29 +180,64 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
     };
     f32x4 xpre[RT];
 #ifndef PTR_FWD_STATIC_TILES
-    // dynamic tile queue per workgroup: the two waves of a SIMD do not progress at the same rate (the older one wins the issue
-    // arbitration: 90 K vs 145 K cycles per tile measured) — with a static split the faster half idles at the end
-    const int tiles_per_block = (ntiles + gridDim.x - 1) / gridDim.x;
-    const int tile_lo = blockIdx.x * tiles_per_block, tile_hi = min(ntiles, tile_lo + tiles_per_block);
-    int *queue = reinterpret_cast<int *>(Wo + kHP + 8);
-    if (tid == 0) *queue = tile_lo + wpb;
-    __syncthreads();
-    int tile = tile_lo + wave;
+    constexpr bool kQueue = W1G != 2;
 #else
-    const int tile_hi = ntiles;
-    int tile = blockIdx.x * wpb + wave;
+    constexpr bool kQueue = false;
 #endif
+    // dynamic tile queue per workgroup: the two waves of a SIMD do not progress at the same rate (the older one wins the issue
+    // arbitration: 90 K vs 145 K cycles per tile measured) — with a static split the faster half idles at the end.
+    // Slab mode (W1G == 2): the waves of a workgroup share the W1 slabs and walk their tiles in LOCKSTEP (one barrier per slab), so a
+    // group of wpb consecutive tiles is assigned statically; a wave whose tile lies past the end runs masked (clamped loads, no stores).
+    const int tiles_per_block = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int tile_lo = kQueue ? blockIdx.x * tiles_per_block : 0, tile_hi = kQueue ? min(ntiles, tile_lo + tiles_per_block) : ntiles;
+    int *queue = reinterpret_cast<int *>(Wo + kHP + 8);
+    int tile = blockIdx.x * wpb + wave;
+    if constexpr (kQueue) {
+        if (tid == 0) *queue = tile_lo + wpb;
+        __syncthreads();
+        tile = tile_lo + wave;
+    }
+    // ---- W1 slabs (W1G == 2): slab sl = W1[:, 48 sl .. 48 sl + 47] as [kHP][kSlabLd] (rows 96..111 = output features 96..99 replicated,
+    // the 4x4 blocks of M tile 6; k >= F zero).  slab_load only issues the global loads (one slab AHEAD, in front of the MFMAs of the
+    // current slab), slab_store commits them to the other buffer behind those MFMAs; one barrier per slab.
+    constexpr int kSlabV = kHP * (kSlabK / 4);                       // float4s per slab
+    constexpr int kSlabU = (kSlabV + NTHR - 1) / NTHR;
+    f32x4 slab_r[W1G == 2 ? kSlabU : 1];
+    int slab_buf = 0;
+    auto slab_load = [&](int sl) {
+        if constexpr (W1G == 2) {
+#pragma unroll
+            for (int u = 0; u < kSlabU; ++u) {
+                const int i4 = tid + u * NTHR, r = i4 / (kSlabK / 4), c = 4 * (i4 - r * (kSlabK / 4));
+                const int wr = r < 96 ? r : 96 + ((r - 96) & 3), k = kSlabK * sl + c;
+                slab_r[u] = *reinterpret_cast<const f32x4 *>(P + (size_t)(wr < kHP ? wr : 0) * F + (k < F ? k : 0));
+            }
+        }
+    };
+    auto slab_store = [&](int sl, int buf) {
+        if constexpr (W1G == 2) {
+#pragma unroll
+            for (int u = 0; u < kSlabU; ++u) {
+                const int i4 = tid + u * NTHR, r = i4 / (kSlabK / 4), c = 4 * (i4 - r * (kSlabK / 4));
+                const bool real = kSlabK * sl + c < F;
+                f32x4 v = slab_r[u];
+                if (!real) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (i4 < kSlabV) *reinterpret_cast<f32x4 *>(W1s + (size_t)buf * kHP * kSlabLd + (size_t)r * kSlabLd + c) = v;
+            }
+        }
+    };
+    if constexpr (W1G == 2) { slab_load(0); slab_store(0, 0); }
     prefetch_first(tile, xpre);
-    for (; tile < tile_hi; ++ntile_done) {
+    for (; (kQueue ? tile : tile - wave) < tile_hi; ++ntile_done) {
         int next_tile = tile_hi;
         auto advance = [&]() {                      // pop the next tile and start its first X loads
-#ifndef PTR_FWD_STATIC_TILES
-            int nxt = 0;
-            if (lane == 0) nxt = atomicAdd(queue, 1);
-            next_tile = __builtin_amdgcn_readfirstlane(nxt);
-#else
-            next_tile = tile + gridDim.x * wpb;
-#endif
+            if constexpr (kQueue) {
+                int nxt = 0;
+                if (lane == 0) nxt = atomicAdd(queue, 1);
+                next_tile = __builtin_amdgcn_readfirstlane(nxt);
+            } else {
+                next_tile = tile + gridDim.x * wpb;
+            }
             prefetch_first(next_tile, xpre);
         };
         const int row0 = tile * rows_per_tile;
@@ -307,21 +350,23 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
         if (NL == 1) advance();
         finish_x(0, xa);
         // A operands (weight fragments): the 7 fragments of a super-step are read as one batch (see the hidden layers below)
-        auto read_w1 = [&](int S, int mt) -> f32x4 {
+        auto read_w1 = [&](int S, int sin, int mt) -> f32x4 {
             const int k0 = 16 * S + 4 * g;
-            if constexpr (W1G) {   // [100][F] in global memory: tile row j of tile mt = feature 16 mt + j, tile 6: feature 96 + (j & 3)
+            if constexpr (W1G == 2) {          // the current slab: super-step sin (0..2) of it
+                return *reinterpret_cast<const f32x4 *>(W1s + (size_t)slab_buf * kHP * kSlabLd + (size_t)(16 * mt + j) * kSlabLd + 16 * sin + 4 * g);
+            } else if constexpr (W1G == 1) {   // [100][F] in global memory: tile row j of tile mt = feature 16 mt + j, tile 6: feature 96 + (j & 3)
                 const int wr = mt < kMT - 1 ? 16 * mt + j : 96 + (j & 3);
                 return *reinterpret_cast<const f32x4 *>(P + (size_t)wr * F + (k0 < F ? k0 : 0));
             } else {
                 return *reinterpret_cast<const f32x4 *>(W1s + (size_t)(16 * mt + j) * ld1 + k0);
             }
         };
-        auto l1_step = [&](int S, f32x4 (&cur)[RT], f32x4 (&nxt)[RT], f32x4 (&nn)[RT]) {
+        auto l1_step = [&](int S, int sin, f32x4 (&cur)[RT], f32x4 (&nxt)[RT], f32x4 (&nn)[RT]) {
             load_raw(S + 2 < nS1 ? S + 2 : 0, nn);            // past the end: a valid address, never consumed
             __builtin_amdgcn_sched_barrier(0);                // the loads stay HERE (the scheduler sinks them towards their use)
             f32x4 wa[kMT];
 #pragma unroll
-            for (int mt = 0; mt < kMT; ++mt) wa[mt] = read_w1(S, mt);
+            for (int mt = 0; mt < kMT; ++mt) wa[mt] = read_w1(S, sin, mt);
             if constexpr (RT > 1) __builtin_amdgcn_sched_barrier(0);
             static_for<kMT>([&](auto mt_) {
                 constexpr int mt = mt_;
@@ -332,9 +377,24 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
             });
             finish_x(S + 1, nxt);                             // S + 1 == nS1: finishes values nobody reads
         };
+        // slab mode: one slab = the three super-steps of a rotation group.  Entering: barrier (the slab is complete in LDS and every
+        // wave has left the other buffer), then the loads of the NEXT slab (slab 0 of the next tile after the last one); leaving: those
+        // loads are committed to the other buffer.
+        auto slab_enter = [&](int S) {
+            if constexpr (W1G == 2) {
+                __syncthreads();
+                slab_load(S + 3 < nS1 ? S / 3 + 1 : 0);
+            }
+        };
+        auto slab_leave = [&](int S) {
+            if constexpr (W1G == 2) {
+                slab_store(S + 3 < nS1 ? S / 3 + 1 : 0, slab_buf ^ 1);
+                slab_buf ^= 1;
+            }
+        };
         // the K tail: tq MFMAs per output tile; A operand = W1[row][16 nSf + tq g + c] straight from the [out][in] layout (W1 in LDS only)
         auto l1_tail = [&](f32x4 (&cur)[RT]) {
-            if constexpr (!W1G) {
+            if constexpr (W1G == 0) {
                 float wt[kMT][2];
 #pragma unroll
                 for (int mt = 0; mt < kMT; ++mt) {
@@ -357,19 +417,25 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
         const int nSm = tq > 0 ? nSf : nS1;
         int S1 = 0;
         for (; S1 + 3 <= nSm; S1 += 3) {                      // branch-free body: the compiler counts the loads in flight exactly
-            l1_step(S1, xa, xb, xc);
-            l1_step(S1 + 1, xb, xc, xa);
-            l1_step(S1 + 2, xc, xa, xb);
+            slab_enter(S1);
+            l1_step(S1, 0, xa, xb, xc);
+            l1_step(S1 + 1, 1, xb, xc, xa);
+            l1_step(S1 + 2, 2, xc, xa, xb);
+            slab_leave(S1);
         }
         const int left = nSm - S1;                            // 0, 1 or 2 leftover super-steps; then the tail reads the next buffer in turn
         if (left == 0) {
             if (tq > 0) l1_tail(xa);
         } else if (left == 1) {
-            l1_step(S1, xa, xb, xc);
+            slab_enter(S1);
+            l1_step(S1, 0, xa, xb, xc);
+            slab_leave(S1);
             if (tq > 0) l1_tail(xb);
         } else {
-            l1_step(S1, xa, xb, xc);
-            l1_step(S1 + 1, xb, xc, xa);
+            slab_enter(S1);
+            l1_step(S1, 0, xa, xb, xc);
+            l1_step(S1 + 1, 1, xb, xc, xa);
+            slab_leave(S1);
             if (tq > 0) l1_tail(xc);
         }
         tile6_finish();
@@ -1003,7 +1069,7 @@ dropout_mask_kernel(MlpArgs a, int site, int n_feat, float *__restrict__ out) {
 static int check_mlp(const char *who, int R, int F, int NL, float p) {
     if (R < 0 || F <= 0 || NL < 1 || NL > kMaxLayers) { set_error("%s: bad shape R=%d F=%d NL=%d", who, R, F, NL); return PTR_ERR_INVALID_ARG; }
     if (!(p >= 0.0f && p < 1.0f)) { set_error("%s: dropout p=%g out of [0,1)", who, (double)p); return PTR_ERR_INVALID_ARG; }
-    const bool w1g = fwd_needs_global_w1(F, NL);
+    const int w1g = fwd_w1_mode(F, NL);
     if (fwd_lds_floats(F, NL, w1g) * sizeof(float) > 160 * 1024 || (w1g && F % 4 != 0) || (F + 15) / 16 > 48) {
         set_error("%s: F=%d with %d hidden layers is outside the fused scorer's range (LDS %zu KB, max 160; F %% 4 == 0 needed "
                   "above ~157 features; F <= 768)", who, F, NL, fwd_lds_floats(F, NL, w1g) * sizeof(float) / 1024);
@@ -1063,7 +1129,7 @@ extern "C" int ptr_mlp_forward(const float *X, const float *params, int R, int F
     if (R > 0 && (!X || !params || !preds || (train && !acts))) { set_error("%s: NULL pointer", who); return PTR_ERR_INVALID_ARG; }
     if (R == 0) return 0;
     MlpArgs a{R, F, NL, train ? p_drop : 0.0f, (uint32_t)seed, (uint32_t)(seed >> 32)};
-    const bool w1g = fwd_needs_global_w1(F, NL);
+    const int w1g = fwd_w1_mode(F, NL);
     const size_t lds = fwd_lds_floats(F, NL, w1g) * sizeof(float);
     const bool vec = (F % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
     // 16 waves x 16-row tiles (4 waves/SIMD) or 8 waves x 32-row tiles (half the weight-fragment LDS reads per MFMA).  Measured
@@ -1081,8 +1147,13 @@ extern "C" int ptr_mlp_forward(const float *X, const float *params, int R, int F
     };
     if (w1g) {   // large F (e.g. Yahoo's 700): W1 streamed from L2, F % 4 == 0 guaranteed by check_mlp
         if (!vec) { set_error("%s: X must be 16-byte aligned for F=%d", who, F); return PTR_ERR_INVALID_ARG; }
-        if (wide) return train ? launch(mlp_fwd_kernel<1, 1024, true, true, true, 0>) : launch(mlp_fwd_kernel<1, 1024, false, true, true, 0>);
-        return train ? launch(mlp_fwd_kernel<2, 512, true, true, true, 0>) : launch(mlp_fwd_kernel<2, 512, false, true, true, 0>);
+        const int force_stream = env_flag("PTR_FWD_W1_STREAM", 0);             // tests / experiments: the per-wave streaming form (read per call)
+        if (w1g == 2 && !force_stream) {
+            if (wide) return train ? launch(mlp_fwd_kernel<1, 1024, true, true, 2, 0>) : launch(mlp_fwd_kernel<1, 1024, false, true, 2, 0>);
+            return train ? launch(mlp_fwd_kernel<2, 512, true, true, 2, 0>) : launch(mlp_fwd_kernel<2, 512, false, true, 2, 0>);
+        }
+        if (wide) return train ? launch(mlp_fwd_kernel<1, 1024, true, true, 1, 0>) : launch(mlp_fwd_kernel<1, 1024, false, true, 1, 0>);
+        return train ? launch(mlp_fwd_kernel<2, 512, true, true, 1, 0>) : launch(mlp_fwd_kernel<2, 512, false, true, 1, 0>);
     }
     // K tail of layer 1 (F mod 16 of 4 or 8 with float4 X loads): no zero-padded k-steps — 136 features: 34 k-steps instead of 36.
     // Measured (B = 4096 x 128 x 136, r3): the hidden-layer K tails alone 383 -> 370 us; with the layer-1 tail on top 373 us — its selects
@@ -1092,10 +1163,10 @@ extern "C" int ptr_mlp_forward(const float *X, const float *params, int R, int F
     auto pick = [&](auto rt_, auto nthr_, auto train_) -> int {
         constexpr int RT_ = decltype(rt_)::value, NT_ = decltype(nthr_)::value;
         constexpr bool TR_ = decltype(train_)::value;
-        if (!vec) return launch(mlp_fwd_kernel<RT_, NT_, TR_, false, false, 0>);
-        if (tq == 2) return launch(mlp_fwd_kernel<RT_, NT_, TR_, true, false, 2>);
-        if (tq == 1) return launch(mlp_fwd_kernel<RT_, NT_, TR_, true, false, 1>);
-        return launch(mlp_fwd_kernel<RT_, NT_, TR_, true, false, 0>);
+        if (!vec) return launch(mlp_fwd_kernel<RT_, NT_, TR_, false, 0, 0>);
+        if (tq == 2) return launch(mlp_fwd_kernel<RT_, NT_, TR_, true, 0, 2>);
+        if (tq == 1) return launch(mlp_fwd_kernel<RT_, NT_, TR_, true, 0, 1>);
+        return launch(mlp_fwd_kernel<RT_, NT_, TR_, true, 0, 0>);
     };
     using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
     using N1024 = std::integral_constant<int, 1024>; using N512 = std::integral_constant<int, 512>;

@@ -55,7 +55,7 @@ def _train_reference(ref, fused, X2d, seed, p, NL):
 # F = 132 / 140: the other widths the single-pass fused backward serves; F = 144 fills all nine 16-feature tiles, leaves no column for the
 # ones column that carries db_0 and therefore takes the layer-wise kernels — its ff_2.bias gradient is checked like the rest
 @pytest.mark.parametrize("F,NL,R", [(136, 3, 2048 + 37), (132, 3, 1500), (140, 3, 777), (144, 3, 1111), (128, 3, 900), (24, 2, 100), (46, 3, 515), (136, 1, 64), (40, 4, 1000), (180, 2, 300), (700, 3, 1111), (256, 3, 640),
-                                    (400, 2, 333)])
+                                    (400, 2, 333), (200, 4, 500), (700, 3, 8 * 32 * 3 + 5)])
 def test_train_forward_backward_match_torch_with_same_masks(F, NL, R, monkeypatch):
     p = 0.1
     fused, ref = make_pair(F, NL, dropout=p)
@@ -89,6 +89,27 @@ def test_layer1_k_tail_form_matches_torch(F, R, monkeypatch):
     out = fused(X)
     monkeypatch.setattr(torch, "randint", torch.randint) if False else None
     exp = _train_reference(ref, fused, X, seed, p, 3)
+    close(out, exp)
+    fused.eval(); ref.eval()
+    with torch.no_grad():
+        close(fused(X), ref(X.cpu()))
+
+
+@pytest.mark.parametrize("F,NL,R", [(700, 3, 1111), (180, 2, 300), (200, 4, 257)])
+@pytest.mark.parametrize("stream", ["0", "1"])
+def test_large_first_layer_slab_and_streaming_forms_agree_with_torch(F, NL, R, stream, monkeypatch):
+    """F above ~157: W1 does not fit in LDS next to the hidden weights.  Default: the workgroup stages 48-column slabs of it (waves in
+    lockstep, static tile groups); four hidden layers leave no room for the slabs and every wave streams its fragments from L2 —
+    PTR_FWD_W1_STREAM=1 selects that form everywhere.  Both against the CPU modules, training (same masks) and eval."""
+    monkeypatch.setenv("PTR_FWD_W1_STREAM", stream)
+    p = 0.1
+    fused, ref = make_pair(F, NL, dropout=p)
+    fused.train()
+    X = torch.randn(R, F, device="cuda")
+    seed = 99 + R
+    monkeypatch.setattr(torch, "randint", lambda *a, **k: torch.tensor([seed]))
+    out = fused(X)
+    exp = _train_reference(ref, fused, X, seed, p, NL)
     close(out, exp)
     fused.eval(); ref.eval()
     with torch.no_grad():
