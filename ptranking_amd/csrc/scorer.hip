@@ -331,6 +331,30 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
                 acc[kMT - 1][rt][0] = g == 0 ? t[0] : (g == 1 ? t[1] : (g == 2 ? t[2] : t[3]));
             }
         };
+        // One super-step of a layer: acc[mt] += A fragment wa[mt] (k-steps c < nc) x B fragment b.  Tiles go in groups of two / three with the
+        // k-step outermost inside a group: consecutive MFMAs write DIFFERENT accumulators (a dependent v_mfma_f32_16x16x4_f32 issues after 40
+        // cycles, an independent one after 32; the 4x4 form of tile 6 needs an s_nop between dependent k-steps) while a group's fragments
+        // die with it (k-step outermost over all seven tiles keeps 28 fragment registers live and spills in the 16-wave form).
+        auto mma_tiles = [&](const f32x4 (&wa)[kMT], const f32x4 (&b)[RT], int nc) {
+            auto one = [&]<int MT>(std::integral_constant<int, MT> mt_, int c) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[MT][rt] = mma(mt_, wa[MT][c], b[rt][c], acc[MT][rt]);
+            };
+            using std::integral_constant;
+#ifdef PTR_FWD_MT_OUTER     // experiment builds: the round-2 order (tile outermost, its four k-steps back to back)
+            static_for<kMT>([&](auto mt_) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (c < nc) one(mt_, c);
+            });
+            return;
+#endif
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (c < nc) { one(integral_constant<int, 0>{}, c); one(integral_constant<int, 1>{}, c); }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (c < nc) { one(integral_constant<int, 2>{}, c); one(integral_constant<int, 3>{}, c); }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (c < nc) { one(integral_constant<int, 4>{}, c); one(integral_constant<int, 5>{}, c); one(integral_constant<int, 6>{}, c); }
+        };
         auto bias_init = [&](const float *b) {
 #pragma unroll
             for (int mt = 0; mt < kMT; ++mt) {
@@ -368,13 +392,7 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
 #pragma unroll
             for (int mt = 0; mt < kMT; ++mt) wa[mt] = read_w1(S, sin, mt);
             if constexpr (RT > 1) __builtin_amdgcn_sched_barrier(0);
-            static_for<kMT>([&](auto mt_) {
-                constexpr int mt = mt_;
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) acc[mt][rt] = mma(mt_, wa[mt][c], cur[rt][c], acc[mt][rt]);
-            });
+            mma_tiles(wa, cur, 4);
             finish_x(S + 1, nxt);                             // S + 1 == nS1: finishes values nobody reads
         };
         // slab mode: one slab = the three super-steps of a rotation group.  Entering: barrier (the slab is complete in LDS and every
@@ -501,13 +519,7 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
                     }
                     if constexpr (RT > 1) __builtin_amdgcn_sched_barrier(0);
                 }
-                static_for<kMT>([&](auto mt_) {
-                    constexpr int mt = mt_;
-#pragma unroll
-                    for (int c = 0; c < (S < kLast ? 4 : 1); ++c)
-#pragma unroll
-                        for (int rt = 0; rt < RT; ++rt) acc[mt][rt] = mma(mt_, wa[mt][c], hin[S][rt][c], acc[mt][rt]);
-                });
+                mma_tiles(wa, hin[S], S < kLast ? 4 : 1);
             }
             tile6_finish();
         }
@@ -656,17 +668,24 @@ mlp_bwd_dz_kernel(const float *__restrict__ P, const float *__restrict__ acts, c
             for (int mt = 0; mt < kMT; ++mt)
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) acc[mt][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // per super-step: the 7 weight fragments as one batch of LDS reads, then the tiles in groups of two / three with the k-step
+            // outermost inside a group — consecutive MFMAs write different accumulators (dependent 16x16x4: 40 cycles, independent: 32)
 #pragma unroll
-            for (int S = 0; S < kMT; ++S)
+            for (int S = 0; S < kMT; ++S) {
+                f32x4 wa[kMT];
 #pragma unroll
-                for (int mt = 0; mt < kMT; ++mt) {
-                    const f32x4 wa = *reinterpret_cast<const f32x4 *>(Wl + (size_t)(16 * mt + j) * kH + 16 * S + 4 * g);
+                for (int mt = 0; mt < kMT; ++mt) wa[mt] = *reinterpret_cast<const f32x4 *>(Wl + (size_t)(16 * mt + j) * kH + 16 * S + 4 * g);
+                auto group = [&](int m0, int m1) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
 #pragma unroll
-                        for (int rt = 0; rt < RT; ++rt)
-                            acc[mt][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c], cur[S][rt][c], acc[mt][rt], 0, 0, 0);
-                }
+                        for (int mt = m0; mt < m1; ++mt)
+#pragma unroll
+                            for (int rt = 0; rt < RT; ++rt)
+                                acc[mt][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mt][c], cur[S][rt][c], acc[mt][rt], 0, 0, 0);
+                };
+                group(0, 2); group(2, 4); group(4, kMT);
+            }
             // gate: a > 0  <=>  kept by dropout AND relu active
 #pragma unroll
             for (int mt = 0; mt < kMT; ++mt)

@@ -31,7 +31,9 @@ python bench.py --scorer listsf --loss LambdaLoss --list-len 256 --batch 1024 --
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/c5stats --output-format csv -- python $ROOT/bench.py --scorer listsf --loss LambdaLoss --list-len 256 --batch 1024 --steps 6 --warmup 2 --windows 1 --no-cpu-baseline > $OUT/c5stats.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/dpstats --output-format csv -- python $ROOT/bench.py --scorer pointsf_default --batch 1024 --steps 30 --warmup 5 --no-cpu-baseline --sweep= --windows 1 > $OUT/dpstats.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/c4stats --output-format csv -- python $ROOT/bench.py --loss ApproxNDCG --list-len 512 --features 700 --batch 1024 --steps 10 --warmup 2 --nbatches 2 --windows 1 --no-cpu-baseline --sweep= > $OUT/c4stats.log 2>&1
 cd $ROOT
+cp $(find $OUT/c4stats -name '*kernel_stats.csv' | head -1) $OUT/r03_c4_step_kernel_stats.csv
 cp $(find $OUT/c5stats -name '*kernel_stats.csv' | head -1) $OUT/r03_c5_listsf_step_kernel_stats.csv
 cp $(find $OUT/dpstats -name '*kernel_stats.csv' | head -1) $OUT/r03_default_pointsf_step_kernel_stats.csv
 # stand-alone kernels at 65 536 queries
