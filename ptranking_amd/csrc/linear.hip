@@ -25,8 +25,6 @@
 
 namespace ptr {
 
-constexpr int kLinWaves = 8;
-constexpr int kLinThreads = kLinWaves * 64;
 
 struct LinArgs {
     int R, K, N;
@@ -40,41 +38,81 @@ struct LinArgs {
 __host__ __device__ inline int lin_ldk(int K) { return (K + 3) / 4 * 4 + 4; }
 
 // Y[r][n0 + n] = epi(sum_k X[r][k] * Wm[n0 + n][k] + bias[n0 + n]),  Wm = W ([N][K] row-major) or, TRANS, W^T with W [K][N].
-template <int MT, int RT, bool TRANS, bool VECX>
-__global__ void __launch_bounds__(kLinThreads)
+// NW waves per workgroup, each walking tiles of 16 * RT documents.  r3: the pipeline of the fused pointsf forward (scorer.hip) —
+//   * weight tile staged with batches of independent loads (a one-load-per-iteration loop waits out an L2 round trip per element; the
+//     transposed form also divided by a run-time column count per element: ~10-18 us of prologue in a 200 us kernel);
+//   * X two super-steps ahead through three register buffers that rotate BY NAME (a v_mov rotation reads the newest in-flight loads);
+//   * the MT weight fragments of a super-step as ONE batch of LDS reads, MFMAs in groups of two tiles with the k-step outermost
+//     (consecutive MFMAs write different accumulators);
+//   * zero-padding selects only on a padded last super-step / the tail tile;
+//   * 16 waves x 16-row tiles (4 waves per SIMD) by default, 8 waves x 32-row tiles for A/B (PTR_LIN_WIDE=0).
+template <int MT, int RT, bool TRANS, bool VECX, int NW>
+__global__ void __launch_bounds__(NW * 64)
 linear_fwd_kernel(const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias,
                   const float *__restrict__ gate, LinArgs a, float *__restrict__ Y) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT = NW * 64;
+    constexpr int kAhead = 2;      // X super-steps in flight (three ahead through four buffers measured no different, hot or cold operands)
     const int K = a.K, N = a.N, R = a.R, ldk = lin_ldk(K);
     const int n0 = blockIdx.y * 16 * MT;
     float *Ws = smem;                                  // [16*MT][ldk]
     float *Bs = Ws + (size_t)16 * MT * ldk;            // [16*MT]
     const int tid = threadIdx.x;
-    // ---- stage the weight tile (zero padded) and the bias
-    for (int idx = tid; idx < 16 * MT * ldk; idx += kLinThreads) Ws[idx] = 0.0f;
-    __syncthreads();
+    // ---- stage the weight tile and the bias; the zero padding (rows past N, columns K .. ldk-1) is written by a disjoint pass
+    const int rows = min(16 * MT, N - n0);
     if constexpr (!TRANS) {
-        const int rows = min(16 * MT, N - n0);
         if ((K & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0) {
-            const int k4 = K >> 2;
-            for (int idx = tid; idx < rows * k4; idx += kLinThreads) {
-                const int r = idx / k4, c = idx - r * k4;
-                *reinterpret_cast<f32x4 *>(Ws + (size_t)r * ldk + 4 * c) = *reinterpret_cast<const f32x4 *>(W + (size_t)(n0 + r) * K + 4 * c);
+            const int k4 = K >> 2, n4 = rows * k4;
+            constexpr int U = 4;
+            for (int base = tid; base < n4; base += U * NT) {
+                f32x4 v[U];
+                int r[U], c[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int idx = min(base + u * NT, n4 - 1);
+                    r[u] = idx / k4; c[u] = idx - r[u] * k4;
+                    v[u] = *reinterpret_cast<const f32x4 *>(W + (size_t)(n0 + r[u]) * K + 4 * c[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (base + u * NT < n4) *reinterpret_cast<f32x4 *>(Ws + (size_t)r[u] * ldk + 4 * c[u]) = v[u];
             }
         } else {
-            for (int idx = tid; idx < rows * K; idx += kLinThreads) {
-                const int r = idx / K, c = idx - r * K;
-                Ws[(size_t)r * ldk + c] = W[(size_t)(n0 + r) * K + c];
+            const int n = rows * K;
+            constexpr int U = 4;
+            for (int base = tid; base < n; base += U * NT) {
+                float v[U];
+                int r[U], c[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int idx = min(base + u * NT, n - 1);
+                    r[u] = idx / K; c[u] = idx - r[u] * K;
+                    v[u] = W[(size_t)(n0 + r[u]) * K + c[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (base + u * NT < n) Ws[(size_t)r[u] * ldk + c[u]] = v[u];
             }
         }
-    } else {   // W is [K][N]: Ws[n][k] = W[k][n0 + n], read coalesced along n
-        const int cols = min(16 * MT, N - n0);
-        for (int idx = tid; idx < K * cols; idx += kLinThreads) {
-            const int k = idx / cols, n = idx - k * cols;
-            Ws[(size_t)n * ldk + k] = W[(size_t)k * N + n0 + n];
+    } else {   // W is [K][N]: Ws[n][k] = W[k][n0 + n]; lane = output column (coalesced along n), wave = k class; no per-element division
+        const int tn = tid & 63, tk = tid >> 6;
+        constexpr int U = 4;
+        for (int n = tn; n < rows; n += 64) {
+            for (int k = tk; k < K; k += U * NW) {
+                float v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) v[u] = W[(size_t)min(k + u * NW, K - 1) * N + n0 + n];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (k + u * NW < K) Ws[(size_t)n * ldk + k + u * NW] = v[u];
+            }
         }
     }
-    for (int i = tid; i < 16 * MT; i += kLinThreads) Bs[i] = (bias && n0 + i < N) ? bias[n0 + i] : 0.0f;
+    for (int idx = tid; idx < 16 * MT * ldk; idx += NT) {
+        const int r = idx / ldk, c = idx - r * ldk;
+        if (r >= rows || c >= K) Ws[idx] = 0.0f;
+    }
+    for (int i = tid; i < 16 * MT; i += NT) Bs[i] = (bias && n0 + i < N) ? bias[n0 + i] : 0.0f;
     __syncthreads();
 
     const int lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6;
@@ -86,8 +124,9 @@ linear_fwd_kernel(const float *__restrict__ X, const float *__restrict__ W, cons
     const bool vecy = ((a.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);
     const bool vecg = gate && ((a.ldg & 3) == 0) && ((reinterpret_cast<uintptr_t>(gate) & 15) == 0);
 
-    for (int tile = blockIdx.x * kLinWaves + wave; tile < ntiles; tile += gridDim.x * kLinWaves) {
+    for (int tile = blockIdx.x * NW + wave; tile < ntiles; tile += gridDim.x * NW) {
         const int row0 = tile * rows_per_tile;
+        const bool tile_full = row0 + rows_per_tile <= R;
         int row[RT];
         const float *xrow[RT];
         bool rok[RT];
@@ -109,12 +148,14 @@ linear_fwd_kernel(const float *__restrict__ X, const float *__restrict__ W, cons
                 }
             }
         };
-        auto finish_x = [&](int S, f32x4 (&xb)[RT]) {
-            const int k0 = 16 * S + 4 * g;
+        auto finish_x = [&](int S, f32x4 (&xb)[RT]) {      // uniform branch: only a padded super-step and the tail tile need the selects
+            if (16 * S + 16 > K || !tile_full) {
+                const int k0 = 16 * S + 4 * g;
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
+                for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) xb[rt][c] *= ((k0 + c < K) && rok[rt]) ? 1.0f : 0.0f;
+                    for (int c = 0; c < 4; ++c) xb[rt][c] *= ((k0 + c < K) && rok[rt]) ? 1.0f : 0.0f;
+            }
         };
         f32x4 acc[MT][RT];
 #pragma unroll
@@ -123,24 +164,59 @@ linear_fwd_kernel(const float *__restrict__ X, const float *__restrict__ W, cons
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) acc[mt][rt] = b4;
         }
-        f32x4 xcur[RT], xnxt[RT];
-        load_raw(0, xcur);
-        finish_x(0, xcur);
-        for (int S = 0; S < nS; ++S) {
-            if (S + 1 < nS) load_raw(S + 1, xnxt);
+        auto step = [&](int S, f32x4 (&cur)[RT], f32x4 (&nxt)[RT], f32x4 (&nn)[RT]) {
+            load_raw(S + kAhead < nS ? S + kAhead : 0, nn);   // past the end: a valid address, never consumed
+            __builtin_amdgcn_sched_barrier(0);                // the loads stay HERE (the scheduler sinks them towards their use)
             const int k0 = 16 * S + 4 * g;
+            const float *wp = Ws + (size_t)j * ldk + (k0 < ldk - 3 ? k0 : 0);
+            if constexpr (MT <= 8) {          // all fragments of the super-step as one batch of LDS reads
+                f32x4 wa[MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const f32x4 wa = *reinterpret_cast<const f32x4 *>(Ws + (size_t)(16 * mt + j) * ldk + (k0 < ldk - 3 ? k0 : 0));
+                for (int mt = 0; mt < MT; ++mt) wa[mt] = *reinterpret_cast<const f32x4 *>(wp + (size_t)16 * mt * ldk);
+                if constexpr (RT > 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+                for (int m0 = 0; m0 < MT; m0 += 2)
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt)
-                        acc[mt][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c], xcur[rt][c], acc[mt][rt], 0, 0, 0);
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int mt = m0; mt < (m0 + 2 < MT ? m0 + 2 : MT); ++mt)
+#pragma unroll
+                            for (int rt = 0; rt < RT; ++rt)
+                                acc[mt][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mt][c], cur[rt][c], acc[mt][rt], 0, 0, 0);
+            } else {                          // 9..10 output tiles (X read once for N = 136): fragments per group of two, registers stay <= 128
+#pragma unroll
+                for (int m0 = 0; m0 < MT; m0 += 2) {
+                    f32x4 wa[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) wa[i] = *reinterpret_cast<const f32x4 *>(wp + (size_t)16 * (m0 + i < MT ? m0 + i : m0) * ldk);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            if (m0 + i < MT) {
+#pragma unroll
+                                for (int rt = 0; rt < RT; ++rt)
+                                    acc[m0 + i][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[i][c], cur[rt][c], acc[m0 + i][rt], 0, 0, 0);
+                            }
+                }
             }
-            if (S + 1 < nS) finish_x(S + 1, xnxt);
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) xcur[rt] = xnxt[rt];
+            finish_x(S + 1, nxt);                             // S + 1 == nS: finishes values nobody reads
+        };
+        f32x4 xa[RT], xb[RT], xc[RT];
+        load_raw(0, xa);
+        load_raw(nS > 1 ? 1 : 0, xb);
+        finish_x(0, xa);
+        int S = 0;
+        for (; S + 3 <= nS; S += 3) {
+            step(S, xa, xb, xc);
+            step(S + 1, xb, xc, xa);
+            step(S + 2, xc, xa, xb);
+        }
+        if (nS - S == 1) {
+            step(S, xa, xb, xc);
+        } else if (nS - S == 2) {
+            step(S, xa, xb, xc);
+            step(S + 1, xb, xc, xa);
         }
         // ---- epilogue
 #pragma unroll
@@ -389,11 +465,12 @@ static int lin_num_cus() {
     return n;
 }
 
-// output tiles (of 16) per workgroup: as many as fit 150 KB of LDS next to K inputs, at most 8, padding minimised
-static void lin_tiling(int K, int N, int &MT, int &nblocks) {
+// output tiles (of 16) per workgroup: as many as fit 150 KB of LDS next to K inputs, at most `cap` (10 for the 16-row form — 11 and 12 spill at 128 VGPRs —: N = 136 in ONE
+// block — X is read once instead of twice, 9 tiles instead of 2 x 5; 8 for the 32-row form's registers), padding minimised
+static void lin_tiling(int K, int N, int cap, int &MT, int &nblocks) {
     const int n16 = (N + 15) / 16;
     int mt_max = (int)((150 * 1024) / ((size_t)16 * lin_ldk(K) * sizeof(float) + 64));
-    if (mt_max > 8) mt_max = 8;
+    if (mt_max > cap) mt_max = cap;
     if (mt_max < 1) mt_max = 1;
     nblocks = (n16 + mt_max - 1) / mt_max;
     MT = (n16 + nblocks - 1) / nblocks;
@@ -406,26 +483,34 @@ static int launch_linear(const float *X, int ldx, const float *W, const float *b
     if (!X || !W || !Y || (act == PTR_LINEAR_GATE && !gate)) { set_error("%s: NULL pointer", who); return PTR_ERR_INVALID_ARG; }
     if (!(p_drop >= 0.0f && p_drop < 1.0f)) { set_error("%s: dropout p=%g out of [0,1)", who, (double)p_drop); return PTR_ERR_INVALID_ARG; }
     if (R == 0) return 0;
+    // 16 waves x 16-row tiles (4 waves per SIMD; <= 128 VGPRs) or, PTR_LIN_WIDE=0, the round-2 form 8 waves x 32-row tiles
+    static const int wide = [] { const char *e = getenv("PTR_LIN_WIDE"); return e ? atoi(e) != 0 : 1; }();
     int MT, nby;
-    lin_tiling(K, N, MT, nby);
+    lin_tiling(K, N, wide ? 10 : 8, MT, nby);
     const size_t lds = ((size_t)16 * MT * lin_ldk(K) + 16 * MT) * sizeof(float);
     if (lds > 160 * 1024) { set_error("%s: K=%d does not fit the LDS weight tile", who, K); return PTR_ERR_UNSUPPORTED; }
     LinArgs a{R, K, N, ldx, ldy, ldg, act, p_drop, (uint32_t)seed, (uint32_t)(seed >> 32), site};
-    const int ntiles = (R + 31) / 32;
+    const int nw = wide ? 16 : 8, rpt = wide ? 16 : 32;
+    const int ntiles = (R + rpt - 1) / rpt;
     int gx = lin_num_cus() / nby;
     if (gx < 1) gx = 1;
-    gx = ntiles < gx * kLinWaves ? (ntiles + kLinWaves - 1) / kLinWaves : gx;
+    gx = ntiles < gx * nw ? (ntiles + nw - 1) / nw : gx;
     const bool vecx = ((ldx & 3) == 0) && ((K & 3) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
     auto go = [&](auto kern) -> int {
         if (int e = allow_lds(kern, lds)) return e;
-        hipLaunchKernelGGL(kern, dim3(gx, nby), dim3(kLinThreads), lds, st, X, W, bias, gate, a, Y);
+        hipLaunchKernelGGL(kern, dim3(gx, nby), dim3(nw * 64), lds, st, X, W, bias, gate, a, Y);
         return check_hip(hipGetLastError(), who);
     };
 #define LIN_CASE(M)                                                                                                     \
-    case M: return vecx ? go(linear_fwd_kernel<M, 2, TRANS, true>) : go(linear_fwd_kernel<M, 2, TRANS, false>);
+    case M:                                                                                                             \
+        if (wide) return vecx ? go(linear_fwd_kernel<M, 1, TRANS, true, 16>) : go(linear_fwd_kernel<M, 1, TRANS, false, 16>);   \
+        return vecx ? go(linear_fwd_kernel<M, 2, TRANS, true, 8>) : go(linear_fwd_kernel<M, 2, TRANS, false, 8>);
+#define LIN_CASE_W(M) case M: return vecx ? go(linear_fwd_kernel<M, 1, TRANS, true, 16>) : go(linear_fwd_kernel<M, 1, TRANS, false, 16>);
     switch (MT) {
         LIN_CASE(1) LIN_CASE(2) LIN_CASE(3) LIN_CASE(4) LIN_CASE(5) LIN_CASE(6) LIN_CASE(7) LIN_CASE(8)
+        LIN_CASE_W(9) LIN_CASE_W(10)
     }
+#undef LIN_CASE_W
 #undef LIN_CASE
     set_error("%s: internal tiling error", who);
     return PTR_ERR_UNSUPPORTED;
@@ -436,7 +521,7 @@ static int launch_linear(const float *X, int ldx, const float *W, const float *b
 // 27 TFLOP/s measured); N = 136 is 9 output tiles -> two blocks of MTO = 5.  MTO * NTW <= 24 accumulator tiles (96 registers) per wave.
 static void bw_tiling(int K, int N, int &MTO, int &NTW) {
     const int n_out = (N + 15) / 16, n_in = (K + 15) / 16;
-    const int nbn = (n_out + 7) / 8;
+    const int nbn = (n_out + 7) / 8;               // (r3: 9 tiles per block — N = 136 in one block, 172 VGPRs — measured SLOWER: 191 -> 216 us)
     MTO = (n_out + nbn - 1) / nbn;
     int ntw_max = 24 / MTO;
     if (ntw_max > 4) ntw_max = 4;

@@ -16,7 +16,9 @@ def close(a, b, tol=2e-5, what=""):
 
 
 @pytest.mark.parametrize("R,K,N", [(1000, 136, 128), (777, 128, 256), (515, 256, 512), (300, 512, 136), (2049, 136, 408), (640, 136, 136),
-                                   (333, 512, 1), (100, 10, 100), (65, 100, 1), (4096, 46, 100), (50, 7, 5), (1, 136, 128)])
+                                   (333, 512, 1), (100, 10, 100), (65, 100, 1), (4096, 46, 100), (50, 7, 5), (1, 136, 128),
+                                   # several trips per wave round the tile loop (256 CUs x 16 waves x 16 rows = 65 536 rows per trip), ragged tail
+                                   (140001, 136, 136), (70003, 100, 100), (66000, 34, 200)])
 @pytest.mark.parametrize("bias", [True, False])
 def test_linear_forward_backward_match_torch_cpu(R, K, N, bias):
     from ptranking_amd.linear import linear
@@ -38,6 +40,31 @@ def test_linear_forward_backward_match_torch_cpu(R, K, N, bias):
     close(wg.grad, wr.grad, tol=5e-5, what="dw")
     if bias:
         close(bg.grad, br.grad, tol=5e-5, what="db")
+
+
+@pytest.mark.parametrize("wide", ["0", "1"])
+def test_linear_tile_forms_agree_with_torch(wide, monkeypatch):
+    """16 waves x 16-row tiles (default) and 8 waves x 32-row tiles (PTR_LIN_WIDE=0) of the forward / backward-input kernel: the switch is
+    read once per process, so each form runs in its own interpreter."""
+    import os, subprocess, sys
+    code = (
+        "import torch\n"
+        "from ptranking_amd.linear import linear\n"
+        "torch.manual_seed(5)\n"
+        "for R, K, N in ((3000, 136, 136), (70001, 100, 100), (515, 256, 512), (50, 7, 5)):\n"
+        "    x = torch.randn(R, K); w = torch.randn(N, K) / K ** 0.5; b = torch.randn(N); g = torch.randn(R, N)\n"
+        "    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)\n"
+        "    yr = torch.nn.functional.linear(xr, wr, b); yr.backward(g)\n"
+        "    xg, wg = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True)\n"
+        "    y = linear(xg, wg, b.cuda()); y.backward(g.cuda())\n"
+        "    for a_, b_ in ((y, yr), (xg.grad, xr.grad)):\n"
+        "        d = (a_.detach().cpu().double() - b_.detach().double()).abs().max().item()\n"
+        "        assert d <= 2e-5 * max(1.0, b_.abs().max().item()), (R, K, N, d)\n"
+        "print('forms ok')\n")
+    env = dict(os.environ, PTR_LIN_WIDE=wide)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and "forms ok" in out.stdout, out.stderr[-2000:]
 
 
 def test_linear_reads_strided_rows_in_place_and_is_bit_stable():
