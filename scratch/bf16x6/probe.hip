@@ -122,3 +122,40 @@ template <int NV, bool IMUL> __device__ void body_v(int iters, float *sink, long
 #define VK(name, NV, IM) extern "C" __global__ void __launch_bounds__(1024) name(int iters, float *sink, long long *out) { body_v<NV, IM>(iters, sink, out); }
 VK(v0, 0, false) VK(v2, 2, false) VK(v4, 4, false) VK(v6, 6, false) VK(v8, 8, false) VK(v12, 12, false)
 VK(m1, 1, true) VK(m2, 2, true) VK(m4, 4, true)
+
+// which VALU classes cost matrix-pipe time beside v_mfma_f32_16x16x4_f32?  NV instructions of ONE class per MFMA
+//   CLS 0 v_fma_f32 | 1 v_xor_b32 | 2 v_lshrrev_b32 | 3 v_mul_lo_u32 | 4 v_cmp + v_cndmask (2 instr) | 5 v_max_f32 | 6 v_mul_f32 | 7 v_add_u32
+template <int NV, int CLS> __device__ void body_c(int iters, float *sink, long long *out) {
+    f32x4 acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float a = 1.0f + threadIdx.x * 1e-3f, b = 0.5f + threadIdx.x * 1e-4f;
+    float v[8]; uint32_t h[8];
+    for (int i = 0; i < 8; ++i) { v[i] = a + i; h[i] = threadIdx.x * 2654435761u + i; }
+    const uint32_t c1 = 0x9e3779b1u + threadIdx.x;
+    const long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < NV; ++n) {
+                const int q = (i + n) & 7;
+                if constexpr (CLS == 0) v[q] = fmaf(v[q], 1.0001f, b);
+                else if constexpr (CLS == 1) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(h[q]) : "v"(c1));
+                else if constexpr (CLS == 2) asm volatile("v_lshrrev_b32 %0, 1, %0\n\tv_or_b32 %0, 0x40000000, %0" : "+v"(h[q]));
+                else if constexpr (CLS == 3) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(h[q]) : "v"(c1));
+                else if constexpr (CLS == 4) asm volatile("v_cmp_ge_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(h[q]) : "v"(c1) : "vcc");
+                else if constexpr (CLS == 5) asm volatile("v_max_f32 %0, %0, %1" : "+v"(v[q]) : "v"(b));
+                else if constexpr (CLS == 6) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(v[q]) : "v"(b));
+                else asm volatile("v_add_u32 %0, %0, %1" : "+v"(h[q]) : "v"(c1));
+            }
+        }
+    }
+    const long long t1 = clock64();
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3] + v[i] + (float)h[i];
+    if (s == 123.456f) sink[0] = s;
+    if ((threadIdx.x & 63) == 0) atomicMax((unsigned long long *)&out[blockIdx.x], (unsigned long long)(t1 - t0));
+}
+#define CK(name, NV, CL) extern "C" __global__ void __launch_bounds__(1024) name(int iters, float *sink, long long *out) { body_c<NV, CL>(iters, sink, out); }
+CK(c0, 4, 0) CK(c1, 4, 1) CK(c2, 2, 2) CK(c3, 4, 3) CK(c4, 2, 4) CK(c5, 4, 5) CK(c6, 4, 6) CK(c7, 4, 7)

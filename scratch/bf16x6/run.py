@@ -54,3 +54,17 @@ for wpb in (4, 8, 16):
         cyc = r[:256].mean() / iters / 8          # slowest wave of each workgroup
         ms = e0.elapsed_time(e1)
         print(f"{wpb // 4} wave(s)/SIMD  {what:14s}: {cyc / (wpb // 4):6.1f} SIMD cycles per MFMA (slowest wave);  kernel {ms:7.2f} ms = {ms * 1e6 / (iters * 8 * (wpb // 4)):6.2f} ns per MFMA per SIMD")
+
+print("which VALU classes cost matrix-pipe time: 4 instructions of one class per v_mfma_f32_16x16x4_f32, 4 waves per SIMD (32.0 = free)")
+for name, what in (("c0", "4 x v_fma_f32"), ("c1", "4 x v_xor_b32"), ("c2", "2 x (v_lshrrev_b32 + v_or_b32)"), ("c3", "4 x v_mul_lo_u32"), ("c4", "2 x (v_cmp_ge_u32 + v_cndmask_b32)"),
+                   ("c5", "4 x v_max_f32"), ("c6", "4 x v_mul_f32"), ("c7", "4 x v_add_u32")):
+    iters = 30000
+    a = (C.c_void_p * 3)(C.cast(C.pointer(C.c_int(iters)), C.c_void_p), ptr(sink), ptr(o))
+    for rep in range(2):
+        o.zero_()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        assert hip.hipModuleLaunchKernel(fn(name), 256, 1, 1, 1024, 1, 1, 0, None, a, None) == 0
+        e1.record(); torch.cuda.synchronize()
+    cyc = o.cpu().numpy()[:256].mean() / iters / 8 / 4
+    print(f"   {what:36s}: {cyc:6.1f} SIMD cycles per MFMA (slowest wave); kernel {e0.elapsed_time(e1):6.2f} ms")
