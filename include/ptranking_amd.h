@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PTR_ABI_VERSION 2
+#define PTR_ABI_VERSION 3
 #define PTR_MAX_LIST_LEN 4096
 #define PTR_MAX_CUTOFFS 32
 #define PTR_MLP_ACT_LD 112
@@ -187,6 +187,17 @@ int ptr_adagrad_step(float *param, const float *grad, float *state_sum, int64_t 
                      float weight_decay, int step, void *stream);
 int ptr_rmsprop_step(float *param, const float *grad, float *square_avg, int64_t n, float lr, float alpha, float eps,
                      float weight_decay, void *stream);
+/* ---- the same scorer on bf16 matrix instructions with fp32 results (ABI v3, csrc/scorer_x6.hip) ---------------------------------
+ * Replaces the same reference code as ptr_mlp_forward (ptranking/base/point_ranker.py:45-55, ptranking/base/utils.py:288-356).
+ * Every fp32 operand is split exactly into three bf16 pieces and a product is the sum of the six piece products above 2^-24 (six
+ * v_mfma_f32_16x16x32_bf16 with fp32 accumulation per 32-deep slice): results agree with the fp32-MFMA entry points to fp32 rounding
+ * (error against float64 equal or lower), the arithmetic type of the path stays fp32.  Same operands and `acts` layout as
+ * ptr_mlp_forward; `wimg` is caller-provided scratch of ptr_mlp_x6_ws_bytes(F, NL) bytes (16-byte aligned) that receives the
+ * pre-split weight image (rebuilt by every call: the weights change every step).  Served: F % 4 == 0, 2 <= NL <= 8 (ws_bytes returns
+ * 0 otherwise and the call fails with PTR_ERR_UNSUPPORTED). */
+size_t ptr_mlp_x6_ws_bytes(int F, int NL);
+int ptr_mlp_forward_x6(const float *X, const float *params, int R, int F, int NL, int train, float p_drop, uint64_t seed,
+                       float *preds, float *acts, void *wimg, void *stream);
 /* Test helper: the dropout keep-mask (1.0 / 0.0) of dropout site `site` for an [R][n_feat] activation. */
 int ptr_mlp_dropout_mask(int R, int n_feat, int site, float p_drop, uint64_t seed, float *out, void *stream);
 

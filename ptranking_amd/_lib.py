@@ -11,7 +11,7 @@ import torch  # noqa: F401  — must be imported first so that OUR .so binds to 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PTR_LIB") or os.path.join(_PKG, "libptranking_amd.so")   # PTR_LIB: an experiment build (build.py --variant)
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_LIST_LEN = 4096
 MAX_CUTOFFS = 32
 
@@ -42,6 +42,8 @@ SIGNATURES = {
     "ptr_mlp_forward": [_vp, _vp, _i, _i, _i, _i, _f, _u64, _vp, _vp, _vp],
     "ptr_mlp_backward": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _vp, _vp, _vp, _vp],
     "ptr_mlp_backward_step": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _i, _vp, _vp, _vp, _i, _vp, _vp],
+    "ptr_mlp_x6_ws_bytes": [_i, _i],
+    "ptr_mlp_forward_x6": [_vp, _vp, _i, _i, _i, _i, _f, _u64, _vp, _vp, _vp, _vp],
     "ptr_adam_step": [_vp, _vp, _vp, _vp, C.c_int64, _f, _f, _f, _f, _f, _i, _vp],
     "ptr_adagrad_step": [_vp, _vp, _vp, C.c_int64, _f, _f, _f, _f, _i, _vp],
     "ptr_rmsprop_step": [_vp, _vp, _vp, C.c_int64, _f, _f, _f, _f, _vp],
@@ -66,7 +68,7 @@ SIGNATURES = {
     "ptr_letor_load": [C.c_char_p, _i, _f, C.c_int64, C.c_int32, C.c_int64, _vp, _i, _vp, _vp, _vp],
 }
 _RESTYPES = {"ptr_last_error": C.c_char_p, "ptr_mlp_num_params": C.c_size_t, "ptr_mlp_backward_ws_floats": C.c_size_t,
-             "ptr_mlp_backward_dz_floats": C.c_size_t, "ptr_linear_backward_weight_ws_floats": C.c_size_t, "ptr_bn_ws_floats": C.c_size_t,
+             "ptr_mlp_backward_dz_floats": C.c_size_t, "ptr_mlp_x6_ws_bytes": C.c_size_t, "ptr_linear_backward_weight_ws_floats": C.c_size_t, "ptr_bn_ws_floats": C.c_size_t,
              "ptr_layernorm_backward_ws_floats": C.c_size_t}
 OPTIONAL = set()
 

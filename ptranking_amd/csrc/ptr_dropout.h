@@ -11,6 +11,19 @@ __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
+constexpr uint32_t kDropRowMul = 0x9E3779B1u, kDropFgMul = 0x85EBCA77u, kDropSiteMul = 0xC2B2AE3Du;
+// the generator proper: ks = row * kDropRowMul + fg * kDropFgMul + site * kDropSiteMul + seed_lo (callers that keep the per-lane part of
+// the key in a register and add a scalar per feature group — scorer_x6.hip — enter here)
+__device__ __forceinline__ void drop_bits_key(uint32_t ks, uint32_t seed_hi, uint32_t &w0, uint32_t &w1) {
+    w0 = lowbias32(ks);
+#ifdef PTR_DROP_FULL_HASH
+    w1 = lowbias32(w0 ^ seed_hi ^ 0x68E31DA4u);
+#else
+    uint32_t t = w0 ^ seed_hi ^ 0x68E31DA4u;
+    t ^= t >> 15; t *= 0x2C1B3C6Du; t ^= t >> 13;
+    w1 = t;
+#endif
+}
 // 64 random bits for features [4*fg, 4*fg+3] of `row` at dropout site `site` (site l = the Dropout in front of hidden layer l)
 __device__ __forceinline__ void drop_bits(uint32_t seed_lo, uint32_t seed_hi, int site, int row, int fg, uint32_t &w0, uint32_t &w1) {
     // A VALU instruction takes its cycles away from the matrix pipe of its SIMD (no MFMA / VALU overlap: scratch/clock), and 32-bit
@@ -20,15 +33,8 @@ __device__ __forceinline__ void drop_bits(uint32_t seed_lo, uint32_t seed_hi, in
     // seed_lo enters ADDITIVELY: a replica that owns rows [row0, row0 + n) of a global batch passes seed_lo + row0 * 0x9E3779B1 and draws
     // exactly the masks the single-device run draws for those rows (ptranking_amd/dp.py fold_row_offset) — data-parallel replicas never
     // share masks, and N ranks x B/N queries reproduce one rank x B
-    const uint32_t key = (uint32_t)row * 0x9E3779B1u + ((uint32_t)fg * 0x85EBCA77u + (uint32_t)site * 0xC2B2AE3Du);
-    w0 = lowbias32(key + seed_lo);
-#ifdef PTR_DROP_FULL_HASH
-    w1 = lowbias32(w0 ^ seed_hi ^ 0x68E31DA4u);
-#else
-    uint32_t t = w0 ^ seed_hi ^ 0x68E31DA4u;
-    t ^= t >> 15; t *= 0x2C1B3C6Du; t ^= t >> 13;
-    w1 = t;
-#endif
+    const uint32_t key = (uint32_t)row * kDropRowMul + ((uint32_t)fg * kDropFgMul + (uint32_t)site * kDropSiteMul);
+    drop_bits_key(key + seed_lo, seed_hi, w0, w1);
 }
 __device__ __forceinline__ f32x4 drop4(f32x4 v, uint32_t w0, uint32_t w1, uint32_t thr, float scale) {
     // multiplicative masks on purpose: with a select hipcc sinks the producing global load under the predicate and

@@ -18,7 +18,7 @@ from . import dp
 from . import functional as F_
 from .host import DeviceEvaluator, DeviceTrainLoop, PointScorerRanker, is_multilabel
 from .listsf import FusedListScorerMixin
-from .scorer import FlatAdagrad, FlatAdam, FlatRMSprop, FusedPointScorer, FusedScorerMixin
+from .scorer import FlatAdagrad, FlatAdam, FlatRMSprop, FusedPointScorer, FusedScorerMixin, mlp_forward
 
 RANKER_NAMES = ("RankNet", "LambdaRank", "LambdaLoss", "ApproxNDCG", "ListNet", "ListMLE", "STListNet", "RankCosine", "RankMSE", "SoftRank", "DASALC", "MDPRank")
 
@@ -106,8 +106,7 @@ class FusedStepMixin:
         fuse_step = self.fuse_optimizer_step and not distributed and type(self.optimizer) in (FlatAdam, FlatAdagrad, FlatRMSprop)
         with torch.cuda.device(dev):
             st = _lib.current_stream(dev)
-            _lib.call("ptr_mlp_forward", _lib.ptr(X), _lib.ptr(flat), R, Fd, NL, 1, C.c_float(p), C.c_uint64(seed), _lib.ptr(buf["preds"]),
-                      _lib.ptr(buf["acts"]), st)
+            mlp_forward(X, flat, R, Fd, NL, 1, p, seed, buf["preds"], buf["acts"], dev)
             stop_training = False
             if 'epoch_k' in kwargs and kwargs['epoch_k'] % self.stop_check_freq == 0:
                 stop_training = self.stop_training(buf["preds"])

@@ -10,6 +10,7 @@ still makes runs reproducible); it is statistically, not bit-wise, the same as `
 """
 import ctypes as C
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -52,6 +53,37 @@ def fusable(**kw):
     return fused_kind(**kw) is not None
 
 
+def x6_enabled():
+    """The bf16x6 scorer kernels (csrc/scorer_x6.hip) are the default; PTR_MLP_X6=0 pins the fp32-MFMA kernels (read per call: tests)."""
+    return os.environ.get("PTR_MLP_X6", "1") != "0"
+
+
+_X6_WS = {}
+
+
+def x6_workspace(dev, F, NL):
+    """Scratch for the pre-split weight image of the bf16x6 kernels (None when the configuration is outside their range)."""
+    n = _lib.query("ptr_mlp_x6_ws_bytes", F, NL)
+    if n == 0:
+        return None
+    key = (dev, F, NL)
+    ws = _X6_WS.get(key)
+    if ws is None:
+        ws = _X6_WS[key] = torch.empty(n, device=dev, dtype=torch.uint8)
+    return ws
+
+
+def mlp_forward(X2d, flat, R, F, NL, train, p, seed, preds, acts, dev):
+    """Scorer forward through the C ABI: the bf16x6 entry point when it serves (F, NL), the fp32-MFMA one otherwise."""
+    ws = x6_workspace(dev, F, NL) if x6_enabled() else None
+    if ws is not None:
+        _lib.call("ptr_mlp_forward_x6", _lib.ptr(X2d), _lib.ptr(flat), R, F, NL, int(train), C.c_float(p), C.c_uint64(seed),
+                  _lib.ptr(preds), _lib.ptr(acts), _lib.ptr(ws), _lib.current_stream(dev))
+    else:
+        _lib.call("ptr_mlp_forward", _lib.ptr(X2d), _lib.ptr(flat), R, F, NL, int(train), C.c_float(p), C.c_uint64(seed),
+                  _lib.ptr(preds), _lib.ptr(acts), _lib.current_stream(dev))
+
+
 class _ScorerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X2d, flat, F, NL, p, seed, store):
@@ -61,8 +93,7 @@ class _ScorerFn(torch.autograd.Function):
         train = bool(store or p > 0.0)
         acts = torch.empty((NL, R, ACT_LD), device=dev, dtype=torch.float32) if train else None
         with torch.cuda.device(dev):
-            _lib.call("ptr_mlp_forward", _lib.ptr(X2d), _lib.ptr(flat), R, F, NL, int(train), C.c_float(p), C.c_uint64(seed),
-                      _lib.ptr(preds), _lib.ptr(acts), _lib.current_stream(dev))
+            mlp_forward(X2d, flat, R, F, NL, train, p, seed, preds, acts, dev)
         if store:
             ctx.save_for_backward(X2d, flat, acts)
             ctx.meta = (R, F, NL, p, seed)
