@@ -2,8 +2,8 @@
 //
 // Reference: ptranking/base/point_ranker.py:30-55, ptranking/base/utils.py:288-356 ((Dropout -> Linear -> ReLU) x NL -> Linear).
 //
-// Arithmetic.  An fp32 number is EXACTLY the sum of three bf16 pieces (8 + 8 + 8 mantissa bits, split by truncation: two AND / SUB
-// pairs), so  a * b = a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1) + terms below 2^-24 |a b|:  six v_mfma_f32_16x16x32_bf16
+// Arithmetic.  An fp32 number is EXACTLY the sum of three bf16 pieces (8 + 8 + 8 mantissa bits; split by rounding to nearest, see
+// split_pack2), so  a * b = a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1) + terms below 2^-24 |a b|:  six v_mfma_f32_16x16x32_bf16
 // (fp32 accumulation inside the instruction) do the work of eight v_mfma_f32_16x16x4_f32 at 6 x 16 instead of 8 x 32 issue cycles, with
 // an error against float64 equal to or below the fp32 MFMA's (scratch/bf16x6, tests/test_x6_gpu.py).  The bf16 matrix pipe also runs
 // BESIDE the vector ALU (the fp32 MFMA shares its issue stream), so the dropout generator and the splitting ride in the MFMA gaps.
@@ -32,37 +32,40 @@ constexpr int kX6PlaneBytes = kX6Rows * 32 * 2;    // 7168
 constexpr int kX6SliceBytes = 3 * kX6PlaneBytes;   // 21504 = 21 DMA pieces of 1 KB
 constexpr int kX6Pieces = kX6SliceBytes / 1024;
 constexpr int kX6Ring = 6;                         // slices resident in LDS
-constexpr int kX6Waves = 8;
 
 __host__ __device__ inline int x6_n1(int F) { return (F + 31) / 32; }
 __host__ __device__ inline int x6_nslices(int F, int NL) { return x6_n1(F) + 4 * (NL - 1); }
 __host__ __device__ inline size_t x6_lds_bytes(int NL) { return (size_t)kX6Ring * kX6SliceBytes + ((size_t)NL * kHP + kHP + 16) * sizeof(float); }
 
-// a = p1 + p2 + p3 exactly; each piece has at most 8 significant bits and sits in the upper half of its word
-__device__ __forceinline__ void split3(float a, uint32_t &p1, uint32_t &p2, uint32_t &p3) {
-    const uint32_t b1 = __float_as_uint(a) & 0xffff0000u;
-    const float r1 = a - __uint_as_float(b1);
-    const uint32_t b2 = __float_as_uint(r1) & 0xffff0000u;
-    const float r2 = r1 - __uint_as_float(b2);
-    p1 = b1; p2 = b2; p3 = __float_as_uint(r2);
+// Split by ROUNDING (v_cvt_pk_bf16_f32, round to nearest even): a = p1 + p2 + p3 exactly (|p2| <= 2^-9 |a|, |p3| <= 2^-18 |a|), and the
+// pieces below the first carry either sign — the dropped products a2 b3 + a3 b2 + a3 b3 (<= 2^-26 |a b|) average out.  A split by
+// truncation (two AND / SUB pairs, r3 probe) has all pieces of one sign: on all-positive data every dropped product pulls the same way
+// and the median relative error was 1.6e-7 against 5e-8 for the fp32 MFMA (tests/test_x6_gpu.py all_positive); same instruction count.
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float x0, float x1) {                // {bf16(x0), bf16(x1)} in one dword, element 0 in the low half
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
 }
-// {upper half of x0, upper half of x1} as one dword (element order of a bf16x8 fragment: even index = low half)
-__device__ __forceinline__ uint32_t pack_hi(uint32_t x0, uint32_t x1) { return __builtin_amdgcn_perm(x1, x0, 0x07060302u); }
-
-// ReLU as ONE instruction: v_med3_f32(x, 0, 3e38) (with +inf the compiler folds it back to fmaxf) (fmaxf adds a canonicalising v_max_f32 x, x in front under IEEE mode).  NOT inline asm:
-// the hazard recogniser does not look into asm blocks, and a VALU read of an MFMA result needs software wait states on gfx950 — an asm
-// v_max right behind the last MFMA read stale accumulators (r4: eval forward off by 1e-1 while the training forward, whose dropout hash
-// happened to sit in between, was right).  A NaN activation comes out as 0 or inf here; NaN inputs are not a supported input.
-__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 3.0e38f); }
-
+// two fp32 values -> one dword of each of the three planes
+__device__ __forceinline__ void split_pack2(float x0, float x1, uint32_t &p1, uint32_t &p2, uint32_t &p3) {
+    p1 = cvt_pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(p1 << 16), r1 = x1 - __uint_as_float(p1 & 0xffff0000u);
+    p2 = cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(p2 << 16), s1 = r1 - __uint_as_float(p2 & 0xffff0000u);
+    p3 = cvt_pk_bf16(s0, s1);
+}
 // four consecutive fp32 values -> dwords d, d+1 of the three plane fragments
 __device__ __forceinline__ void split_pack4(const f32x4 v, Frag (&f)[3], int d) {
-    uint32_t x[4][3];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) split3(v[c], x[c][0], x[c][1], x[c][2]);
-#pragma unroll
-    for (int p = 0; p < 3; ++p) { f[p].u[d] = pack_hi(x[0][p], x[1][p]); f[p].u[d + 1] = pack_hi(x[2][p], x[3][p]); }
+    split_pack2(v[0], v[1], f[0].u[d], f[1].u[d], f[2].u[d]);
+    split_pack2(v[2], v[3], f[0].u[d + 1], f[1].u[d + 1], f[2].u[d + 1]);
 }
+
+// ReLU as ONE instruction: v_med3_f32(x, 0, 3e38) (with +inf the compiler folds it back to fmaxf, which adds a canonicalising
+// v_max_f32 x, x in front under IEEE mode).  NOT inline asm: the hazard recogniser does not look into asm blocks, and a VALU read of an MFMA
+// result needs software wait states on gfx950 — an asm v_max right behind the last MFMA read stale accumulators (r4: eval forward off by
+// 1e-1 while the training forward, whose dropout hash happened to sit in between, was right).  A NaN activation comes out as 0 or 3e38
+// here; NaN inputs are not a supported input.
+__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 3.0e38f); }
 
 // ---- weight image: one thread per (slice, out-feature row, lane group g) = 8 k-slots of the three planes
 __global__ void __launch_bounds__(256) x6_prep_kernel(const float *__restrict__ P, int F, int NL, uint8_t *__restrict__ img) {
@@ -104,8 +107,15 @@ __device__ __forceinline__ void x6_glds16(const void *gsrc, uint32_t lds_dst) {
 using x6_rsrc = __amdgpu_buffer_rsrc_t;
 __device__ __forceinline__ x6_rsrc x6_srd(void *p, uint32_t bytes) { return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)bytes, 0x00020000); }
 __device__ __forceinline__ void x6_store16(x6_rsrc srd, uint32_t off, f32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srd, (int)off, 0, 0);
+#ifndef PTR_X6_STORE_AUX
+#define PTR_X6_STORE_AUX 0
+#endif
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srd, (int)off, 0, PTR_X6_STORE_AUX);
 }
+__device__ __forceinline__ f32x4 x6_load16(x6_rsrc srd, uint32_t voff, uint32_t soff) {      // out of range: zeros
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void x6_store4(x6_rsrc srd, uint32_t off, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), srd, (int)off, 0, 0); }
 constexpr uint32_t kX6Oob = 0xFFFFF000u;       // an offset no buffer of ours reaches
 
 #define X6_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16((A).v, (B).v, (C), 0, 0, 0)
@@ -137,22 +147,26 @@ constexpr uint32_t kX6Oob = 0xFFFFF000u;       // an offset no buffer of ours re
 template <int... Ks> struct X6K {};
 template <int R, int K0, int... Ks> constexpr int x6_kget(X6K<K0, Ks...>) { if constexpr (R == 0) return K0; else return x6_kget<R - 1>(X6K<Ks...>{}); }
 
-template <bool TRAIN, bool STORE>
-__global__ void __launch_bounds__(kX6Waves * 64)
+// DT: 16-document tiles per wave.  DT = 2: 8 waves per workgroup (two per SIMD, 256 registers each) — the form that is built.  DT = 4 (4 waves,
+// one per SIMD, 512 registers: nothing spills, half the A-fragment LDS reads per document) was measured in r4 at 261 / 367 us against
+// 240 / 352 us for DT = 2 (eval / training, 524288 x 136): no partner wave to hide a stall behind; its instantiation is not kept.
+template <bool TRAIN, bool STORE, int DT>
+__global__ void __launch_bounds__(16 / DT * 64, DT == 4 ? 1 : 2)
 mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, const uint8_t *__restrict__ img, MlpArgs a,
                   float *__restrict__ preds, float *__restrict__ acts) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_x6[];
+    constexpr int NW = 16 / DT, RPT = 16 * DT, PW = (kX6Pieces + NW - 1) / NW;      // waves, rows per wave tile, DMA pieces per wave and slice
     const int F = a.F, NL = a.NL, R = a.R;
     float *Bs = reinterpret_cast<float *>(smem_x6 + (size_t)kX6Ring * kX6SliceBytes);
     float *Wo = Bs + (size_t)NL * kHP;
     const int tid = threadIdx.x;
-    for (int i = tid; i < NL * kHP; i += kX6Waves * 64) { const int l = i / kHP, c = i - l * kHP; Bs[i] = c < kH ? P[off_b(l, F) + c] : 0.0f; }
-    for (int i = tid; i < kHP + 16; i += kX6Waves * 64) Wo[i] = i < kH ? P[off_wout(NL, F) + i] : (i == kHP ? P[off_wout(NL, F) + kH] : 0.0f);
+    for (int i = tid; i < NL * kHP; i += NW * 64) { const int l = i / kHP, c = i - l * kHP; Bs[i] = c < kH ? P[off_b(l, F) + c] : 0.0f; }
+    for (int i = tid; i < kHP + 16; i += NW * 64) Wo[i] = i < kH ? P[off_wout(NL, F) + i] : (i == kHP ? P[off_wout(NL, F) + kH] : 0.0f);
     __syncthreads();
     const float b_out = Wo[kHP];
 
     const int lane = tid & 63, j = lane & 15, g = lane >> 4, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntiles = (R + 31) >> 5;
+    const int ntiles = (R + RPT - 1) / RPT;
     const uint32_t thr = drop_thr(a.p_drop);
     const float scale = TRAIN ? 1.0f / (1.0f - a.p_drop) : 1.0f;
     const int n1 = x6_n1(F), ns = n1 + 4 * (NL - 1);
@@ -164,12 +178,12 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
     // ---- the weight stream: slice n of the cyclic sequence 0 .. ns-1 lands in ring slot n mod kX6Ring.  Every wave issues three 1 KB
     // pieces per slice (21 pieces: the last waves repeat piece 20 — same bytes to the same place)
     int dma_slice = 0, dma_slot = 0;
-    auto dma_issue = [&]() {
+    auto dma_issue = [&]() __attribute__((always_inline)) {
         const uint8_t *src = img + (size_t)dma_slice * kX6SliceBytes + lane * 16;
         const uint32_t dst = ring + (uint32_t)dma_slot * kX6SliceBytes;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            int q = wave * 3 + i;
+        for (int i = 0; i < PW; ++i) {
+            int q = wave * PW + i;
             q = q < kX6Pieces ? q : kX6Pieces - 1;
             x6_glds16(src + q * 1024, __builtin_amdgcn_readfirstlane(dst + (uint32_t)q * 1024));
         }
@@ -178,25 +192,41 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
     };
 #pragma unroll 1
     for (int d = 0; d < kX6Ring - 1; ++d) dma_issue();
-    static_assert(kX6Ring == 6, "the vmcnt immediates below are 3 * (kX6Ring - 2) and 3 * (kX6Ring - 3)");
-    // slice 0: this wave's pieces have landed when at most the 12 pieces of slices 1..4 are outstanding (vmcnt counts in order)
-    asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+    static_assert(kX6Ring == 6 && (PW == 3 || PW == 6), "the vmcnt immediates below are PW * (kX6Ring - 2) and PW * (kX6Ring - 3) (+ the store margin)");
+    if constexpr (STORE && DT == 2) {    // six more operations behind slices 1..4 (see slice_sync): slice 0 once more, into the free slot
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            x6_glds16(img + (size_t)i * 1024 + lane * 16, __builtin_amdgcn_readfirstlane(ring + (uint32_t)(kX6Ring - 1) * kX6SliceBytes + (uint32_t)i * 1024));
+    }
+    // slice 0: this wave's pieces have landed when at most the pieces of slices 1..4 (+ the extra six) are outstanding (vmcnt counts in order)
+    if constexpr (DT == 4) asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
+    else if constexpr (STORE) asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
     int cur_slot = 0;                // slot of the slice being multiplied
 #ifdef PTR_X6_TRACE     // experiment builds: shader-clock stamps of workgroup 0 at every SYNC (arrival, release) behind the weight image
     unsigned long long *trace = reinterpret_cast<unsigned long long *>(const_cast<uint8_t *>(img) + (size_t)ns * kX6SliceBytes) + wave * 256;
     int nstamp = 0;
-#define X6_STAMP() do { if (blockIdx.x == 0 && lane == 0 && nstamp < 256) trace[nstamp++] = clock64(); } while (0)
+#define X6_STAMP() do { if (blockIdx.x == 0 && lane == 0 && nstamp < 254) { trace[nstamp++] = clock64(); trace[nstamp & 1 ? 255 : 254] = wall_clock64(); if (nstamp == 1) trace[253] = wall_clock64(); } } while (0)   /* [253] / [255]: 100 MHz counter at the first / last stamp */
 #else
 #define X6_STAMP() do { } while (0)
 #endif
     // SYNC in the middle of slice i: this wave's pieces of slice i + 1 have landed (behind them it has issued the 9 pieces of slices
     // i + 2 .. i + 4 at most); barrier: all of slice i + 1 is in LDS and every wave has finished slice i - 1, whose slot takes slice i + 5
-    auto slice_sync = [&]() -> uint32_t {
+    // Training: the activation stores count in vmcnt too (gfx9 has ONE in-order counter for loads and stores) and drain at the HBM write
+    // rate — several steps per epilogue.  Behind the pieces of slice i + 1 a wave has issued, in ANY window of four steps, at least 14 more
+    // vector-memory operations (the 14 stores of a layer's epilogue; in layer 1 the X loads: 4 per step), so 23 may stay outstanding
+    // instead of 9 and the stores drain beside the MFMAs (the compiler's own scratch traffic would only add to the count).  The first
+    // steps of a workgroup get the same margin from six extra DMA pieces issued behind the prologue's (into the slot slice 5 overwrites).
+    auto slice_sync = [&]() __attribute__((always_inline)) -> uint32_t {
         X6_STAMP();
 #ifdef PTR_X6_NOBAR          // ablation builds (wrong results, timing only)
-        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
-        asm volatile("s_waitcnt vmcnt(9)\n\ts_barrier" ::: "memory");
+        // DT = 4: 18 pieces behind slice i + 1, and in any four steps 28 stores (one epilogue) or 32 X loads; the prologue's 24 X loads
+        // give the first steps the same margin
+        if constexpr (DT == 4) { if constexpr (STORE) asm volatile("s_waitcnt vmcnt(46)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory"); }
+        else if constexpr (STORE) asm volatile("s_waitcnt vmcnt(23)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(9)\n\ts_barrier" ::: "memory");
 #endif
         X6_STAMP();
 #ifndef PTR_X6_NODMA
@@ -211,35 +241,37 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
     using lds_f32x4 = __attribute__((address_space(3))) f32x4;
     uint32_t bs_base = x6_lds_addr(Bs) + (uint32_t)g * 16, wo_base = x6_lds_addr(Wo) + (uint32_t)g * 16;
     asm volatile("" : "+v"(bs_base), "+v"(wo_base));
-    auto lds4 = [](uint32_t base, int byte_off) { return *reinterpret_cast<lds_f32x4 *>((uintptr_t)(base + (uint32_t)byte_off)); };
+    auto lds4 = [](uint32_t base, int byte_off) __attribute__((always_inline)) { return *reinterpret_cast<lds_f32x4 *>((uintptr_t)(base + (uint32_t)byte_off)); };
     const uint32_t layer_bytes = (uint32_t)R * (kAL * 4);                       // host: NL * R * 448 < 2^32 - 4096
+    const x6_rsrc xsrd = x6_srd(const_cast<float *>(X), (uint32_t)R * (uint32_t)(F * 4));     // host: R * F * 4 < 2^32 - 4096
+    const x6_rsrc psrd = x6_srd(preds, (uint32_t)R * 4u);
     const x6_rsrc asrd = x6_srd(acts, STORE ? (uint32_t)NL * layer_bytes : 0u);
-    f32x4 acc[kMT][2];
-    Frag bp[4][2][3];               // B fragments of the current hidden layer: [slice][doc tile][plane]
-    Frag bfx[2][2][3];              // layer 1: B fragments of slice s in set s & 1
-    f32x4 raw[2][2];                // layer 1: X values [doc tile][half] of the slice whose fragments are built next
+    f32x4 acc[kMT][DT];
+    Frag bp[4][DT][3];               // B fragments of the current hidden layer: [slice][doc tile][plane]
+    Frag bfx[2][DT][3];              // layer 1: B fragments of slice s in set s & 1
+    f32x4 raw[2][DT][2];             // layer 1: X values of slice s in set s & 1, [doc tile][half] — loaded two steps before their fragments are built
     Frag af[2][3];                  // A fragments of one tile: [set][plane]
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
 
-    auto read_a = [&](Frag (&buf)[3], uint32_t abase, int mt) {
+    auto read_a = [&](Frag (&buf)[3], uint32_t abase, int mt) __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) buf[p].q = *reinterpret_cast<lds_u32x4 *>((uintptr_t)(abase + (uint32_t)(p * kX6PlaneBytes + mt * 1024)));
     };
     // acc[mt][dt] += the six plane products of a slice, small terms first
-    auto mma_tile = [&](const Frag (&buf)[3], auto mt_, const Frag (&bf)[2][3]) {
+    auto mma_tile = [&](const Frag (&buf)[3], auto mt_, const Frag (&bf)[DT][3]) __attribute__((always_inline)) {
         constexpr int mt = decltype(mt_)::value;
         constexpr int kA[6] = {0, 1, 2, 0, 1, 0}, kB[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
         for (int q = 0; q < 6; ++q)
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) acc[mt][dt] = X6_MFMA(buf[kA[q]], bf[dt][kB[q]], acc[mt][dt]);
+            for (int dt = 0; dt < DT; ++dt) acc[mt][dt] = X6_MFMA(buf[kA[q]], bf[dt][kB[q]], acc[mt][dt]);
     };
     // one slice step (see the schedule above).  In: af[AP] = tile 0 of this slice; out: af[AP ^ 1] = tile 0 of the next slice (its base
     // returned).  work(r): the VALU work beside the MFMAs of tile r; Ks: VALU instructions per MFMA of the interleave hint (0 = none)
-    auto slice_step = [&](auto ap_, uint32_t abase, const Frag (&bf)[2][3], auto &&work, auto ks_) -> uint32_t {
+    auto slice_step = [&](auto ap_, uint32_t abase, const Frag (&bf)[DT][3], auto &&work, auto ks_) __attribute__((always_inline)) -> uint32_t {
         constexpr int AP = decltype(ap_)::value;
         uint32_t nb = 0;
-        static_for<kMT>([&](auto r_) {
+        static_for<kMT>([&](auto r_) __attribute__((always_inline)) {
             constexpr int r = decltype(r_)::value;
             constexpr int K = x6_kget<r>(decltype(ks_){});
             if constexpr (r == 3) nb = slice_sync();
@@ -248,45 +280,50 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
             X6_SB();
             mma_tile(af[AP ^ (r & 1)], r_, bf);
             work(r_);
-            if constexpr (K > 0) X6_MIX(12, K);
+            if constexpr (K > 0) X6_MIX(6 * DT, K);
             X6_SB();
         });
         return nb;
     };
     using KNone = X6K<0, 0, 0, 0, 0, 0, 0>;
-    auto nowork = [](auto) {};
+    auto nowork = [](auto) __attribute__((always_inline)) {};
 
     // tiles of 32 documents: workgroup b, wave w, pass it -> tile (it * gridDim.x + b) * 8 + w; every wave of a workgroup runs the same
     // number of passes (lockstep), a wave whose tile lies past the end runs masked (clamped loads, no stores)
-    const int npass = (ntiles + kX6Waves * (int)gridDim.x - 1) / (kX6Waves * (int)gridDim.x);
-    auto tile_of = [&](int it) { return (it * (int)gridDim.x + (int)blockIdx.x) * kX6Waves + wave; };
-    // quarter q = (dt, h) of slice s of `tile`: the float4 a lane contributes to the B fragment
-    auto load_xq = [&](int tile, int s, int q) {
-        const int dt = q >> 1, h = q & 1, k = 32 * s + 8 * g + 4 * h, r = tile * 32 + 16 * dt + j;
-#ifdef PTR_X6_NOX
-        const float *xr = X + (size_t)((r < R ? r : R - 1) & 1023) * F;
-#else
-        const float *xr = X + (size_t)(r < R ? r : R - 1) * F;
-#endif
-        raw[dt][h] = *reinterpret_cast<const f32x4 *>(xr + (k < F ? k : 0));
-    };
-    // quarter q of the X fragment of slice s: input dropout (site 0) + split.  Columns >= F need no masking: their weight planes are zero
-    // and the clamped loads return finite numbers
-    // Dropout keys: key = row * kDropRowMul + fg * kDropFgMul + site * kDropSiteMul + seed_lo (ptr_dropout.h).  The lane-dependent part
-    // (row, lane group g) lives in ONE register per document tile, everything else is a scalar added per use — written as
-    // `g * kDropFgMul + constant` the compiler hoists a register per (tile, site) out of the tile loop and spills them all
-    auto xkey = [&](int tile, int dt) { return (uint32_t)(tile * 32 + 16 * dt + j) * kDropRowMul + (uint32_t)(2 * g) * kDropFgMul + a.seed_lo; };
-    auto make_bq = [&](int s, uint32_t (&xk)[2], Frag (&bf)[2][3], int q) {
+    const int npass = (ntiles + NW * (int)gridDim.x - 1) / (NW * (int)gridDim.x);
+    auto tile_of = [&](int it) __attribute__((always_inline)) { return (it * (int)gridDim.x + (int)blockIdx.x) * NW + wave; };
+    // Per-lane constants, one register each; everything that depends on the tile is a SCALAR added per use (s_mul / s_add on the scalar
+    // unit, one v_add or an soffset operand on the vector side) — per-tile VGPR copies of rows, offsets and keys cost a dozen registers
+    // this kernel does not have:
+    //   jX / jA   byte offset of the lane's 16 (32) bytes inside row j of X / of `acts`
+    //   jH / jK   dropout key parts  j * kDropRowMul + g * kDropFgMul + seed_lo (hidden sites, fg = 4 mt + g) / with 2 g (X site, fg = 8 s + 2 g + h)
+    uint32_t jX = (uint32_t)j * (uint32_t)(F * 4) + (uint32_t)g * 32, jA = (uint32_t)j * (kAL * 4) + (uint32_t)g * 16;
+    uint32_t jH = (uint32_t)j * kDropRowMul + (uint32_t)g * kDropFgMul + a.seed_lo, jK = jH + (uint32_t)g * kDropFgMul;
+    asm volatile("" : "+v"(jX), "+v"(jA), "+v"(jH), "+v"(jK));
+    // quarter q = (dt, h) of slice s of the 32 documents from row t32 on: the float4 a lane contributes to the B fragment.  X is read through
+    // a buffer resource: rows past R get an out-of-range offset (zeros); columns past F read the next row — finite numbers that meet
+    // zero weight planes
+    auto load_xq = [&](f32x4 (&rw)[DT][2], int t32, int s, int q) __attribute__((always_inline)) {
         const int dt = q >> 1, h = q & 1;
-        f32x4 v = raw[dt][h];
+#ifdef PTR_X6_NOX
+        const uint32_t vo = jX, so = (uint32_t)((t32 + 16 * dt) & 1023) * (uint32_t)(F * 4);
+#else
+        const uint32_t vo = j < R - t32 - 16 * dt ? jX : kX6Oob, so = (uint32_t)(t32 + 16 * dt) * (uint32_t)(F * 4);
+#endif
+        rw[dt][h] = x6_load16(xsrd, vo, so + (uint32_t)(128 * s + 16 * h));
+    };
+    // quarter q of the X fragment of slice s: input dropout (site 0, fg = 8 s + 2 g + h) + split
+    auto make_bq = [&](const f32x4 (&rw)[DT][2], int t32, int s, Frag (&bf)[DT][3], int q) __attribute__((always_inline)) {
+        const int dt = q >> 1, h = q & 1;
+        f32x4 v = rw[dt][h];
         if constexpr (TRAIN) {
             uint32_t w0, w1;
-            drop_bits_key(xk[dt] + (uint32_t)(8 * s + h) * kDropFgMul, a.seed_hi, w0, w1);     // site 0, fg = 8 s + 2 g + h
+            drop_bits_key(jK + ((uint32_t)(t32 + 16 * dt) * kDropRowMul + (uint32_t)(8 * s + h) * kDropFgMul), a.seed_hi, w0, w1);
             v = drop4(v, w0, w1, thr, scale);
         }
         split_pack4(v, bf[dt], 2 * h);
     };
-    auto bias_init = [&]() {            // layer 1's bias
+    auto bias_init = [&]() __attribute__((always_inline)) {            // layer 1's bias
 #pragma unroll
         for (int mt = 0; mt < kMT; ++mt) {
             const f32x4 b4 = lds4(bs_base, 64 * mt);
@@ -295,11 +332,13 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
     };
 
     // kernel prologue: the fragments of slice 0 of the first tile, the X values of slice 1, the first A fragment
+    {
+        const int t0 = tile_of(0) * RPT;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) load_xq(tile_of(0), 0, q);
-    uint32_t xk[2] = {xkey(tile_of(0), 0), xkey(tile_of(0), 1)};      // X-site keys of the tile whose layer 1 runs (or is prepared) next
+        for (int q = 0; q < 2 * DT; ++q) { load_xq(raw[0], t0, 0, q); load_xq(raw[1], t0, n1 > 1 ? 1 : 0, q); }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { make_bq(0, xk, bfx[0], q); load_xq(tile_of(0), n1 > 1 ? 1 : 0, q); }
+        for (int q = 0; q < 2 * DT; ++q) { make_bq(raw[0], t0, 0, bfx[0], q); load_xq(raw[0], t0, n1 > 2 ? 2 : 0, q); }
+    }
     bias_init();
     uint32_t abase = lane_a;
     read_a(af[0], abase, 0);
@@ -309,36 +348,27 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
 #pragma unroll 1
     for (int it = 0; it < npass; ++it) {
         const int tile = tile_of(it), tile_next = tile_of(it + 1);
-        int row[2];
-        bool rok[2];
-        uint32_t aoff[2];            // byte offset of this lane's 16 bytes of tile 0 in layer 0 of `acts` (out of range for rows past R)
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            row[dt] = tile * 32 + 16 * dt + j; rok[dt] = row[dt] < R;
-            aoff[dt] = rok[dt] ? (uint32_t)row[dt] * (kAL * 4) + g * 16 : kX6Oob;
-        }
-        uint32_t hk[2];              // hidden-site keys: row and lane group g (fg = 4 mt + g)
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) hk[dt] = (uint32_t)row[dt] * kDropRowMul + (uint32_t)g * kDropFgMul + a.seed_lo;
-
-        // epilogue of out-feature tile mt after the layer in front of dropout site `site`: ReLU, dropout, activation store, split into the
-        // next layer's B fragments
-        auto store_off = [&](int layer, int dt) {       // opaque: `+ 64 mt` stays an immediate instead of seven hoisted select operands
-            uint32_t o = rok[dt] ? aoff[dt] + (uint32_t)layer * layer_bytes : kX6Oob;
+        const int t32 = tile * RPT, t32n = tile_next * RPT;        // first row of this / the next tile
+        auto store_off = [&](int layer, int dt) __attribute__((always_inline)) {       // opaque: `+ 64 mt` stays an immediate instead of seven hoisted select operands
+#ifdef PTR_X6_L2STORE      // ablation: the same store instructions, aimed at an L2-resident part of the buffer
+            uint32_t o = j < R - t32 - 16 * dt ? jA + ((uint32_t)((t32 + 16 * dt) & 2047) * (kAL * 4)) : kX6Oob;
+#else
+            uint32_t o = j < R - t32 - 16 * dt ? jA + ((uint32_t)(t32 + 16 * dt) * (kAL * 4) + (uint32_t)layer * layer_bytes) : kX6Oob;
+#endif
             asm volatile("" : "+v"(o));
             return o;
         };
-        auto epilogue = [&](auto mt_, int site) {
+        auto epilogue = [&](auto mt_, int site) __attribute__((always_inline)) {
             constexpr int mt = decltype(mt_)::value;
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
+            for (int dt = 0; dt < DT; ++dt) {
                 f32x4 h = acc[mt][dt];
                 acc[mt][dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};        // the next layer's first MFMA takes the inline constant: no live registers
 #pragma unroll
                 for (int c = 0; c < 4; ++c) h[c] = relu1(h[c]);
                 if constexpr (TRAIN) {
                     uint32_t w0, w1;
-                    drop_bits_key(hk[dt] + ((uint32_t)(4 * mt) * kDropFgMul + (uint32_t)site * kDropSiteMul), a.seed_hi, w0, w1);
+                    drop_bits_key(jH + ((uint32_t)(t32 + 16 * dt) * kDropRowMul + (uint32_t)(4 * mt) * kDropFgMul + (uint32_t)site * kDropSiteMul), a.seed_hi, w0, w1);
                     h = drop4(h, w0, w1, thr, scale);
                 }
                 if constexpr (STORE) {
@@ -359,13 +389,15 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
         };
         // last hidden activation + output layer (100 -> 1): VALU dot product per lane, reduced over the 4 lane groups at the end;
         // the accumulators restart from the bias of layer 1
-        float sc[2] = {0.0f, 0.0f};
-        auto epilogue_out = [&](auto mt_) {
+        float sc[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) sc[dt] = 0.0f;
+        auto epilogue_out = [&](auto mt_) __attribute__((always_inline)) {
             constexpr int mt = decltype(mt_)::value;
             const f32x4 w4 = lds4(wo_base, 64 * mt);
             const f32x4 bn = lds4(bs_base, 64 * mt);
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
+            for (int dt = 0; dt < DT; ++dt) {
                 f32x4 h = acc[mt][dt];
                 acc[mt][dt] = bn;
 #pragma unroll
@@ -379,19 +411,26 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
         };
 
         // ---- layer 1.  Step s multiplies bfx[s & 1] and, beside the MFMAs of tiles 0 / 1 / 3 / 4, builds quarter q of the fragments of
-        // slice s + 1 from `raw` into bfx[(s + 1) & 1], reloading the quarter with slice s + 2 (past the end: a valid address, never used)
-        auto l1_step = [&](auto par_, int s) {
+        // slice s + 1 from raw[(s + 1) & 1] into bfx[(s + 1) & 1], reloading the quarter with slice s + 3 (past the end: a valid address,
+        // never used).  Two steps of distance: in training the loads queue behind the activation stores of the last epilogue (vmcnt is
+        // one in-order counter), and a load consumed one step after a 14-store burst stalled the whole lockstep workgroup (r4 trace)
+        auto l1_step = [&](auto par_, int s) __attribute__((always_inline)) {
             constexpr int PAR = decltype(par_)::value;
-            abase = slice_step(par_, abase, bfx[PAR], [&](auto r_) {
+            abase = slice_step(par_, abase, bfx[PAR], [&](auto r_) __attribute__((always_inline)) {
                 constexpr int r = decltype(r_)::value;
-                constexpr int q = r == 0 ? 0 : r == 1 ? 1 : r == 3 ? 2 : r == 4 ? 3 : -1;
-                if constexpr (q >= 0) { make_bq(s + 1, xk, bfx[PAR ^ 1], q); load_xq(tile, s + 2 < n1 ? s + 2 : 0, q); }
-            }, X6K<KX, KX, 0, KX, KX, 0, 0>{});
+                auto quarter = [&](int q) __attribute__((always_inline)) { make_bq(raw[PAR ^ 1], t32, s + 1, bfx[PAR ^ 1], q); load_xq(raw[PAR ^ 1], t32, s + 3 < n1 ? s + 3 : 0, q); };
+                if constexpr (DT == 2) {            // quarters 0..3 beside tiles 0, 1, 3, 4
+                    constexpr int q = r == 0 ? 0 : r == 1 ? 1 : r == 3 ? 2 : r == 4 ? 3 : -1;
+                    if constexpr (q >= 0) quarter(q);
+                } else {                            // eight quarters: two beside tile 0, one beside each other tile
+                    if constexpr (r == 0) { quarter(0); quarter(1); } else quarter(r + 1);
+                }
+            }, std::conditional_t<DT == 2, X6K<KX, KX, 0, KX, KX, 0, 0>, X6K<KX, KX / 2, KX / 2, KX / 2, KX / 2, KX / 2, KX / 2>>{});
         };
         // the last slice of layer 1: the epilogue of a tile rides beside the MFMAs of the next one
-        auto l1_last = [&](auto par_) {
+        auto l1_last = [&](auto par_) __attribute__((always_inline)) {
             constexpr int PAR = decltype(par_)::value;
-            abase = slice_step(par_, abase, bfx[PAR], [&](auto r_) {
+            abase = slice_step(par_, abase, bfx[PAR], [&](auto r_) __attribute__((always_inline)) {
                 constexpr int r = decltype(r_)::value;
                 if constexpr (r > 0) epilogue(std::integral_constant<int, r - 1>{}, 1);
             }, X6K<0, KE, KE, KE, KE, KE, KE>{});
@@ -408,26 +447,27 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
         if (s < n1 - 1) { l1_step(I0{}, s); l1_last(I1{}); } else { l1_last(I0{}); }
 
         // ---- hidden layers 2 .. NL: B fragments = the registers the previous epilogue left
-        auto hidden = [&](auto lastlayer_, int l) {
+        auto hidden = [&](auto lastlayer_, int l) __attribute__((always_inline)) {
             constexpr bool LAST = decltype(lastlayer_)::value;
             abase = slice_step(I0{}, abase, bp[0], nowork, KNone{});
             abase = slice_step(I1{}, abase, bp[1], nowork, KNone{});
-            if constexpr (LAST) {                    // the next tile's first X slice (past the end: clamped rows, never used)
+            if constexpr (LAST) {                    // the next tile's first two X slices, in front of this layer's store burst
 #pragma unroll
-                for (int q = 0; q < 4; ++q) load_xq(tile_next, 0, q);
-                xk[0] = xkey(tile_next, 0); xk[1] = xkey(tile_next, 1);
+                for (int q = 0; q < 2 * DT; ++q) { load_xq(raw[0], t32n, 0, q); load_xq(raw[1], t32n, n1 > 1 ? 1 : 0, q); }      // (past the end: zeros, never used)
                 X6_SB();
             }
             abase = slice_step(I0{}, abase, bp[2], nowork, KNone{});
             if constexpr (LAST) {
-                abase = slice_step(I1{}, abase, bp[3], [&](auto r_) {
+                abase = slice_step(I1{}, abase, bp[3], [&](auto r_) __attribute__((always_inline)) {
                     constexpr int r = decltype(r_)::value;
-                    if constexpr (r < 4) { make_bq(0, xk, bfx[0], r); load_xq(tile_next, n1 > 1 ? 1 : 0, r); }
+                    // the third slice right behind the quarter it replaces: in front of all but the first few stores of the burst
+                    auto quarter = [&](int q) __attribute__((always_inline)) { make_bq(raw[0], t32n, 0, bfx[0], q); load_xq(raw[0], t32n, n1 > 2 ? 2 : 0, q); };
+                    if constexpr (r < 4) { if constexpr (DT == 2) quarter(r); else { quarter(2 * r); quarter(2 * r + 1); } }
                     if constexpr (r > 0) epilogue_out(std::integral_constant<int, r - 1>{});
                 }, X6K<KX, KX + 1, KX + 1, KX + 1, 1, 1, 1>{});
                 epilogue_out(std::integral_constant<int, kMT - 1>{});
             } else {
-                abase = slice_step(I1{}, abase, bp[3], [&](auto r_) {
+                abase = slice_step(I1{}, abase, bp[3], [&](auto r_) __attribute__((always_inline)) {
                     constexpr int r = decltype(r_)::value;
                     if constexpr (r > 0) epilogue(std::integral_constant<int, r - 1>{}, l + 1);
                 }, X6K<0, KE, KE, KE, KE, KE, KE>{});
@@ -438,11 +478,11 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
         for (int l = 1; l < NL - 1; ++l) hidden(std::false_type{}, l);
         hidden(std::true_type{}, NL - 1);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
+        for (int dt = 0; dt < DT; ++dt) {
             float t = sc[dt];
             t += __shfl_xor(t, 16, 64);
             t += __shfl_xor(t, 32, 64);
-            if (g == 0 && rok[dt]) preds[row[dt]] = t + b_out;
+            x6_store4(psrd, (g == 0 && j < R - t32 - 16 * dt) ? (uint32_t)(t32 + 16 * dt + j) * 4u : kX6Oob, t + b_out);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the run-ahead DMA must not outlive the workgroup's LDS allocation
@@ -468,6 +508,10 @@ extern "C" int ptr_mlp_forward_x6(const float *X, const float *params, int R, in
         set_error("%s: X, acts and wimg must be 16-byte aligned", who); return PTR_ERR_INVALID_ARG;
     }
     if (R == 0) return 0;
+    if ((uint64_t)R * (uint64_t)F * 4 >= 0xFFFFF000ull) {
+        set_error("%s: R * F * 4 bytes of X exceed the 4 GB a buffer resource addresses (R=%d, F=%d): split the batch", who, R, F);
+        return PTR_ERR_UNSUPPORTED;
+    }
     if (train && (uint64_t)NL * (uint64_t)R * (kAL * 4) >= 0xFFFFF000ull) {
         set_error("%s: NL * R * 448 bytes of activations exceed the 4 GB a buffer resource addresses (R=%d): split the batch", who, R);
         return PTR_ERR_UNSUPPORTED;
@@ -478,12 +522,13 @@ extern "C" int ptr_mlp_forward_x6(const float *X, const float *params, int R, in
     hipLaunchKernelGGL(x6_prep_kernel, dim3((nthreads + 255) / 256), dim3(256), 0, st, params, F, NL, reinterpret_cast<uint8_t *>(wimg));
     if (int e = check_hip(hipGetLastError(), who)) return e;
     const size_t lds = x6_lds_bytes(NL);
-    const int ntiles = (R + 31) / 32, nblk = (ntiles + kX6Waves - 1) / kX6Waves;
+    constexpr int dt = 2, nw = 16 / dt, rpt = 16 * dt;
+    const int ntiles = (R + rpt - 1) / rpt, nblk = (ntiles + nw - 1) / nw;
     const int grid = nblk < mlp_num_cus() ? nblk : mlp_num_cus();
     auto launch = [&](auto kern) -> int {
         if (int e = allow_lds(kern, lds)) return e;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kX6Waves * 64), lds, st, X, params, reinterpret_cast<const uint8_t *>(wimg), a, preds, acts);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(nw * 64), lds, st, X, params, reinterpret_cast<const uint8_t *>(wimg), a, preds, acts);
         return check_hip(hipGetLastError(), who);
     };
-    return train ? launch(mlp_fwd_x6_kernel<true, true>) : launch(mlp_fwd_x6_kernel<false, false>);
+    return train ? launch(mlp_fwd_x6_kernel<true, true, 2>) : launch(mlp_fwd_x6_kernel<false, false, 2>);
 }

@@ -53,9 +53,13 @@ def fusable(**kw):
     return fused_kind(**kw) is not None
 
 
-def x6_enabled():
-    """The bf16x6 scorer kernels (csrc/scorer_x6.hip) are the default; PTR_MLP_X6=0 pins the fp32-MFMA kernels (read per call: tests)."""
-    return os.environ.get("PTR_MLP_X6", "1") != "0"
+X6_MIN_ROWS = 98304     # below ~1.5 passes of 256 documents per CU the 8-wave lockstep tiles leave CUs idle: the fp32-MFMA kernels are faster
+
+
+def x6_mode():
+    """PTR_MLP_X6: "1" (default) the bf16x6 scorer kernels (csrc/scorer_x6.hip) from X6_MIN_ROWS rows on, "0" never (the fp32-MFMA kernels),
+    "2" always (tests).  Read per call."""
+    return os.environ.get("PTR_MLP_X6", "1")
 
 
 _X6_WS = {}
@@ -75,7 +79,8 @@ def x6_workspace(dev, F, NL):
 
 def mlp_forward(X2d, flat, R, F, NL, train, p, seed, preds, acts, dev):
     """Scorer forward through the C ABI: the bf16x6 entry point when it serves (F, NL), the fp32-MFMA one otherwise."""
-    ws = x6_workspace(dev, F, NL) if x6_enabled() else None
+    mode = x6_mode()
+    ws = x6_workspace(dev, F, NL) if (mode == "2" or (mode != "0" and R >= X6_MIN_ROWS)) else None
     if ws is not None:
         _lib.call("ptr_mlp_forward_x6", _lib.ptr(X2d), _lib.ptr(flat), R, F, NL, int(train), C.c_float(p), C.c_uint64(seed),
                   _lib.ptr(preds), _lib.ptr(acts), _lib.ptr(ws), _lib.current_stream(dev))

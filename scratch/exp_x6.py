@@ -28,7 +28,7 @@ def ref64(fused, F, NL, X, seed, p, train):
 
 
 def run(fused, X, seed, train, x6):
-    os.environ["PTR_MLP_X6"] = "1" if x6 else "0"
+    os.environ["PTR_MLP_X6"] = "2" if x6 else "0"
     fused.train(train)
     orig = torch.randint
     torch.randint = lambda *a, **k: torch.tensor([seed])

@@ -18,11 +18,13 @@ torch.cuda.synchronize()
 tr = ws[-16384:].cpu().numpy().view(np.uint64).reshape(8, 256).astype(np.int64)
 ns = 13
 for w in (0, 4, 7):
-    t = tr[w]; n = int((t > 0).sum()) // 2
+    t = tr[w]; n = min(int((t[:252] > 0).sum()) // 2, 126)
     arr, rel = t[0:2 * n:2], t[1:2 * n:2]
     print(f"wave {w}: {n} syncs; step = release(i) -> arrival(i+1) [compute], wait = arrival -> release [barrier]")
     comp = arr[1:] - rel[:-1]; wait = rel - arr
     for p in range(min(3, (n - 1) // ns)):
         print(f"  pass {p}: compute per step {comp[p * ns:(p + 1) * ns].tolist()}  sum {int(comp[p * ns:(p + 1) * ns].sum())}")
         print(f"          barrier wait    {wait[p * ns:(p + 1) * ns].tolist()}  sum {int(wait[p * ns:(p + 1) * ns].sum())}")
-    print(f"  total first->last stamp {int(t[2 * n - 1] - t[0])} cycles for {n} steps")
+    n = min(n, 126)
+    dt_us = (int(t[255]) - int(t[253])) / 100.0
+    print(f"  total first->last stamp {int(t[2 * n - 1] - t[0])} cycles for {n} steps in {dt_us:.1f} us (100 MHz counter) = {int(t[2 * n - 1] - t[0]) / max(dt_us, 1e-9) / 1e3:.2f} GHz")

@@ -91,8 +91,11 @@ def _masked_forward(ref, fused, X2d_cpu, seed, p, NL, dtype, chunk=65536, masks=
 @pytest.mark.parametrize("F,NL,R", [(136, 3, 65536), (136, 3, 524288), (136, 3, 8192 * 5 + 17), (136, 3, 8192 * 37 + 17),
                                     (132, 3, 8192 * 9 + 3), (140, 2, 8192 * 6 + 61), (700, 3, 65536), (700, 3, 8192 * 9 + 17),
                                     (136, 1, 100001), (46, 3, 70001), (256, 2, 66000)])
-def test_scorer_train_forward_backward_at_bench_scale(F, NL, R, monkeypatch):
+@pytest.mark.parametrize("x6", ["0", "2"])
+def test_scorer_train_forward_backward_at_bench_scale(F, NL, R, x6, monkeypatch):
+    """x6 = "0": fp32-MFMA forward, "2": bf16x6 forward wherever it serves the shape (F % 4 == 0, NL >= 2)."""
     from ptranking_amd.scorer import FusedPointScorer
+    monkeypatch.setenv("PTR_MLP_X6", x6)
     p = 0.1
     torch.manual_seed(R % 1000 + F)
     fused = FusedPointScorer(F, num_layers=NL, dropout=p).cuda()
@@ -144,9 +147,12 @@ def test_scorer_backward_is_run_to_run_bit_stable_at_bench_scale():
     ("RankNet", dict(sigma=1.0), "ranknet_loss", dict(sigma=1.0), 1024, 32),
     ("ListNet", None, "listnet_loss", {}, 512, 256),
 ])
-def test_direct_train_step_at_headline_batch_matches_cpu_reference(name, paras, oracle_fn, okw, B, L):
+@pytest.mark.parametrize("x6", ["0", "2"])
+def test_direct_train_step_at_headline_batch_matches_cpu_reference(name, paras, oracle_fn, okw, B, L, x6, monkeypatch):
+    """x6 = "0": fp32-MFMA forward, "2": bf16x6 forward (csrc/scorer_x6.hip) under the same fused backward / Adam."""
     from oracle import torch_ref as T
     import ptranking_amd as pa
+    monkeypatch.setenv("PTR_MLP_X6", x6)
     F, NL, p = 136, 3, 0.1
     sf = {"sf_id": "pointsf", "opt": "Adam", "lr": 1e-3,
           "pointsf": dict(num_features=F, num_layers=NL, AF="R", TL_AF="S", apply_tl_af=False, BN=False, bn_type=None, bn_affine=False,
@@ -189,8 +195,18 @@ def test_direct_train_step_at_headline_batch_matches_cpu_reference(name, paras, 
         # pre-activations of this batch) rounding noise becomes a +-lr move on either side.  Nearly all coordinates agree to 2e-5; none
         # may be off by more than a tenth of the 3 * lr a coordinate can travel in three steps.
         d = (p1.detach().cpu() - p2.detach()).abs()
-        assert float(d.max()) <= 0.1 * 3 * 1e-3, (n1, float(d.max()))
-        assert float((d > 2e-5 + 1e-4 * p2.detach().abs()).float().mean()) < 2e-3, (n1, float((d > 2e-5).float().mean()))
+        if x6 == "0":
+            assert float(d.max()) <= 0.1 * 3 * 1e-3, (n1, float(d.max()))
+            assert float((d > 2e-5 + 1e-4 * p2.detach().abs()).float().mean()) < 2e-3, (n1, float((d > 2e-5).float().mean()))
+        else:
+            # The bf16x6 forward is as accurate as the fp32-MFMA one (same error against float64, test_x6_gpu.py; identical gradient error
+            # once rows at a ReLU kink are screened, scratch/dbg_x6_grad64.py) but rounds DIFFERENTLY from the CPU's fp32 GEMM, so a handful of
+            # the 4 * 10^7 pre-activations of this batch (measured: 4, all below 2e-7) land on the other side of their kink.  A flipped gate
+            # changes one document's contribution to a whole weight row; Adam turns that into a full +-lr move wherever the coordinate's
+            # gradient is near 0 (measured: 1 / 4 / 20 of the 13 600 first-layer coordinates after 1 / 2 / 3 steps, all others within 1e-4).
+            assert float(d.max()) <= 2 * 3 * 1e-3, (n1, float(d.max()))
+            assert float((d > 1e-4 + 1e-4 * p2.detach().abs()).float().mean()) < 5e-3, (n1, float((d > 1e-4).float().mean()))
+            assert float((d > 2e-5 + 1e-4 * p2.detach().abs()).float().mean()) < 5e-2, (n1, float((d > 2e-5).float().mean()))
 
 
 # (d) the loss kernels at B = 4096 (launch geometry of the benchmark) against the C oracle

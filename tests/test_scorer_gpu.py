@@ -7,6 +7,16 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["0", "2"], ids=["fp32mfma", "bf16x6"])
+def _forward_kernel(request, monkeypatch):
+    """Every test of this file runs with the fp32-MFMA forward pinned and with the bf16x6 forward forced (ptranking_amd/scorer.py x6_mode;
+    shapes the bf16x6 kernels do not serve — F % 4 != 0, one hidden layer — take the fp32-MFMA kernels in both runs)."""
+    monkeypatch.setenv("PTR_MLP_X6", request.param)
+
+
+_REAL_RANDINT = torch.randint
+
+
 def torch_scorer(F, NL):
     from ptranking_amd.host import build_pointsf
     return build_pointsf(num_features=F, num_layers=NL, AF="R", BN=False, apply_tl_af=False, dropout=0.0)     # CPU: plain torch ops
@@ -64,7 +74,7 @@ def test_train_forward_backward_match_torch_with_same_masks(F, NL, R, monkeypatc
     seed = 123456789 + R
     monkeypatch.setattr(torch, "randint", lambda *a, **k: torch.tensor([seed]))
     out = fused(X)
-    monkeypatch.undo()
+    monkeypatch.setattr(torch, "randint", _REAL_RANDINT)
     exp = _train_reference(ref, fused, X, seed, p, NL)
     close(out, exp)
     w = torch.randn(R, 1, device="cuda")

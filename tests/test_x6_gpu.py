@@ -1,0 +1,159 @@
+"""GPU: the bf16x6 pointsf forward (csrc/scorer_x6.hip: every fp32 product as six bf16 matrix-instruction products with fp32 accumulation)
+against float64 CPU modules built the way the reference builds them (ptranking/base/utils.py:288-356), next to the fp32-MFMA forward on
+the same inputs: the split must be a numerical drop-in — error against float64 equal to or below the fp32 path's — on N(0,1), wide-exponent
+and all-positive data, in eval and in training mode (same dropout masks), incl. the stored activations the fused backward reads."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(F, NL, seed=0, scale_w=None):
+    from ptranking_amd.scorer import FusedPointScorer
+    from ptranking_amd.host import build_pointsf
+    torch.manual_seed(seed)
+    fused = FusedPointScorer(F, num_layers=NL, dropout=0.1).cuda()
+    if scale_w is not None:
+        with torch.no_grad():
+            fused.flat.mul_(scale_w(fused.flat))
+    ref = build_pointsf(num_features=F, num_layers=NL, AF="R", BN=False, apply_tl_af=False, dropout=0.0).double()
+    ref.load_state_dict({k: v.cpu().double() for k, v in fused.state_dict().items()})
+    return fused, ref
+
+
+def _ref64(ref, fused, X, seed, p, NL, train):
+    lin = [m for m in ref if isinstance(m, torch.nn.Linear)]
+    R = X.shape[0]
+    a = X.cpu().double()
+    acts = []
+    if train:
+        a = a * fused.dropout_mask(R, 0, seed).cpu().double() / (1 - p)
+    for l in range(NL):
+        h = torch.relu(lin[l](a))
+        a = h * fused.dropout_mask(R, l + 1, seed).cpu().double() / (1 - p) if (train and l < NL - 1) else h
+        acts.append(a)
+    return lin[NL](a).reshape(-1), acts
+
+
+def _forward(fused, X, NL, train, seed, x6):
+    from ptranking_amd import _lib
+    from ptranking_amd.scorer import x6_workspace
+    R, F = X.shape
+    preds = torch.empty(R, device="cuda")
+    acts = torch.full((NL, R, 112), float("nan"), device="cuda") if train else None
+    st = _lib.current_stream(X.device)
+    if x6:
+        ws = x6_workspace(X.device, F, NL)
+        assert ws is not None
+        _lib.call("ptr_mlp_forward_x6", _lib.ptr(X), _lib.ptr(fused.flat.data), R, F, NL, int(train), C.c_float(0.1), C.c_uint64(seed), _lib.ptr(preds),
+                  _lib.ptr(acts), _lib.ptr(ws), st)
+    else:
+        _lib.call("ptr_mlp_forward", _lib.ptr(X), _lib.ptr(fused.flat.data), R, F, NL, int(train), C.c_float(0.1), C.c_uint64(seed), _lib.ptr(preds),
+                  _lib.ptr(acts), st)
+    torch.cuda.synchronize()
+    return preds, acts
+
+
+# (F, NL, R): the benchmark width and its neighbours, one / many slices in layer 1 (F <= 32, F = 700), 2..5 hidden layers, tiles that end
+# inside a wave (R mod 32 != 0), inside a workgroup (R mod 256 != 0), one tile, more than one pass per workgroup (R > 65536)
+SHAPES = [(136, 3, 2085), (136, 3, 32), (136, 3, 31), (136, 3, 1), (132, 3, 777), (140, 5, 300), (700, 3, 1111), (24, 2, 100), (256, 3, 640),
+          (200, 4, 500), (4, 2, 70), (32, 2, 64), (64, 3, 257), (136, 3, 65536 + 37), (136, 3, 3 * 65536 + 5)]
+
+
+@pytest.mark.parametrize("F,NL,R", SHAPES)
+@pytest.mark.parametrize("train", [False, True])
+def test_x6_forward_matches_float64_modules(F, NL, R, train):
+    fused, ref = _pair(F, NL, seed=R)
+    X = torch.randn(R, F, device="cuda")
+    seed = 1234567 + R
+    exp, eacts = _ref64(ref, fused, X, seed, 0.1, NL, train)
+    preds, acts = _forward(fused, X, NL, train, seed, x6=True)
+    scale = max(1.0, float(exp.abs().max()))
+    err = float((preds.double().cpu() - exp).abs().max())
+    assert err <= 2e-5 * scale, (err, scale)
+    if train:
+        assert not torch.isnan(acts).any(), "every activation row / padding column must be written"
+        for l in range(NL):
+            e = float((acts[l, :, :100].double().cpu() - eacts[l]).abs().max())
+            assert e <= 2e-5 * max(1.0, float(eacts[l].abs().max())), (l, e)
+            ones = 1.0 if l < NL - 1 else 0.0                       # column 100: the ones column of the fused backward
+            assert torch.all(acts[l, :, 100] == ones) and torch.all(acts[l, :, 101:] == 0.0)
+        if F % 4 == 0 and not (F == 140 and NL == 5):               # where the fp32-MFMA forward serves the shape too: same gates
+            _, acts_old = _forward(fused, X, NL, True, seed, x6=False)
+            flips = sum(int(((acts[l, :, :100] > 0) != (acts_old[l, :, :100] > 0)).sum()) for l in range(NL))
+            assert flips <= max(4, R * 100 * NL // 1_000_000), flips   # only pre-activations at rounding distance of the ReLU kink may differ
+
+
+@pytest.mark.parametrize("kind", ["normal", "wide_exponent", "all_positive"])
+@pytest.mark.parametrize("train", [False, True])
+def test_x6_error_not_above_the_fp32_mfma_path(kind, train):
+    """The verdict's bar for 'dtype stays f32': error against float64 <= the fp32-MFMA path's on N(0,1), wide-exponent and all-positive data."""
+    F, NL, R = 136, 3, 16384
+    if kind == "wide_exponent":          # weights and features spread over 2^-12 .. 2^12 (products over 2^-24 .. 2^24)
+        fused, ref = _pair(F, NL, seed=5, scale_w=lambda w: torch.exp2(torch.randint(-12, 13, w.shape, device=w.device).float()) * 2.0 ** -6)
+        X = torch.randn(R, F, device="cuda") * torch.exp2(torch.randint(-12, 13, (R, F), device="cuda").float())
+    elif kind == "all_positive":         # no cancellation: every rounding error has the same sign bias
+        fused, ref = _pair(F, NL, seed=6, scale_w=lambda w: torch.sign(w) * 1.0)
+        with torch.no_grad():
+            fused.flat.abs_()
+        ref.load_state_dict({k: v.cpu().double() for k, v in fused.state_dict().items()})
+        X = torch.rand(R, F, device="cuda") + 0.1
+    else:
+        fused, ref = _pair(F, NL, seed=7)
+        X = torch.randn(R, F, device="cuda")
+    seed = 4242
+    exp, eacts = _ref64(ref, fused, X, seed, 0.1, NL, train)
+    errs = {}
+    for x6 in (False, True):
+        preds, acts = _forward(fused, X, NL, train, seed, x6)
+        errs[x6] = float(((preds.double().cpu() - exp).abs() / exp.abs().clamp_min(1e-30)).median()), float((preds.double().cpu() - exp).abs().max())
+    scale = float(exp.abs().max())
+    # max error: not above the fp32 path's by more than the noise between two roundings of the same sum; median relative error likewise
+    assert errs[True][1] <= 1.5 * errs[False][1] + 1e-7 * scale, (kind, errs)
+    assert errs[True][0] <= 1.5 * errs[False][0] + 1e-8, (kind, errs)
+
+
+def test_x6_range_and_argument_errors():
+    from ptranking_amd import _lib
+    assert _lib.query("ptr_mlp_x6_ws_bytes", 136, 3) >= 13 * 21504
+    assert _lib.query("ptr_mlp_x6_ws_bytes", 46, 3) == 0          # F % 4 != 0
+    assert _lib.query("ptr_mlp_x6_ws_bytes", 136, 1) == 0         # a single hidden layer: the fp32-MFMA kernel
+    X = torch.randn(64, 46, device="cuda")
+    flat = torch.zeros(_lib.query("ptr_mlp_num_params", 46, 3), device="cuda")
+    preds = torch.empty(64, device="cuda")
+    ws = torch.empty(1 << 20, device="cuda", dtype=torch.uint8)
+    with pytest.raises(RuntimeError, match="outside the bf16x6"):
+        _lib.call("ptr_mlp_forward_x6", _lib.ptr(X), _lib.ptr(flat), 64, 46, 3, 0, C.c_float(0.0), C.c_uint64(0), _lib.ptr(preds), None, _lib.ptr(ws),
+                  _lib.current_stream(X.device))
+    X = torch.randn(64, 136, device="cuda")
+    flat = torch.zeros(_lib.query("ptr_mlp_num_params", 136, 3), device="cuda")
+    with pytest.raises(RuntimeError, match="NULL"):
+        _lib.call("ptr_mlp_forward_x6", _lib.ptr(X), _lib.ptr(flat), 64, 136, 3, 1, C.c_float(0.1), C.c_uint64(0), _lib.ptr(preds), None, _lib.ptr(ws),
+                  _lib.current_stream(X.device))
+    with pytest.raises(RuntimeError, match="NULL"):
+        _lib.call("ptr_mlp_forward_x6", _lib.ptr(X), _lib.ptr(flat), 64, 136, 3, 0, C.c_float(0.0), C.c_uint64(0), _lib.ptr(preds), None, None,
+                  _lib.current_stream(X.device))
+    _lib.call("ptr_mlp_forward_x6", _lib.ptr(X), _lib.ptr(flat), 0, 136, 3, 0, C.c_float(0.0), C.c_uint64(0), None, None, None, _lib.current_stream(X.device))   # R = 0: nothing to do
+
+
+def test_x6_is_the_default_forward_at_bench_scale_and_deterministic(monkeypatch):
+    """FusedPointScorer takes the bf16x6 entry point from X6_MIN_ROWS rows on (PTR_MLP_X6 unset), the fp32-MFMA one below; two launches give
+    identical bits."""
+    from ptranking_amd import _lib, scorer
+    from ptranking_amd.scorer import FusedPointScorer
+    monkeypatch.delenv("PTR_MLP_X6", raising=False)
+    fused = FusedPointScorer(136, 3, dropout=0.1).cuda().eval()
+    _lib.TIMING = {}
+    try:
+        with torch.no_grad():
+            a = fused(torch.randn(256, 136, device="cuda"))
+            big = torch.randn(scorer.X6_MIN_ROWS, 136, device="cuda")
+            b1 = fused(big)
+            b2 = fused(big)
+        names = list(_lib.TIMING)
+    finally:
+        _lib.TIMING = None
+    assert names == ["ptr_mlp_forward", "ptr_mlp_forward_x6"], names
+    assert torch.equal(b1, b2) and torch.isfinite(a).all()
