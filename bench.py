@@ -41,6 +41,7 @@ import torch.distributed as dist
 
 HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3      # dense fp32-input MFMA peak = fp32 vector peak (same guide)
+BF16X6_PEAK_TFLOPS = 2500.0 / 6   # effective fp32 peak of the bf16x6 formulation: dense bf16 MFMA peak (same guide) / six products per fp32 product
 MSLR_P = [0.5147, 0.3250, 0.1339, 0.0183, 0.0081]   # label histogram of MSLR-WEB30K
 SEED = 137                        # ptranking/ltr_global.py:7
 EVENT_EVERY = 4                   # per-kernel HIP-event brackets on every 4th step of the timed region
@@ -210,12 +211,44 @@ def main():
     ap.add_argument("--scorer", default="pointsf", choices=["pointsf", "pointsf_default", "listsf"],
                     help="listsf = BASELINE.json config 5: 2-head / 6-layer DASALC encoder (fused MFMA attention), use with --loss LambdaLoss "
                          "--list-len 256 --batch 1024")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="N = 1 only: initialise a one-rank RCCL process group and run the data-parallel step through it (backward -> "
+                         "all-reduce -> optimiser step instead of the fused single-device step); what a 1-GPU box can execute of the RCCL path")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: become the launcher.  One rank per GPU over RCCL, exactly the command line the
+    # module docstring gives; rank 0 of the child job prints the one JSON line.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: this node exposes {torch.cuda.device_count()} GPU(s); one rank per GPU is required")
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
+    # stdout carries exactly ONE line, the JSON: RCCL prints a version banner to stdout when a process group is torn down, so from here on
+    # file descriptor 1 of every rank points at stderr and the JSON goes to a private duplicate of the original stdout
+    json_out = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
+    if args.force_collectives:
+        if args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
+            raise SystemExit("--force-collectives is for single-GPU runs")
+        os.environ["PTR_DP_INIT_SINGLE"] = "1"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        with __import__("socket").socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
 
     import ptranking_amd as pa
     from ptranking_amd import _lib, dp
 
     rank, world, local = dp.init_from_env()
+    if args.force_collectives:
+        dp.SINGLE_RANK_COLLECTIVES = True
     if world != args.gpus and rank == 0:
         print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     if not torch.cuda.is_available():
@@ -311,9 +344,11 @@ def main():
     elapsed, timing, ar_timing, final_loss = measure(ranker, B, args.steps, args.warmup, 5)
     # The contract's window is the one above (`steps`, `ms_per_step`, `value`).  It is tens of ms long, so its spread is reported too:
     # args.windows - 1 further windows of the same K steps, each bracketed the same way
+    # Every window gets the pre-warm of the first (with ONE warm-up step in front of freshly synthesised batches the
+    # later windows ran 10 % slower than the contract's — a cold-start artefact, not noise).
     window_ms = [1e3 * elapsed / args.steps]
     for _ in range(max(0, args.windows - 1)):
-        el, _, _, _ = measure(ranker, B, args.steps, 1, 0)
+        el, _, _, _ = measure(ranker, B, args.steps, args.warmup, 5)
         window_ms.append(1e3 * el / args.steps)
 
     by_batch = {}
@@ -364,9 +399,12 @@ def main():
         dist.all_gather_object(gathered, facts)
         backend = dist.get_backend()
     else:
-        gathered, backend = [facts], None
+        gathered, backend = [facts], (dist.get_backend() if dist.is_initialized() else None)
     parallel_facts = {"world_size": world, "backend": backend, "rccl": backend == "nccl", "ranks": gathered,
-                      "rccl_ranks": world if backend == "nccl" else 0}
+                      "rccl_ranks": world if backend == "nccl" else 0,
+                      "allreduce_ms": (float(np.mean([a.elapsed_time(b) for a, b in ar_timing])) if ar_timing else None),
+                      "launch": "self-launched torch.distributed.run" if os.environ.get("TORCHELASTIC_RUN_ID") or world > 1 else "single process",
+                      "single_rank_collectives": bool(args.force_collectives)}
     if world > 1:
         assert len({g["allreduce_calls"] for g in gathered}) == 1 and gathered[0]["allreduce_calls"] > 0, gathered
         if backend == "nccl":
@@ -387,6 +425,9 @@ def main():
                       "ApproxNDCG": "ptr_approxndcg_fwd_bwd", "ListNet": "ptr_listnet_fwd_bwd", "ListMLE": "ptr_listmle_fwd_bwd"}[args.loss]
         t_fwd, t_loss, t_bwd, t_adam, t_sum = (avg_ms(n) for n in ("ptr_mlp_forward", loss_entry, "ptr_mlp_backward", "ptr_adam_step",
                                                                     "ptr_sum_f32"))
+        fwd_x6 = t_fwd is None and avg_ms("ptr_mlp_forward_x6") is not None
+        if fwd_x6:               # the bf16x6 forward (csrc/scorer_x6.hip): from scorer.X6_MIN_ROWS documents per step on
+            t_fwd = avg_ms("ptr_mlp_forward_x6")
         bwd_fused_step = t_bwd is None and avg_ms("ptr_mlp_backward_step") is not None
         if bwd_fused_step:       # single device: backward + optimiser step + loss-slot sum in one entry point (rankers._direct_train_op)
             t_bwd = avg_ms("ptr_mlp_backward_step")
@@ -443,9 +484,15 @@ def main():
             kernels["lambdarank_loss_grad_L256"] = loss_kernel_entry(256, l256, None)
         if t_fwd:
             tf = fwd_flop / (t_fwd * 1e-3) / 1e12
-            kernels["scorer_forward"] = {"kernel": "mlp_fwd_kernel<RT,TRAIN,VEC> (fused pointsf scorer forward, fp32 MFMA 16x16x4, dropout in-kernel; training: 16 waves x 16-row tiles)",
-                                         "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                         "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_bytes("ptr::mlp_fwd_kernel"), "avg_launch_ms": t_fwd,
+            fwd_peak = BF16X6_PEAK_TFLOPS if fwd_x6 else MFMA_F32_PEAK_TFLOPS
+            kernels["scorer_forward"] = {"kernel": ("x6_prep_kernel + mlp_fwd_x6_kernel<TRAIN,STORE,2> (fused pointsf scorer forward, every fp32 product as six "
+                                                    "v_mfma_f32_16x16x32_bf16 products with fp32 accumulation; weight planes streamed through an LDS ring by LDS-DMA; "
+                                                    "8 waves x 32-document tiles)" if fwd_x6 else
+                                                    "mlp_fwd_kernel<RT,TRAIN,VEC> (fused pointsf scorer forward, fp32 MFMA 16x16x4, dropout in-kernel; training: 16 waves x 16-row tiles)"),
+                                         "formulation": "bf16x6 (fp32 results)" if fwd_x6 else "fp32 MFMA",
+                                         "bound": "mfma", "achieved": tf, "peak": fwd_peak, "unit": "TFLOP/s (effective fp32)" if fwd_x6 else "TFLOP/s",
+                                         "frac": tf / fwd_peak, "frac_of_fp32_mfma_peak": tf / MFMA_F32_PEAK_TFLOPS,
+                                         "traffic": pmc_bytes("ptr::mlp_fwd_x6_kernel" if fwd_x6 else "ptr::mlp_fwd_kernel"), "avg_launch_ms": t_fwd,
                                          "algorithmic_flop_per_launch": fwd_flop, "algorithmic_bytes_per_launch": R * (4 * F + 4),
                                          "design_bytes_per_launch": NL * R * 448}
         if t_adam:
@@ -510,6 +557,9 @@ def main():
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": step_ms, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "formulation": {"scorer_forward": "bf16x6: fp32 operands split exactly into three bf16 pieces, six bf16 MFMA products per fp32 product, fp32 "
+                                              "accumulation (error vs float64 <= the fp32-MFMA path, tests/test_x6_gpu.py)" if fwd_x6 else "fp32 MFMA",
+                            "scorer_backward": "fp32 MFMA", "loss": "fp32 VALU"},
             "config": {"workload": (f"{args.loss} train step (pointsf 3x100 ReLU scorer, dropout 0.1, Adam), " if args.scorer == "pointsf" else
                                     f"{args.loss} train step (the reference's DEFAULT pointsf: 5 x [Linear 100 -> BatchNorm(affine) -> GELU] + "
                                     f"Linear -> BatchNorm -> Sigmoid, dropout 0.1, Adam), " if args.scorer == "pointsf_default" else
@@ -534,8 +584,9 @@ def main():
             out["ms_per_step_at_1024"] = by_batch["1024"]["ms_per_step"]
         if world == 1 and not args.no_cpu_baseline and args.scorer == "pointsf":
             out["cpu_baseline"] = cpu_baseline(L, F, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

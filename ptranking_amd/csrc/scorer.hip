@@ -1004,15 +1004,10 @@ reduce_partials_kernel(const float *__restrict__ ws, int nblk, int nblk_tail, si
     __shared__ float part[16][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (o.loss_out && blockIdx.x == gridDim.x - 1) {
-        // one extra block: the loss slots of the batch, summed EXACTLY like sum_f32_kernel (256 threads, strided, wave butterflies, the four
-        // wave sums in order) so that the fused step returns the same bits as the separate call
-        float acc = 0.0f;
-        if (threadIdx.x < kBlock)
-            for (int i = threadIdx.x; i < o.nq; i += kBlock) acc += o.loss_q[i];
-        acc = wave_sum(acc);
-        if (lane == 0) part[0][w] = acc;
-        __syncthreads();
-        if (threadIdx.x == 0) o.loss_out[0] = ((part[0][0] + part[0][1]) + part[0][2]) + part[0][3];
+        // one extra block: the loss slots of the batch, summed by the function sum_f32_kernel calls (ptr_device.h block1024_sum): the fused
+        // step returns the same bits as the separate call
+        const float tot = block1024_sum(o.loss_q, o.nq, &part[0][0]);
+        if (threadIdx.x == 0) o.loss_out[0] = tot;
         return;
     }
     const size_t i = (size_t)blockIdx.x * 64 + lane;

@@ -33,8 +33,14 @@ def _timed_all_reduce(t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
 
+# A process group of ONE rank normally takes the single-device path (no collective, optimiser step fused into the backward).  SINGLE_RANK_COLLECTIVES
+# = True keeps the data-parallel path — gradient all-reduce over the group's backend, then the optimiser step — so that the RCCL code path can be
+# executed on a one-GPU box (tests/test_dp_gpu.py, `bench.py --force-collectives`); the result is the single-device one (a sum over one rank).
+SINGLE_RANK_COLLECTIVES = False
+
+
 def is_distributed():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or SINGLE_RANK_COLLECTIVES)
 
 
 def world_size():
@@ -54,7 +60,7 @@ def init_from_env(backend=None):
     if torch.cuda.is_available():
         local = local % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local)
-    if ws > 1 and not dist.is_initialized():
+    if (ws > 1 or os.environ.get("PTR_DP_INIT_SINGLE") == "1") and not dist.is_initialized():     # PTR_DP_INIT_SINGLE=1: a group of one rank too
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -68,7 +74,8 @@ def init_from_env(backend=None):
 
 
 ROW_KEY = 0x9E3779B1        # the per-row multiplier of the counter-based dropout generator (csrc/ptr_dropout.h drop_bits)
-ROW_OFFSET = None           # explicit global index of this rank's first row (unequal shards); None: rank * local rows
+ROW_OFFSET = None           # explicit global index of this rank's first row; None: derived from QUERY_SHARD, else rank * local rows
+QUERY_SHARD = None          # (first global query, number of local queries) of this rank's slice, recorded by shard_queries()
 
 
 def fold_row_offset(seed, row0):
@@ -80,13 +87,18 @@ def fold_row_offset(seed, row0):
 
 def local_dropout_seed(seed, local_rows):
     """The seed this rank passes to the dropout kernels for a batch of `local_rows` rows (documents for the pointwise scorers).  With
-    every rank drawing the same base seed (same torch.manual_seed, as the reference's single process would) and equal shards this
-    makes rank r's row i use the mask of global row r * local_rows + i: replicas never share masks and N ranks
-    x B/N reproduce one rank x B.  Single process: the seed unchanged."""
-    if not is_distributed():
-        return seed if ROW_OFFSET is None else fold_row_offset(seed, int(ROW_OFFSET))
-    row0 = int(ROW_OFFSET) if ROW_OFFSET is not None else rank() * int(local_rows)
-    return fold_row_offset(seed, row0)
+    every rank drawing the same base seed (same torch.manual_seed, as the reference's single process would) this makes rank r's row i
+    use the mask of global row (rows of ranks < r) + i: replicas never share masks and N ranks x B/N reproduce
+    one rank x B.  Equal shards: rank * local_rows; a slice taken with shard_queries() is placed by its recorded query offset (uneven
+    splits included); ROW_OFFSET overrides both.  Single process: the seed unchanged."""
+    if ROW_OFFSET is not None:
+        return fold_row_offset(seed, int(ROW_OFFSET))
+    if not is_distributed() or world_size() == 1:
+        return seed
+    local_rows = int(local_rows)
+    if QUERY_SHARD is not None and QUERY_SHARD[1] > 0 and local_rows % QUERY_SHARD[1] == 0:
+        return fold_row_offset(seed, QUERY_SHARD[0] * (local_rows // QUERY_SHARD[1]))     # rows per query x queries in front of this rank
+    return fold_row_offset(seed, rank() * local_rows)
 
 
 def seed_replica(seed):
@@ -100,11 +112,17 @@ def seed_replica(seed):
 
 def shard_queries(num_queries, rank_=None, world_=None):
     """Contiguous slice [lo, hi) of the query dimension owned by this rank (remainder spread over the first ranks)."""
+    global QUERY_SHARD
     r = rank() if rank_ is None else rank_
     w = world_size() if world_ is None else world_
     base, rem = divmod(num_queries, w)
     lo = r * base + min(r, rem)
-    return lo, lo + base + (1 if r < rem else 0)
+    hi = lo + base + (1 if r < rem else 0)
+    if rank_ is None and world_ is None:
+        # this rank's own slice: remembered so that local_dropout_seed can place the replica's rows in the global batch when the split is
+        # uneven (rank * local rows would overlap the neighbours' mask windows, ADVICE r3) — no collective needed
+        QUERY_SHARD = (lo, hi - lo)
+    return lo, hi
 
 
 class ViewGradBucket:
@@ -112,12 +130,13 @@ class ViewGradBucket:
     module parameters' .grad are views of it and the fused stack writes its gradients straight into it): `gbuf` = [numel gradient
     floats | spare tail], of which `extra` tail floats travel with the gradients in the one all-reduce.  Nothing is re-pointed."""
 
-    def __init__(self, gbuf, numel, extra, on_zero):
+    def __init__(self, gbuf, numel, extra, on_zero, before_reduce=None):
         if gbuf.numel() < numel + extra:
             raise ValueError("gradient buffer has no room for the extra scalars")
         self.numel, self.extra = numel, extra
         self.flat = gbuf[:numel + extra]
         self._on_zero = on_zero
+        self._before_reduce = before_reduce      # owner hook: gradients something re-pointed go back into the flat buffer first (ADVICE r3)
 
     @property
     def extras(self):
@@ -129,6 +148,8 @@ class ViewGradBucket:
             self.extras.zero_()
 
     def all_reduce(self):
+        if self._before_reduce is not None:
+            self._before_reduce()
         if is_distributed():
             _timed_all_reduce(self.flat)
 

@@ -192,16 +192,21 @@ class scorer_lens:
             return self
         from .linear import FusedStack
 
+        # Two passes: first VALIDATE every stack, then arm them — a refusal half way through the walk must not leave the stacks
+        # already visited with these lens (the next unpadded forward with the same batch size would mask its BN statistics with them).
+        found = []
+
         def walk(m):
             if isinstance(m, FusedStack):
                 has_bn = any(type(c).__name__ in _BN_NAMES for c in m.children())
-                probe = self.X if (self.X is not None and self.X.dim() == 3) else None
-                if probe is None:       # only the device and the rank matter for stacks that do not see the raw features
-                    probe = torch.zeros((1, 1, 4), device=self.lens.device)
+                # probe every stack with ITS OWN input width (a nested stack — the listsf tail behind the encoder — never sees the raw
+                # features, and FusedStack.forward decides its module-by-module fallback from its own input)
+                lin0 = next((c for c in m.modules() if isinstance(c, torch.nn.Linear)), None)
+                width = lin0.in_features if lin0 is not None else 4
+                probe = torch.empty((1, 1, width), device=self.lens.device if self.X is None else self.X.device)
                 if has_bn and not m.handles_padding(probe):
                     self._refuse()
-                m.batch_lens = self.lens
-                self.stacks.append(m)
+                found.append(m)
             elif type(m).__name__ in _BN_NAMES:
                 self._refuse()
             else:
@@ -210,6 +215,9 @@ class scorer_lens:
 
         for top in _scorer_modules(self.ranker):
             walk(top)
+        for m in found:
+            m.batch_lens = self.lens
+        self.stacks = found
         return self
 
     @staticmethod

@@ -13,6 +13,7 @@ tail stacks with ff_dims 128/256/512, the Q|K|V and fc projections).
 CPU tensors take the plain torch ops (host-logic tests only; the product path is the GPU one).
 """
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -88,7 +89,16 @@ class _LinearFn(torch.autograd.Function):
 
 
 def linear(x, weight, bias=None):
+    """nn.functional.linear on the hand-written GEMM kernels for GPU tensors.
+
+    CPU tensors: FusedLinear IS an nn.Linear and FusedStack IS an nn.Sequential, and on a CPU tensor they behave as those torch modules do
+    (torch's own F.linear — not the oracle, not a re-implementation of ours).  That is what lets the host-side plumbing the drop-in reuses
+    from the reference run where no GPU is (state_dict round trips, the reference's kfold_cv_eval loop on the installed classes in
+    tests/test_host_cpu.py, golden-fixture generation).  It is NOT a fallback for the product path: a GPU tensor never takes it, the device
+    entry points of _lib refuse CPU tensors, and PTR_STRICT_DEVICE=1 turns this branch into an error as well."""
     if not x.is_cuda:
+        if os.environ.get("PTR_STRICT_DEVICE") == "1":
+            raise _lib.NativeLibraryError(f"linear: tensor on {x.device} with PTR_STRICT_DEVICE=1 — the hand-written kernels run on the GPU only")
         return F.linear(x, weight, bias)
     return _LinearFn.apply(x, weight, bias)
 
@@ -471,6 +481,9 @@ class FusedStack(nn.Sequential):
         if p > 0.0 and len(lins) > 1 and x.shape[-1] % 4:
             # the fused input dropout works on float4 feature groups: other widths (46-feature MQ2007/2008 data in front of a listsf
             # head / tail stack or a GELU pointsf) run module by module — FusedLinear GEMMs take any K, nn.Dropout / torch activations
+            if getattr(self, "batch_lens", None) is not None and plan["kind"] is not None:
+                raise NotImplementedError("a padded batch (batch_lens) reached a batch-norm stack on its module-by-module path: the padded "
+                                          "rows would enter the BN statistics (host.scorer_lens should have refused this configuration)")
             return super().forward(x)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0      # CPU generator: no device sync
         if p > 0.0:

@@ -16,6 +16,7 @@ There is no CPU / eager fallback: CPU tensors raise.
 """
 import copy
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -40,16 +41,25 @@ def _voff(t, floats):
 
 
 DS_SPILL_MAX_BYTES = 8 << 30     # scaled-dS scratch of the attention backward (4 B H L^2 bytes): 0.54 GB at config 5 — 288 GB of HBM3E has room
+DS_SPILL_FREE_FRACTION = 0.15    # ... but never more than this share of what the device has free right now (ADVICE r3)
+_DS_SPILL_ON = os.environ.get("PTR_ATTN_DS_SPILL", "1") != "0"      # A/B runs; read once at import
 
 
 def _ds_scratch(B, H, L, dev):
     """[B*H*L*L] scratch that lets the dQ kernel be ONE GEMM unit (dS . K) instead of recomputing S and dP (ptr_mhsa_backward's ds_ws);
-    None for short lists (the recomputation is cheap there), beyond DS_SPILL_MAX_BYTES, or with PTR_ATTN_DS_SPILL=0 (A/B runs)."""
-    import os
+    None — the recomputing dQ kernel — for short lists (the recomputation is cheap there), beyond DS_SPILL_MAX_BYTES or
+    DS_SPILL_FREE_FRACTION of the free device memory, when the allocation fails, or with PTR_ATTN_DS_SPILL=0."""
     n = B * H * L * L
-    if L < 128 or 4 * n > DS_SPILL_MAX_BYTES or os.environ.get("PTR_ATTN_DS_SPILL", "1") == "0":
+    if L < 128 or 4 * n > DS_SPILL_MAX_BYTES or not _DS_SPILL_ON:
         return None
-    return torch.empty(n, device=dev, dtype=torch.float32)
+    try:
+        free, _ = torch.cuda.mem_get_info(dev)
+        cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)       # the caching allocator can serve from this too
+        if 4 * n > DS_SPILL_FREE_FRACTION * (free + cached):
+            return None
+        return torch.empty(n, device=dev, dtype=torch.float32)
+    except torch.cuda.OutOfMemoryError:
+        return None
 
 
 class _MhsaCoreFn(torch.autograd.Function):

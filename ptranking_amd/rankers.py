@@ -114,9 +114,11 @@ class FusedStepMixin:
                       _lib.ptr(buf["loss_q"]), _lib.ptr(buf["dpreds"]), st)
             if fuse_step:
                 kind, lr, h1, h2, eps, wd, step, s1, s2 = self.optimizer.fused_step_args(flat)
-                _lib.call("ptr_mlp_backward_step", _lib.ptr(X), _lib.ptr(flat), _lib.ptr(buf["acts"]), _lib.ptr(buf["dpreds"]), R, Fd, NL, C.c_float(p),
-                          C.c_uint64(seed), _lib.ptr(buf["dz"]), _lib.ptr(buf["ws"]), _lib.ptr(flat.grad), kind, C.c_float(lr), C.c_float(h1),
-                          C.c_float(h2), C.c_float(eps), C.c_float(wd), step, _lib.ptr(s1), _lib.ptr(s2), _lib.ptr(buf["loss_q"]), B, _lib.ptr(loss), st)
+                try:
+                    self._launch_backward_step(X, flat, buf, R, Fd, NL, p, seed, kind, lr, h1, h2, eps, wd, step, s1, s2, B, loss, st)
+                except Exception:
+                    self.optimizer.state[flat]["step"] -= 1      # the launch failed: the bias-correction counter must not run ahead
+                    raise
             else:
                 _lib.call("ptr_mlp_backward", _lib.ptr(X), _lib.ptr(flat), _lib.ptr(buf["acts"]), _lib.ptr(buf["dpreds"]), R, Fd, NL, C.c_float(p),
                           C.c_uint64(seed), _lib.ptr(buf["dz"]), _lib.ptr(buf["ws"]), _lib.ptr(flat.grad), st)
@@ -124,6 +126,11 @@ class FusedStepMixin:
                     dp.all_reduce_sum(flat.grad)
                 self.optimizer.step_flat(flat)
         return loss.reshape(()), stop_training
+
+    def _launch_backward_step(self, X, flat, buf, R, Fd, NL, p, seed, kind, lr, h1, h2, eps, wd, step, s1, s2, B, loss, st):
+        _lib.call("ptr_mlp_backward_step", _lib.ptr(X), _lib.ptr(flat), _lib.ptr(buf["acts"]), _lib.ptr(buf["dpreds"]), R, Fd, NL, C.c_float(p),
+                  C.c_uint64(seed), _lib.ptr(buf["dz"]), _lib.ptr(buf["ws"]), _lib.ptr(flat.grad), kind, C.c_float(lr), C.c_float(h1),
+                  C.c_float(h2), C.c_float(eps), C.c_float(wd), step, _lib.ptr(s1), _lib.ptr(s2), _lib.ptr(buf["loss_q"]), B, _lib.ptr(loss), st)
 
     def _bucket(self, extra=0):
         if self._grad_bucket is None or self._grad_bucket.extra != extra:
@@ -147,6 +154,9 @@ class FusedStepMixin:
                 loss.backward()
                 if self._dp_single.grad is None:          # no gradient on this rank (e.g. an all-padding shard): every rank
                     self._dp_single.grad = torch.zeros_like(self._dp_single)   # must still join the collective
+                stack = getattr(self.optimizer, "stack", None)
+                if stack is not None:                     # flat-view optimiser: gradients that something re-pointed (module.zero_grad(),
+                    stack.reattach_grads()                # a foreign bucket) must be back in the flat buffer BEFORE it is reduced
                 dp.all_reduce_sum(self._dp_single.grad)
             else:
                 bucket = self._bucket()

@@ -344,7 +344,7 @@ class _FlatViewMixin:
         """dp.FlatGradBucket's interface over the flat gradient buffer itself (+ `extra` <= 4 scalars in its spare tail): the one
         all-reduce of a loss that ships scalars with its gradients (ApproxNDCG's batch coupling, RankMSE's batch mean)."""
         n = self.flat_param.numel()
-        return dp.ViewGradBucket(self.stack._gbuf, n, extra, self.zero_grad)
+        return dp.ViewGradBucket(self.stack._gbuf, n, extra, self.zero_grad, before_reduce=self.stack.reattach_grads)
 
 
 class FlatViewAdam(_FlatViewMixin, FlatAdam):

@@ -181,3 +181,31 @@ def test_row_offset_folding_and_view_bucket():
     assert zeroed == [1] and float(gbuf[:12].abs().sum()) == 0 and float(gbuf[12]) == 12.0
     with pytest.raises(ValueError):
         dp.ViewGradBucket(gbuf, 13, 2, lambda: None)
+
+
+def _uneven_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from ptranking_amd import dp
+    dp.init_from_env(backend="gloo")
+    seed, L = (77 << 32) | 12345, 16
+    lo, hi = dp.shard_queries(5)                      # 5 queries over 2 ranks: (0, 3) and (3, 5)
+    got = dp.local_dropout_seed(seed, (hi - lo) * L)                 # pointwise scorer: rows = documents
+    got_heads = dp.local_dropout_seed(seed, (hi - lo) * 2 * L)       # attention rows: queries x heads x documents
+    torch.save({"lo": lo, "hi": hi, "seed": got, "want": dp.fold_row_offset(seed, lo * L), "seed_heads": got_heads,
+                "want_heads": dp.fold_row_offset(seed, lo * 2 * L), "naive": dp.fold_row_offset(seed, rank * (hi - lo) * L)},
+               os.path.join(out_dir, f"u{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_uneven_shards_get_disjoint_mask_windows(tmp_path):
+    """with B % world != 0 shard_queries gives the remainder to the first ranks; `rank * local_rows` would start rank 1's dropout
+    rows at 2 * 16 = 32 while rank 0 owns rows 0..47 — overlapping mask windows.  The slice recorded by shard_queries() places every replica
+    at its true global row (queries in front x rows per query), for any rows-per-query unit, without a collective."""
+    port = _free_port()
+    mp.spawn(_uneven_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), f"u{r}.pt")) for r in range(2))
+    assert (r0["lo"], r0["hi"], r1["lo"], r1["hi"]) == (0, 3, 3, 5)
+    for r in (r0, r1):
+        assert r["seed"] == r["want"] and r["seed_heads"] == r["want_heads"]
+    assert r1["seed"] != r1["naive"]                  # rank 1: 3 * 16 = 48 rows in front of it, not 1 * 32

@@ -334,3 +334,58 @@ def test_replicas_draw_different_dropout_masks_and_reproduce_the_single_device_s
     ref = r.point_sf.flat.grad.detach().cpu()
     scale = max(1.0, float(ref.abs().max()))
     assert float((r0["grads"] - ref).abs().max()) <= 2e-5 * scale
+
+
+# ---- the RCCL code path itself: a process group of ONE rank over backend "nccl" (= RCCL on ROCm) is all a single-GPU box can execute
+def _rccl_single_worker(port, out_path, name):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", PTR_DP_INIT_SINGLE="1")
+    os.environ.pop("PTR_DP_BACKEND", None)
+    import ptranking_amd as pa
+    from ptranking_amd import dp
+    rank, world, local = dp.init_from_env()                    # backend defaults to nccl on a GPU box, device_id = cuda:0
+    assert (rank, world, local) == (0, 1, 0) and dist.is_initialized() and dist.get_backend() == "nccl"
+    X, Y = _data()
+    Xd, Yd = X.cuda(), Y.cuda()
+    out = {}
+    for collectives in (False, True):
+        dp.SINGLE_RANK_COLLECTIVES = collectives
+        assert dp.is_distributed() == collectives
+        r = _make(name)
+        dp.TIMING = []
+        for step in range(3):
+            loss, _ = r.train_op(Xd, Yd, epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
+        torch.cuda.synchronize()
+        out[collectives] = {"flat": r.point_sf.flat.detach().cpu(), "loss": float(loss.detach()), "allreduce_calls": len(dp.TIMING),
+                            "allreduce_ms": [a.elapsed_time(b) for a, b in dp.TIMING]}
+        dp.TIMING = None
+    dp.SINGLE_RANK_COLLECTIVES = False
+    # a plain RCCL all-reduce of the flat gradient buffer's size, value-checked (sum over one rank = identity)
+    t = torch.arange(34001, device="cuda", dtype=torch.float32)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    out["identity_ok"] = bool(torch.equal(t.cpu(), torch.arange(34001, dtype=torch.float32)))
+    torch.save(out, out_path)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["LambdaRank", "ApproxNDCG"])
+def test_rccl_process_group_of_one_runs_the_data_parallel_step(name, tmp_path):
+    """backend "nccl" initialised through dp.init_from_env (device_id bound), the data-parallel train step — backward -> RCCL all-reduce of the
+    flat gradient (+ ApproxNDCG's two scalars) -> optimiser step — executed through it and compared with the fused single-device step:
+    a sum over one rank must give bit-identical parameters.  (Two RCCL ranks need two GPUs: the driver's multi-GPU bench.)"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out_path = str(tmp_path / "rccl1.pt")
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_rccl_single_worker, args=(port, out_path, name))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0, f"RCCL worker exited with {p.exitcode}"
+    out = torch.load(out_path)
+    assert out["identity_ok"]
+    assert out[True]["allreduce_calls"] == 3 and out[False]["allreduce_calls"] == 0, (out[True]["allreduce_calls"], out[False]["allreduce_calls"])
+    d = float((out[True]["flat"] - out[False]["flat"]).abs().max())
+    if name == "LambdaRank":         # a sum of queries: the same kernels in the same order, the all-reduce adds nothing
+        assert torch.equal(out[True]["flat"], out[False]["flat"]), d
+        assert out[True]["loss"] == out[False]["loss"]
+    else:                            # ApproxNDCG's batch coupling: the DP step computes gradients at scale 1 and rescales by the reduced
+        assert d <= 2e-6, d          # sum(1/IDCG) (dp.py), the single-device step lets the kernel apply it — equal up to fp32 rounding
+        assert abs(out[True]["loss"] - out[False]["loss"]) <= 1e-5 * max(1.0, abs(out[False]["loss"]))
