@@ -1230,7 +1230,9 @@ int ptr::mlp_backward_impl(const char *who, const float *X, const float *params,
     MlpArgs a{R, F, NL, p_drop, (uint32_t)seed, (uint32_t)(seed >> 32)};
     if (R > 0 && bwd_fused_supported(F, NL, X, acts)) {
         // single pass: X and the stored activations are read once, dZ never leaves the chip (scorer_bwd.hip); dz is not touched
-        if (int e = launch_bwd_fused(X, params, acts, dpreds, a, ws, st, who)) return e;
+        // (bf16x6 formulation from PTR_BWD_X6's row threshold on, scorer_bwd_x6.hip; the fp32-MFMA kernel otherwise)
+        if (int e = bwd_x6_supported(R, F, NL, X, acts) ? launch_bwd_x6(X, params, acts, dpreds, a, ws, st, who)
+                                                        : launch_bwd_fused(X, params, acts, dpreds, a, ws, st, who)) return e;
         const int nb = bwd_fused_grid(R);
         const size_t NPf = n_params(NL, F);
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((NPf + 63) / 64) + (opt.loss_out ? 1 : 0)), dim3(1024), 0, st, ws, nb, nb, NPf, NPf, NPf,

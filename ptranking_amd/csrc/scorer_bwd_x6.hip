@@ -1,0 +1,433 @@
+// Single-pass fused backward of the pointsf scorer on bf16 matrix instructions with fp32 results ("bf16 x 6", see scorer_x6.hip for the
+// arithmetic): dZ chain + every weight gradient in ONE kernel that reads X and the stored activations once and never materialises dZ in HBM.
+//
+// Reference: the autograd backward of ptranking/base/point_ranker.py:45-55 + ptranking/base/utils.py:288-356
+// ((Dropout -> Linear -> ReLU) x 3 -> Linear).  Served: three hidden layers, 129 <= F <= 143, F % 4 == 0 (the shapes of the fp32-MFMA fused
+// backward, scorer_bwd.hip, whose partial-gradient layout and reduction it shares); everything else takes the fp32 kernels.
+//
+// Structure.  A persistent 8-wave workgroup per CU walks slabs of 32 documents (two 16-document tiles = one 32-deep contraction slice of
+// the weight gradients).  Per slab the operands live in LDS as bf16 PLANE IMAGES [3 planes][32 documents][features] (row stride 224 B for
+// 112 features, 288 B for the 144 of X — strides ds_read_b64_tr_b16 reads without bank conflicts, scratch/x6probe):
+//     ZA, ZB   dZ of the hidden layers (dZ3 -> ZA, dZ2 -> ZB, dZ1 -> ZA again)
+//     A1, A2   the stored activations of layers 1 / 2 (column 100 = the ones column the forward stores: column 100 of a dW tile row is db)
+//     XI       the input features with the input dropout recomputed (column F = 1: db of layer 1)
+// and are consumed by v_mfma_f32_16x16x32_bf16 in two roles:
+//   * dZ chain ("transposed world"): dA^T[in][doc] = W^T[in][out] * dZ^T[out][doc].  Wave w (0..6) owns in-feature tile w of both chain
+//     layers and keeps its W^T fragments — split into planes once, in the prologue — in REGISTERS for the whole kernel (2 layers x 4 slices
+//     x 3 planes); the B operand is a ds_read_b128 of a dZ image (8 consecutive out-features of one document), the result is gated by the
+//     stored activation (a 4-bit mask kept from the staging pass), split and written back as the next dZ image.
+//   * weight gradients ("document-contraction world"): dW_l[out][in] = sum_docs dZ_l[doc][out] * A_{l-1}[doc][in] with the slab's 32 documents
+//     as the k index: both operands come out of the [doc][feature] images through ds_read_b64_tr_b16, the transpose-read that hands lane
+//     (feature, group G) the documents 4G..4G+3 (+16) of its feature.  Wave w owns out-feature row w of dW_3, dW_2 and in-tiles 0..3 of
+//     dW_1; wave 7 (no chain tile) owns in-tiles 4..8 of dW_1 for all seven rows: 18 / 35 accumulator tiles per wave, all in registers.
+// The stored activations of the NEXT slab land in an fp32 staging area by LDS-DMA while the current slab is multiplied; X and dLoss/dscore
+// are prefetched into registers.  Four barriers per slab: staging pass | chain 3 + dW_3 | chain 2 + dW_2 | dW_1.
+// Results are bit-stable: fixed tile ownership, fixed document order, per-workgroup partials reduced by reduce_partials_kernel.
+#include "ptr_mlp.h"
+
+namespace ptr {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+using i16x4 = __attribute__((ext_vector_type(4))) short;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+union BFrag { bf16x8 v; u32x4 q; uint32_t u[4]; };
+
+constexpr int kB6S = 32;                        // documents per slab
+constexpr int kB6ZRS = 224, kB6ZPL = kB6S * kB6ZRS, kB6ZIMG = 3 * kB6ZPL;        // 112-column images: row stride, plane, image (21504 B)
+constexpr int kB6XRS = 288, kB6XPL = kB6S * kB6XRS, kB6XIMG = 3 * kB6XPL;        // the X image: 144 columns (27648 B)
+constexpr int kB6STG = kB6S * kAL * 4;                                           // fp32 staging of one layer's slab (14336 B)
+constexpr int kB6_ZA = 0, kB6_ZB = kB6ZIMG, kB6_A1 = 2 * kB6ZIMG, kB6_A2 = 3 * kB6ZIMG, kB6_XI = 4 * kB6ZIMG, kB6_ST = kB6_XI + kB6XIMG;
+constexpr int kB6Lds = kB6_ST + 3 * kB6STG + 256;                                // + a zero pad the last image's over-read lands in
+static_assert(kB6Lds <= 160 * 1024, "LDS budget");
+
+__device__ __forceinline__ uint32_t b6_cvt_pk(float x0, float x1) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{x0, x1}, bf16x2)); }
+// two fp32 values -> one dword of each plane (round-to-nearest split, see scorer_x6.hip split_pack2)
+__device__ __forceinline__ void b6_split2(float x0, float x1, uint32_t &p1, uint32_t &p2, uint32_t &p3) {
+    p1 = b6_cvt_pk(x0, x1);
+    const float r0 = x0 - __uint_as_float(p1 << 16), r1 = x1 - __uint_as_float(p1 & 0xffff0000u);
+    p2 = b6_cvt_pk(r0, r1);
+    const float s0 = r0 - __uint_as_float(p2 << 16), s1 = r1 - __uint_as_float(p2 & 0xffff0000u);
+    p3 = b6_cvt_pk(s0, s1);
+}
+using lds_u32x4_b = __attribute__((address_space(3))) u32x4;
+using lds_u32x2_b = __attribute__((address_space(3))) u32x2;
+using lds_f32x4_b = __attribute__((address_space(3))) f32x4;
+using lds_i16x4_b = __attribute__((address_space(3))) i16x4;
+__device__ __forceinline__ uint32_t b6_lds_addr(const void *p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p; }
+// Global memory is read through buffer resources (32-bit lane offset + scalar offset; out-of-range lanes read zeros): 64-bit per-lane
+// pointers cost two registers per (piece, tile) once hipcc hoists their loop-invariant parts.
+using b6_srd = __attribute__((ext_vector_type(4))) int;
+using b6_rsrc = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ b6_srd b6_make_srd(const void *p, uint32_t bytes) {
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    return b6_srd{(int)(uint32_t)a, (int)((uint32_t)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+// 64 lanes x 16 bytes, buffer (lane offset + scalar offset) -> LDS (wave-uniform base + lane * 16); invisible to hipcc's waitcnt bookkeeping
+__device__ __forceinline__ void b6_bdma16(b6_srd srd, uint32_t voff, uint32_t soff, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(srd), "s"(soff), "s"(lds_dst) : "memory");
+}
+// four consecutive features of one document -> the three planes of an image (8 bytes each)
+__device__ __forceinline__ void b6_write4(uint32_t addr, int plane_bytes, const f32x4 v) {
+    uint32_t a[3], b[3];
+    b6_split2(v[0], v[1], a[0], a[1], a[2]);
+    b6_split2(v[2], v[3], b[0], b[1], b[2]);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<lds_u32x2_b *>((uintptr_t)(addr + (uint32_t)(p * plane_bytes))) = u32x2{a[p], b[p]};
+}
+// LDS writes of this wave complete (lgkmcnt) -> workgroup barrier; NOT __syncthreads(): its fence would also drain the DMA / prefetch loads
+__device__ __forceinline__ void b6_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// A scalar the compiler cannot fold: image bases go through this INSIDE the slab loop, or hipcc precomputes one address register per (image,
+// plane, tile) combination — the images lie past the 64 KB ds offset range — hoists the dozens of them out of the loop and spills them
+__device__ __forceinline__ uint32_t b6_opaque(uint32_t x) { asm volatile("" : "+s"(x)); return x; }
+#define B6_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16((A).v, (B).v, (C), 0, 0, 0)
+
+template <int NT1>
+__global__ void __launch_bounds__(512, 2)
+mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, const float *__restrict__ acts, const float *__restrict__ dpreds,
+                  MlpArgs a, float *__restrict__ ws, size_t np_stride) {
+    static_assert(NT1 == 9, "the X image is laid out for nine in-feature tiles");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_b6[];
+    constexpr int NL = 3;
+    const int F = a.F, R = a.R;
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, W = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lds0 = b6_lds_addr(smem_b6);
+    const int nslabs = (R + kB6S - 1) / kB6S;
+    const uint32_t thr = a.p_drop > 0.0f ? drop_thr(a.p_drop) : 0u;
+    const float scale = a.p_drop > 0.0f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+    const bool chain = W < 7;
+    // every image starts as zeros (rows of documents past R in the last slab are read before anything was written there: 0 x NaN = NaN)
+    for (int i = tid; i < kB6Lds / 16; i += 512) reinterpret_cast<u32x4 *>(smem_b6)[i] = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();                       // before the first DMA lands in the staging area
+
+    // ---- persistent registers: ONE array of 42 x 4, used by role (a single instruction stream allocates the maximum over the waves anyway —
+    // separate arrays for the chain fragments and the accumulators would add up: 296 spills in the first build):
+    //   chain wave w: st[0..4] dW_3 row w in-tiles 0..4, st[5..9] dW_2 row w in-tiles 0..4, st[10..17] dW_1 row w in-tiles 0..7 (18 accumulator
+    //                 tiles); its W^T fragments as bits: st[18 + 3 (3 c + s) + p] = plane p of the full slice s < 3 of chain layer c, and the
+    //                 contraction TAIL (out-features 96..99 + the zero padding to 111) as 16-deep fragments, two dwords per plane: dword
+    //                 2 (3 c + p) + {0, 1} of st[36..38] — 21 fragment slots instead of 24, and no B fragment reads past its image row
+    //   wave 7:       st[2 m + q] dW_3 row m in-tile 5 + q, st[14 + 2 m + q] the same of dW_2, st[28 + m] dW_1 row m in-tile 8 (35 tiles)
+    // so that every phase is balanced: 48 chain + 30 dW MFMAs per chain wave against 84 dW MFMAs of wave 7 in the two chain phases, 48 / 42 in
+    // the last one.
+    f32x4 st[39];
+#pragma unroll
+    for (int i = 0; i < 39; ++i) st[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float wo4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (chain) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {              // chain c = 0: layer 2 (dZ3 -> dA2), c = 1: layer 1 (dZ2 -> dA1)
+            const float *Wl = P + off_W(2 - c, F);
+            const int ri = 16 * W + j;                              // in-feature = row of W^T
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = 32 * s + 8 * g + e;               // out-feature = contraction index (< 96)
+                    v[e] = ri < kH ? Wl[(size_t)k * kH + ri] : 0.0f;
+                }
+                BFrag pl[3];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) b6_split2(v[2 * d], v[2 * d + 1], pl[0].u[d], pl[1].u[d], pl[2].u[d]);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) st[18 + 3 * (3 * c + s) + p] = __builtin_bit_cast(f32x4, pl[p].q);
+            }
+            {   // tail: k = 96 + 4 g + e, e < 4
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const int k = 96 + 4 * g + e; v[e] = (ri < kH && k < kH) ? Wl[(size_t)k * kH + ri] : 0.0f; }
+                uint32_t t0[3], t1[3];
+                b6_split2(v[0], v[1], t0[0], t0[1], t0[2]);
+                b6_split2(v[2], v[3], t1[0], t1[1], t1[2]);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const int d = 2 * (3 * c + p);                  // dword index among the 12 tail dwords (st[36..38])
+                    st[36 + d / 4][d % 4] = __uint_as_float(t0[p]);
+                    st[36 + d / 4][d % 4 + 1] = __uint_as_float(t1[p]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int f = 16 * W + 4 * g + r; wo4[r] = f < kH ? P[off_wout(NL, F) + f] : 0.0f; }
+    }
+    float awo[4] = {0.0f, 0.0f, 0.0f, 0.0f}, abo = 0.0f;
+
+    // per-lane addresses
+    const uint32_t wr_z = (uint32_t)(j * kB6ZRS + 8 * g);            // + 16 dt rows, + 32 tile bytes: this lane's 8 bytes of a 112-column image row
+    const uint32_t wr_x = (uint32_t)(j * kB6XRS + 8 * g);
+    const uint32_t rd_b = (uint32_t)(j * kB6ZRS + 16 * g);           // chain B fragment: document j, 8 features from 32 s + 8 g
+    const uint32_t rd_t = (uint32_t)(j * kB6ZRS + 192 + 8 * g);      // ... of the 16-deep tail: 4 features from 96 + 4 g
+    const uint32_t tr_z = (uint32_t)((4 * g + (j >> 2)) * kB6ZRS + 8 * (j & 3));     // transpose-read chunk of a 112-column image
+    const uint32_t tr_x = (uint32_t)((4 * g + (j >> 2)) * kB6XRS + 8 * (j & 3));
+    const uint32_t st_a = (uint32_t)(j * (kAL * 4) + 16 * g);        // fp32 staging: document j, 4 features from 16 tile + 4 g
+
+    // the slab's fragment of tile t (16 features x 32 documents) of an image, k slot (G, e): e < 4 document 4 G + e, e >= 4 document 16 + 4 G + e - 4
+    auto read_tr = [&](BFrag (&f)[3], uint32_t img_lane, int plane_bytes, int row_bytes, int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_i16x4_b *>((uintptr_t)(img_lane + (uint32_t)(p * plane_bytes + 32 * t))));
+            const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_i16x4_b *>((uintptr_t)(img_lane + (uint32_t)(p * plane_bytes + 32 * t + 16 * row_bytes))));
+            const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+            f[p].u[0] = l2[0]; f[p].u[1] = l2[1]; f[p].u[2] = h2[0]; f[p].u[3] = h2[1];
+        }
+    };
+    auto mma6 = [&](f32x4 &c, const BFrag (&af)[3], const BFrag (&bf)[3]) __attribute__((always_inline)) {
+        c = B6_MFMA(af[0], bf[2], c); c = B6_MFMA(af[1], bf[1], c); c = B6_MFMA(af[2], bf[0], c);
+        c = B6_MFMA(af[0], bf[1], c); c = B6_MFMA(af[1], bf[0], c); c = B6_MFMA(af[0], bf[0], c);
+    };
+    auto mma6w = [&](f32x4 &c, int w0, const BFrag (&bf)[3]) __attribute__((always_inline)) {       // A = the W^T fragment kept in st[w0 .. w0 + 2]
+        const bf16x8 a0 = __builtin_bit_cast(bf16x8, st[w0]), a1 = __builtin_bit_cast(bf16x8, st[w0 + 1]), a2 = __builtin_bit_cast(bf16x8, st[w0 + 2]);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bf[2].v, c, 0, 0, 0); c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bf[1].v, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, bf[0].v, c, 0, 0, 0); c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bf[1].v, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bf[0].v, c, 0, 0, 0); c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bf[0].v, c, 0, 0, 0);
+    };
+    // the 16-deep tail of chain layer cl: A = its two dwords per plane out of st[36..38], B = 8 bytes per plane (features 96 + 4 g .. + 3)
+    auto mma6t = [&](f32x4 &c, int cl, const u32x2 (&bt)[3]) __attribute__((always_inline)) {       // cl: constant after unrolling
+        i16x4 at[3], bb[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int d = 2 * (3 * cl + p);
+            at[p] = __builtin_bit_cast(i16x4, u32x2{__float_as_uint(st[36 + d / 4][d % 4]), __float_as_uint(st[36 + d / 4][d % 4 + 1])});
+            bb[p] = __builtin_bit_cast(i16x4, bt[p]);
+        }
+        c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(at[0], bb[2], c, 0, 0, 0); c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(at[1], bb[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(at[2], bb[0], c, 0, 0, 0); c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(at[0], bb[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(at[1], bb[0], c, 0, 0, 0); c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(at[0], bb[0], c, 0, 0, 0);
+    };
+    // one dW row: A fragment = dZ tile `mo` of image zimg, B fragments = in-tiles n0 .. n0 + NN - 1 of image aimg
+    auto dw_row = [&](auto nn_, int acc0, uint32_t zimg, int mo, uint32_t aimg_lane, int a_plane, int a_row, int n0) __attribute__((always_inline)) {
+        constexpr int NN = decltype(nn_)::value;
+        BFrag za[3];
+        read_tr(za, zimg + tr_z + (uint32_t)(32 * mo), kB6ZPL, kB6ZRS, 0);
+#pragma unroll
+        for (int n = 0; n < NN; ++n) {
+            BFrag ab[3];
+            read_tr(ab, aimg_lane, a_plane, a_row, n0 + n);
+            mma6(st[acc0 + n], za, ab);
+            __builtin_amdgcn_sched_barrier(0);        // one fragment in flight: the scheduler otherwise issues every read of the row up front and spills
+        }
+    };
+
+    // ---- prefetch state: X tiles and dLoss/dscore of the next slab in registers, its stored activations by DMA into the staging area
+    f32x4 xr[2][2];                        // X of the CURRENT slab, [tile slot][doc tile]: chain wave: slot 0 = tile w; wave 7: tiles 7, 8 — loaded
+                                           // behind B1, turned into the XI image in front of B3 (it is only read by the dW_1 phase)
+    float dsv[2];
+    const b6_rsrc xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0, (int)((uint32_t)R * (uint32_t)(F * 4)), 0x00020000);
+    const b6_rsrc dsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dpreds), 0, (int)((uint32_t)R * 4u), 0x00020000);
+    const b6_srd asrd = b6_make_srd(acts, (uint32_t)NL * (uint32_t)R * (kAL * 4));       // host: NL * R * 448 and R * F * 4 < 4 GB
+    uint32_t jx = (uint32_t)j * (uint32_t)(F * 4) + (uint32_t)g * 16, j4 = (uint32_t)j * 4, l16 = (uint32_t)lane * 16;
+    asm volatile("" : "+v"(jx), "+v"(j4), "+v"(l16));
+    auto load_x = [&](int slab) __attribute__((always_inline)) {
+        const int row0 = slab * kB6S;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                const int t = chain ? W : 7 + sl;                    // rows past R: zeros; columns past F: the next row's numbers (selected away)
+                if (!(chain && sl == 1))
+                    xr[sl][dt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrd, (int)jx, (int)((uint32_t)(row0 + 16 * dt) * (uint32_t)(F * 4) + (uint32_t)(64 * t)), 0));
+            }
+    };
+    // dropout key of the X site: row * kDropRowMul + fg * kDropFgMul + seed_lo with fg = 4 t + g — the lane part in ONE register, the rest scalar
+    uint32_t jk = (uint32_t)j * kDropRowMul + (uint32_t)g * kDropFgMul + a.seed_lo;
+    asm volatile("" : "+v"(jk));
+    auto stage_x_tile = [&](int row0, int t, const f32x4 (&x2)[2]) __attribute__((always_inline)) {
+        int col = 16 * t + 4 * g;
+        asm volatile("" : "+v"(col));          // opaque: the column selects below are computed here, not hoisted as 24 lane masks (spilled SGPR pairs)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            uint32_t w0, w1;
+            drop_bits_key(jk + ((uint32_t)(row0 + 16 * dt) * kDropRowMul + (uint32_t)(4 * t) * kDropFgMul), a.seed_hi, w0, w1);
+            f32x4 v = drop4(x2[dt], w0, w1, thr, scale);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = col + r < F ? v[r] : (col + r == F ? 1.0f : 0.0f);      // the ones column: column F of dW_1 is db_1
+            b6_write4(b6_opaque(lds0 + kB6_XI + (uint32_t)(32 * t)) + wr_x + (uint32_t)(16 * dt * kB6XRS), kB6XPL, v);
+        }
+    };
+    auto stage_x = [&](int slab) __attribute__((always_inline)) {
+        if (chain) stage_x_tile(slab * kB6S, W, xr[0]);
+        else { stage_x_tile(slab * kB6S, 7, xr[0]); stage_x_tile(slab * kB6S, 8, xr[1]); }
+    };
+    // the next slab's stored activations by DMA into the staging area, its dLoss/dscore into registers
+    auto prefetch = [&](int slab) __attribute__((always_inline)) {
+        const int row0 = slab * kB6S;
+        // a slab image is contiguous in a layer (row stride = 448 B): 14 pieces of 1 KB per layer, 42 in all (pieces past the end of a layer's
+        // rows read the next layer / zeros: those documents carry dLoss/dscore = 0)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int k = W + 8 * q;                                 // scalar
+            if (k < 3 * 14) {
+                const int layer = k / 14, ch = k - 14 * layer;
+                b6_bdma16(asrd, l16, (uint32_t)layer * (uint32_t)R * (kAL * 4) + (uint32_t)row0 * (kAL * 4) + (uint32_t)ch * 1024,
+                          __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(kB6_ST + layer * kB6STG + ch * 1024)));
+            }
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)                               // rows past R: out of range, 0 — exactly the gradient they must contribute
+            dsv[dt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dsrd, (int)j4, (int)((uint32_t)(row0 + 16 * dt) * 4u), 0));
+    };
+    const int slab0 = blockIdx.x;
+    prefetch(slab0 < nslabs ? slab0 : nslabs - 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                       // zero fill + first staging visible to every wave
+
+    for (int slab = slab0; slab < nslabs; slab += gridDim.x) {
+        const int row0 = slab * kB6S;
+        uint32_t m2 = 0u, m1 = 0u;                     // gate bits (activation > 0) of this lane's 2 x 4 elements of layers 2 / 1
+        // ---- staging pass: dZ3, the plane images of A2 / A1 / X
+        if (chain) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const uint32_t so = b6_opaque(lds0 + (uint32_t)(kB6_ST + 64 * W)) + st_a + (uint32_t)(16 * dt * kAL * 4);
+                const f32x4 a1 = *reinterpret_cast<lds_f32x4_b *>((uintptr_t)so);
+                const f32x4 a2 = *reinterpret_cast<lds_f32x4_b *>((uintptr_t)(so + kB6STG));
+                const f32x4 a3 = *reinterpret_cast<lds_f32x4_b *>((uintptr_t)(so + 2 * kB6STG));
+                const float ds = dsv[dt];
+                f32x4 z3;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    z3[r] = a3[r] > 0.0f ? ds * wo4[r] : 0.0f;
+                    awo[r] = fmaf(ds, a3[r], awo[r]);
+                    m2 |= (a2[r] > 0.0f ? 1u : 0u) << (4 * dt + r);
+                    m1 |= (a1[r] > 0.0f ? 1u : 0u) << (4 * dt + r);
+                }
+                if (W == 0 && g == 0) abo += ds;
+                const uint32_t wo = wr_z + b6_opaque(lds0 + (uint32_t)(32 * W)) + (uint32_t)(16 * dt * kB6ZRS);
+                b6_write4(wo + kB6_ZA, kB6ZPL, z3);
+                b6_write4(wo + kB6_A2, kB6ZPL, a2);       // (ZA .. A2 lie within the 64 KB the ds offset field reaches from `wo`)
+                b6_write4(wo + kB6_A1, kB6ZPL, a1);
+            }
+        }
+        b6_barrier();                                                // B1: images complete, staging consumed
+        {
+            const int nxt = slab + (int)gridDim.x;
+            prefetch(nxt < nslabs ? nxt : nslabs - 1);
+            load_x(slab);
+        }
+        // ---- chain 3 (dZ3 -> dZ2) + dW_3, chain 2 (dZ2 -> dZ1) + dW_2
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const uint32_t zin = b6_opaque(lds0 + (c == 0 ? kB6_ZA : kB6_ZB)), zout = b6_opaque(lds0 + (c == 0 ? kB6_ZB : kB6_ZA) + (uint32_t)(32 * W));
+            const uint32_t aim = b6_opaque(lds0 + (c == 0 ? kB6_A2 : kB6_A1));
+            if (chain) {
+                f32x4 cc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        BFrag b[3];
+#pragma unroll
+                        for (int p = 0; p < 3; ++p)
+                            b[p].q = *reinterpret_cast<lds_u32x4_b *>((uintptr_t)(zin + rd_b + (uint32_t)(p * kB6ZPL + 16 * dt * kB6ZRS + 64 * s)));
+                        mma6w(cc[dt], 18 + 3 * (3 * c + s), b);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    u32x2 bt[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        bt[p] = *reinterpret_cast<lds_u32x2_b *>((uintptr_t)(zin + rd_t + (uint32_t)(p * kB6ZPL + 16 * dt * kB6ZRS)));
+                    mma6t(cc[dt], c, bt);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const uint32_t m = c == 0 ? m2 : m1;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    f32x4 dz;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dz[r] = (m >> (4 * dt + r)) & 1u ? cc[dt][r] * scale : 0.0f;
+                    b6_write4(zout + wr_z + (uint32_t)(16 * dt * kB6ZRS), kB6ZPL, dz);
+                }
+                // dW of the layer whose dZ is the chain's INPUT: row w, in-tiles 0..4 of the activations below it
+                dw_row(std::integral_constant<int, 5>{}, 5 * c, zin, W, aim + tr_z, kB6ZPL, kB6ZRS, 0);
+            } else {
+#pragma unroll
+                for (int mo = 0; mo < 7; ++mo)       // wave 7: in-tiles 5, 6 of every row
+                    dw_row(std::integral_constant<int, 2>{}, 14 * c + 2 * mo, zin, mo, aim + tr_z, kB6ZPL, kB6ZRS, 5);
+            }
+            if (c == 1) stage_x(slab);                               // the XI image, complete at B3
+            b6_barrier();                                            // B2 / B3
+        }
+        // ---- dW_1: dZ1 (in ZA) x the X image
+        {
+            const uint32_t za = b6_opaque(lds0 + kB6_ZA), xi = b6_opaque(lds0 + kB6_XI) + tr_x;
+            if (chain) {
+                dw_row(std::integral_constant<int, 8>{}, 10, za, W, xi, kB6XPL, kB6XRS, 0);
+            } else {
+#pragma unroll
+                for (int mo = 0; mo < 7; ++mo) dw_row(std::integral_constant<int, 1>{}, 28 + mo, za, mo, xi, kB6XPL, kB6XRS, 8);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the next slab's staging has landed
+        b6_barrier();                                                // B4
+    }
+
+    // ---- this workgroup's partial gradient, flat parameter layout (every element written exactly once)
+    float *out = ws + (size_t)blockIdx.x * np_stride;
+    auto store_tile = [&](const f32x4 &c, int layer, int mo, int ni) __attribute__((always_inline)) {
+        const int K = layer == 0 ? F : kH;
+        const int in = 16 * ni + j;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = 16 * mo + 4 * g + r;
+            if (o < kH) {
+                if (in < K) out[off_W(layer, F) + (size_t)o * K + in] = c[r];
+                else if (in == K) out[off_b(layer, F) + o] = c[r];
+            }
+        }
+    };
+    if (chain) {
+#pragma unroll
+        for (int n = 0; n < 5; ++n) { store_tile(st[n], 2, W, n); store_tile(st[5 + n], 1, W, n); }
+#pragma unroll
+        for (int n = 0; n < 8; ++n) store_tile(st[10 + n], 0, W, n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = awo[r];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m, 64);
+            const int f = 16 * W + 4 * g + r;
+            if (j == 0 && f < kH) out[off_wout(NL, F) + f] = v;
+        }
+        if (W == 0) {
+            float v = abo;
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m, 64);
+            if (lane == 0) out[off_wout(NL, F) + kH] = v;
+        }
+    } else {
+#pragma unroll
+        for (int mo = 0; mo < 7; ++mo) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { store_tile(st[2 * mo + q], 2, mo, 5 + q); store_tile(st[14 + 2 * mo + q], 1, mo, 5 + q); }
+            store_tile(st[28 + mo], 0, mo, 8);
+        }
+    }
+}
+
+static int bwd_x6_mode() {                   // PTR_BWD_X6: "0" never, "1" (default) from 98 304 documents on, "2" always (tests); read per call
+    const char *e = getenv("PTR_BWD_X6");
+    return e ? atoi(e) : 1;
+}
+bool bwd_x6_supported(int R, int F, int NL, const void *X, const void *acts) {
+    const int mode = bwd_x6_mode();
+    if (mode == 0 || (mode == 1 && R < 98304)) return false;
+    const int NT1 = (F + 15) / 16;
+    return NL == 3 && NT1 == 9 && F % 4 == 0 && F < 16 * NT1 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 && (reinterpret_cast<uintptr_t>(acts) & 15) == 0;
+}
+int launch_bwd_x6(const float *X, const float *params, const float *acts, const float *dpreds, const MlpArgs &a, float *ws, hipStream_t st,
+                  const char *who) {
+    const int grid = bwd_fused_grid(a.R);
+    const size_t NP = n_params(a.NL, a.F);
+    auto kern = mlp_bwd_x6_kernel<9>;
+    if (int e = allow_lds(kern, kB6Lds)) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), kB6Lds, st, X, params, acts, dpreds, a, ws, NP);
+    return check_hip(hipGetLastError(), who);
+}
+
+}  // namespace ptr
