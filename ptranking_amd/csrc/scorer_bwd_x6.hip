@@ -40,7 +40,8 @@ constexpr int kB6ZRS = 224, kB6ZPL = kB6S * kB6ZRS, kB6ZIMG = 3 * kB6ZPL;       
 constexpr int kB6XRS = 288, kB6XPL = kB6S * kB6XRS, kB6XIMG = 3 * kB6XPL;        // the X image: 144 columns (27648 B)
 constexpr int kB6STG = kB6S * kAL * 4;                                           // fp32 staging of one layer's slab (14336 B)
 constexpr int kB6_ZA = 0, kB6_ZB = kB6ZIMG, kB6_A1 = 2 * kB6ZIMG, kB6_A2 = 3 * kB6ZIMG, kB6_XI = 4 * kB6ZIMG, kB6_ST = kB6_XI + kB6XIMG;
-constexpr int kB6Lds = kB6_ST + 3 * kB6STG + 256;                                // + a zero pad the last image's over-read lands in
+constexpr int kB6_WO = kB6_ST + 3 * kB6STG;                                      // w_out [112] (re-read per slab: four registers less)
+constexpr int kB6Lds = kB6_WO + 512;
 static_assert(kB6Lds <= 160 * 1024, "LDS budget");
 
 __device__ __forceinline__ uint32_t b6_cvt_pk(float x0, float x1) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{x0, x1}, bf16x2)); }
@@ -116,7 +117,6 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
     f32x4 st[39];
 #pragma unroll
     for (int i = 0; i < 39; ++i) st[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    float wo4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (chain) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {              // chain c = 0: layer 2 (dZ3 -> dA2), c = 1: layer 1 (dZ2 -> dA1)
@@ -151,19 +151,16 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
                 }
             }
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const int f = 16 * W + 4 * g + r; wo4[r] = f < kH ? P[off_wout(NL, F) + f] : 0.0f; }
     }
+    if (tid < kHP) reinterpret_cast<float *>(smem_b6 + kB6_WO)[tid] = tid < kH ? P[off_wout(NL, F) + tid] : 0.0f;
     float awo[4] = {0.0f, 0.0f, 0.0f, 0.0f}, abo = 0.0f;
 
     // per-lane addresses
     const uint32_t wr_z = (uint32_t)(j * kB6ZRS + 8 * g);            // + 16 dt rows, + 32 tile bytes: this lane's 8 bytes of a 112-column image row
     const uint32_t wr_x = (uint32_t)(j * kB6XRS + 8 * g);
     const uint32_t rd_b = (uint32_t)(j * kB6ZRS + 16 * g);           // chain B fragment: document j, 8 features from 32 s + 8 g
-    const uint32_t rd_t = (uint32_t)(j * kB6ZRS + 192 + 8 * g);      // ... of the 16-deep tail: 4 features from 96 + 4 g
     const uint32_t tr_z = (uint32_t)((4 * g + (j >> 2)) * kB6ZRS + 8 * (j & 3));     // transpose-read chunk of a 112-column image
     const uint32_t tr_x = (uint32_t)((4 * g + (j >> 2)) * kB6XRS + 8 * (j & 3));
-    const uint32_t st_a = (uint32_t)(j * (kAL * 4) + 16 * g);        // fp32 staging: document j, 4 features from 16 tile + 4 g
 
     // the slab's fragment of tile t (16 features x 32 documents) of an image, k slot (G, e): e < 4 document 4 G + e, e >= 4 document 16 + 4 G + e - 4
     auto read_tr = [&](BFrag (&f)[3], uint32_t img_lane, int plane_bytes, int row_bytes, int t) __attribute__((always_inline)) {
@@ -198,21 +195,35 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
         c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(at[2], bb[0], c, 0, 0, 0); c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(at[0], bb[1], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(at[1], bb[0], c, 0, 0, 0); c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(at[0], bb[0], c, 0, 0, 0);
     };
-    // one dW row: A fragment = dZ tile `mo` of image zimg, B fragments = in-tiles n0 .. n0 + NN - 1 of image aimg
-    auto dw_row = [&](auto nn_, int acc0, uint32_t zimg, int mo, uint32_t aimg_lane, int a_plane, int a_row, int n0) __attribute__((always_inline)) {
+    // one dW row: A fragment = dZ tile `mo` of image zimg, B fragments = in-tiles n0 .. n0 + NN - 1 of image aimg.  PIPE: the next B fragment is
+    // read while the current one is multiplied (12 registers more: only where the phase has them — not in chain 2, where X is in flight)
+    auto dw_row = [&](auto nn_, auto pipe_, int acc0, uint32_t zimg, int mo, uint32_t aimg_lane, int a_plane, int a_row, int n0) __attribute__((always_inline)) {
         constexpr int NN = decltype(nn_)::value;
+        constexpr bool PIPE = decltype(pipe_)::value;
         BFrag za[3];
         read_tr(za, zimg + tr_z + (uint32_t)(32 * mo), kB6ZPL, kB6ZRS, 0);
+        if constexpr (PIPE && NN > 1) {
+            BFrag ab[2][3];
+            read_tr(ab[0], aimg_lane, a_plane, a_row, n0);
 #pragma unroll
-        for (int n = 0; n < NN; ++n) {
-            BFrag ab[3];
-            read_tr(ab, aimg_lane, a_plane, a_row, n0 + n);
-            mma6(st[acc0 + n], za, ab);
-            __builtin_amdgcn_sched_barrier(0);        // one fragment in flight: the scheduler otherwise issues every read of the row up front and spills
+            for (int n = 0; n < NN; ++n) {
+                if (n + 1 < NN) read_tr(ab[(n + 1) & 1], aimg_lane, a_plane, a_row, n0 + n + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma6(st[acc0 + n], za, ab[n & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int n = 0; n < NN; ++n) {
+                BFrag ab[3];
+                read_tr(ab, aimg_lane, a_plane, a_row, n0 + n);
+                mma6(st[acc0 + n], za, ab);
+                __builtin_amdgcn_sched_barrier(0);        // one fragment in flight: the scheduler otherwise issues every read of the row up front and spills
+            }
         }
     };
 
-    // ---- prefetch state: X tiles and dLoss/dscore of the next slab in registers, its stored activations by DMA into the staging area
+    // ---- prefetch state: the stored activations of the next slab by DMA, dLoss/dscore in registers; X of the current slab in registers
     f32x4 xr[2][2];                        // X of the CURRENT slab, [tile slot][doc tile]: chain wave: slot 0 = tile w; wave 7: tiles 7, 8 — loaded
                                            // behind B1, turned into the XI image in front of B3 (it is only read by the dW_1 phase)
     float dsv[2];
@@ -235,7 +246,8 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
     // dropout key of the X site: row * kDropRowMul + fg * kDropFgMul + seed_lo with fg = 4 t + g — the lane part in ONE register, the rest scalar
     uint32_t jk = (uint32_t)j * kDropRowMul + (uint32_t)g * kDropFgMul + a.seed_lo;
     asm volatile("" : "+v"(jk));
-    auto stage_x_tile = [&](int row0, int t, const f32x4 (&x2)[2]) __attribute__((always_inline)) {
+    auto stage_x_tile = [&](int row0, int t_, const f32x4 (&x2)[2]) __attribute__((always_inline)) {
+        const int t = (int)b6_opaque((uint32_t)t_);
         int col = 16 * t + 4 * g;
         asm volatile("" : "+v"(col));          // opaque: the column selects below are computed here, not hoisted as 24 lane masks (spilled SGPR pairs)
 #pragma unroll
@@ -275,14 +287,23 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                       // zero fill + first staging visible to every wave
 
+#ifdef PTR_B6_TRACE       // experiment builds: shader-clock stamps of workgroup 0 behind its partial gradient (ws is sized for 2 partials per CU)
+    unsigned long long *trace = reinterpret_cast<unsigned long long *>(ws + (size_t)gridDim.x * np_stride) + W * 256;
+    int nstamp = 0;
+#define B6_STAMP() do { if (blockIdx.x == 0 && lane == 0 && nstamp < 256) trace[nstamp++] = clock64(); } while (0)
+#else
+#define B6_STAMP() do { } while (0)
+#endif
     for (int slab = slab0; slab < nslabs; slab += gridDim.x) {
+        B6_STAMP();
         const int row0 = slab * kB6S;
         uint32_t m2 = 0u, m1 = 0u;                     // gate bits (activation > 0) of this lane's 2 x 4 elements of layers 2 / 1
         // ---- staging pass: dZ3, the plane images of A2 / A1 / X
         if (chain) {
+            const f32x4 wo4 = *reinterpret_cast<lds_f32x4_b *>((uintptr_t)(b6_opaque(lds0 + (uint32_t)(kB6_WO + 64 * W)) + (uint32_t)(16 * g)));
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                const uint32_t so = b6_opaque(lds0 + (uint32_t)(kB6_ST + 64 * W)) + st_a + (uint32_t)(16 * dt * kAL * 4);
+                const uint32_t so = b6_opaque(lds0 + (uint32_t)(kB6_ST + 64 * W)) + 2 * wr_z + (uint32_t)(16 * dt * kAL * 4);     // j * 448 + 16 g
                 const f32x4 a1 = *reinterpret_cast<lds_f32x4_b *>((uintptr_t)so);
                 const f32x4 a2 = *reinterpret_cast<lds_f32x4_b *>((uintptr_t)(so + kB6STG));
                 const f32x4 a3 = *reinterpret_cast<lds_f32x4_b *>((uintptr_t)(so + 2 * kB6STG));
@@ -302,36 +323,51 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
                 b6_write4(wo + kB6_A1, kB6ZPL, a1);
             }
         }
+        B6_STAMP();
         b6_barrier();                                                // B1: images complete, staging consumed
+        B6_STAMP();
         {
             const int nxt = slab + (int)gridDim.x;
             prefetch(nxt < nslabs ? nxt : nslabs - 1);
-            load_x(slab);
         }
         // ---- chain 3 (dZ3 -> dZ2) + dW_3, chain 2 (dZ2 -> dZ1) + dW_2
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
+            if (c == 1) load_x(slab);                               // behind B2: live through this phase only (registers), staged in front of B3
             const uint32_t zin = b6_opaque(lds0 + (c == 0 ? kB6_ZA : kB6_ZB)), zout = b6_opaque(lds0 + (c == 0 ? kB6_ZB : kB6_ZA) + (uint32_t)(32 * W));
             const uint32_t aim = b6_opaque(lds0 + (c == 0 ? kB6_A2 : kB6_A1));
             if (chain) {
                 f32x4 cc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+                auto read_b = [&](BFrag (&b)[3], int u) __attribute__((always_inline)) {       // u = 2 s + dt
 #pragma unroll
-                for (int s = 0; s < 3; ++s)
+                    for (int p = 0; p < 3; ++p)
+                        b[p].q = *reinterpret_cast<lds_u32x4_b *>((uintptr_t)(zin + rd_b + (uint32_t)(p * kB6ZPL + 16 * (u & 1) * kB6ZRS + 64 * (u >> 1))));
+                };
+                if (c == 0) {                        // chain 3 has the registers for a fragment in flight beside the one being multiplied
+                    BFrag b[2][3];
+                    read_b(b[0], 0);
 #pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
-                        BFrag b[3];
-#pragma unroll
-                        for (int p = 0; p < 3; ++p)
-                            b[p].q = *reinterpret_cast<lds_u32x4_b *>((uintptr_t)(zin + rd_b + (uint32_t)(p * kB6ZPL + 16 * dt * kB6ZRS + 64 * s)));
-                        mma6w(cc[dt], 18 + 3 * (3 * c + s), b);
+                    for (int u = 0; u < 6; ++u) {
+                        if (u + 1 < 6) read_b(b[(u + 1) & 1], u + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mma6w(cc[u & 1], 18 + 3 * (3 * c + (u >> 1)), b[u & 1]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) {
+                        BFrag b[3];
+                        read_b(b, u);
+                        mma6w(cc[u & 1], 18 + 3 * (3 * c + (u >> 1)), b);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
                     u32x2 bt[3];
 #pragma unroll
                     for (int p = 0; p < 3; ++p)
-                        bt[p] = *reinterpret_cast<lds_u32x2_b *>((uintptr_t)(zin + rd_t + (uint32_t)(p * kB6ZPL + 16 * dt * kB6ZRS)));
+                        bt[p] = *reinterpret_cast<lds_u32x2_b *>((uintptr_t)(zin + wr_z + (uint32_t)(192 + p * kB6ZPL + 16 * dt * kB6ZRS)));
                     mma6t(cc[dt], c, bt);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -344,26 +380,31 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
                     b6_write4(zout + wr_z + (uint32_t)(16 * dt * kB6ZRS), kB6ZPL, dz);
                 }
                 // dW of the layer whose dZ is the chain's INPUT: row w, in-tiles 0..4 of the activations below it
-                dw_row(std::integral_constant<int, 5>{}, 5 * c, zin, W, aim + tr_z, kB6ZPL, kB6ZRS, 0);
+                if (c == 0) dw_row(std::integral_constant<int, 5>{}, std::true_type{}, 0, zin, W, aim + tr_z, kB6ZPL, kB6ZRS, 0);
+                else dw_row(std::integral_constant<int, 5>{}, std::false_type{}, 5, zin, W, aim + tr_z, kB6ZPL, kB6ZRS, 0);
             } else {
 #pragma unroll
                 for (int mo = 0; mo < 7; ++mo)       // wave 7: in-tiles 5, 6 of every row
-                    dw_row(std::integral_constant<int, 2>{}, 14 * c + 2 * mo, zin, mo, aim + tr_z, kB6ZPL, kB6ZRS, 5);
+                    dw_row(std::integral_constant<int, 2>{}, std::false_type{}, 14 * c + 2 * mo, zin, mo, aim + tr_z, kB6ZPL, kB6ZRS, 5);
             }
             if (c == 1) stage_x(slab);                               // the XI image, complete at B3
+            B6_STAMP();
             b6_barrier();                                            // B2 / B3
+            B6_STAMP();
         }
         // ---- dW_1: dZ1 (in ZA) x the X image
         {
             const uint32_t za = b6_opaque(lds0 + kB6_ZA), xi = b6_opaque(lds0 + kB6_XI) + tr_x;
             if (chain) {
-                dw_row(std::integral_constant<int, 8>{}, 10, za, W, xi, kB6XPL, kB6XRS, 0);
+                dw_row(std::integral_constant<int, 8>{}, std::true_type{}, 10, za, W, xi, kB6XPL, kB6XRS, 0);
             } else {
 #pragma unroll
-                for (int mo = 0; mo < 7; ++mo) dw_row(std::integral_constant<int, 1>{}, 28 + mo, za, mo, xi, kB6XPL, kB6XRS, 8);
+                for (int mo = 0; mo < 7; ++mo) dw_row(std::integral_constant<int, 1>{}, std::false_type{}, 28 + mo, za, mo, xi, kB6XPL, kB6XRS, 8);
             }
         }
+        B6_STAMP();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the next slab's staging has landed
+        B6_STAMP();
         b6_barrier();                                                // B4
     }
 
@@ -410,14 +451,17 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
     }
 }
 
-static int bwd_x6_mode() {                   // PTR_BWD_X6: "0" never, "1" (default) from 98 304 documents on, "2" always (tests); read per call
+// PTR_BWD_X6 (read per call): "1" selects this kernel wherever it serves the shape.  It is OPT-IN: r4 measured it at parity with the fp32-MFMA
+// fused backward (610 vs 600 us at 524 288 x 136; both spend ~21 K cycles per 32-document slab, of which the MFMAs are 6.6 K here and 16 K
+// there: the four barrier-separated phases, the staging pass and the LDS traffic set the time, not the matrix pipe) — see DESIGN.md 3.2.
+static int bwd_x6_mode() {
     const char *e = getenv("PTR_BWD_X6");
-    return e ? atoi(e) : 1;
+    return e ? atoi(e) : 0;
 }
 bool bwd_x6_supported(int R, int F, int NL, const void *X, const void *acts) {
-    const int mode = bwd_x6_mode();
-    if (mode == 0 || (mode == 1 && R < 98304)) return false;
+    if (bwd_x6_mode() == 0) return false;
     const int NT1 = (F + 15) / 16;
+    if ((uint64_t)NL * (uint64_t)R * (kAL * 4) >= 0xFFFFF000ull || (uint64_t)R * (uint64_t)F * 4 >= 0xFFFFF000ull) return false;     // buffer resources: < 4 GB
     return NL == 3 && NT1 == 9 && F % 4 == 0 && F < 16 * NT1 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 && (reinterpret_cast<uintptr_t>(acts) & 15) == 0;
 }
 int launch_bwd_x6(const float *X, const float *params, const float *acts, const float *dpreds, const MlpArgs &a, float *ws, hipStream_t st,

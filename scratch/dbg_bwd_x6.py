@@ -15,7 +15,7 @@ for F, R in ((136, 2085), (136, 32), (132, 777), (140, 4096 + 5), (136, 131072),
     ws = torch.empty(_lib.query("ptr_mlp_backward_ws_floats", F, NL), device="cuda")
     g = {}
     for mode in ("0", "2"):
-        os.environ["PTR_BWD_X6"] = mode
+        os.environ["PTR_BWD_X6"] = "1" if mode == "2" else "0"
         grad = torch.full_like(fused.flat.data, float("nan"))
         def bwd():
             _lib.call("ptr_mlp_backward", _lib.ptr(X), _lib.ptr(fused.flat.data), _lib.ptr(acts), _lib.ptr(dp), R, F, NL, C.c_float(0.1), C.c_uint64(77), None,

@@ -157,3 +157,88 @@ def test_x6_is_the_default_forward_at_bench_scale_and_deterministic(monkeypatch)
         _lib.TIMING = None
     assert names == ["ptr_mlp_forward", "ptr_mlp_forward_x6"], names
     assert torch.equal(b1, b2) and torch.isfinite(a).all()
+
+
+# ---- the bf16x6 fused backward (csrc/scorer_bwd_x6.hip; opt-in: PTR_BWD_X6=1)
+@pytest.mark.parametrize("F,R", [(136, 2085), (136, 32), (136, 1), (132, 777), (140, 4101), (136, 65536 + 37)])
+@pytest.mark.parametrize("p", [0.1, 0.0])
+def test_x6_backward_matches_float64_modules_and_the_fp32_kernel(F, R, p, monkeypatch):
+    """Gradients of sum(w * scores) through the stored activations of a training forward: the bf16x6 backward against float64 CPU modules
+    (same dropout masks) with the tolerance of the fp32-MFMA backward's tests, and against the fp32-MFMA fused backward on identical inputs."""
+    from ptranking_amd import _lib
+    from ptranking_amd.scorer import FusedPointScorer
+    from ptranking_amd.host import build_pointsf
+    NL = 3
+    torch.manual_seed(R + F)
+    fused = FusedPointScorer(F, num_layers=NL, dropout=p).cuda()
+    fused.train()
+    X = torch.randn(R, F, device="cuda")
+    w = torch.randn(R, device="cuda")
+    seed = 99 + R
+    preds = torch.empty(R, device="cuda")
+    acts = torch.empty(NL, R, 112, device="cuda")
+    st = _lib.current_stream(X.device)
+    _lib.call("ptr_mlp_forward", _lib.ptr(X), _lib.ptr(fused.flat.data), R, F, NL, 1, C.c_float(p), C.c_uint64(seed), _lib.ptr(preds), _lib.ptr(acts), st)
+    ws = torch.empty(_lib.query("ptr_mlp_backward_ws_floats", F, NL), device="cuda")
+    grads = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PTR_BWD_X6", mode)
+        g = torch.full_like(fused.flat.data, float("nan"))
+        _lib.call("ptr_mlp_backward", _lib.ptr(X), _lib.ptr(fused.flat.data), _lib.ptr(acts), _lib.ptr(w), R, F, NL, C.c_float(p), C.c_uint64(seed), None,
+                  _lib.ptr(ws), _lib.ptr(g), st)
+        torch.cuda.synchronize()
+        assert not torch.isnan(g).any(), "every parameter's gradient must be written"
+        grads[mode] = g.cpu().double()
+    # float64 reference with the kernel's masks
+    ref = build_pointsf(num_features=F, num_layers=NL, AF="R", BN=False, apply_tl_af=False, dropout=0.0).double()
+    ref.load_state_dict({k: v.cpu().double() for k, v in fused.state_dict().items()})
+    lin = [m for m in ref if isinstance(m, torch.nn.Linear)]
+    a = X.cpu().double()
+    if p > 0:
+        a = a * fused.dropout_mask(R, 0, seed).cpu().double() / (1 - p)
+    for l in range(NL):
+        h = torch.relu(lin[l](a))
+        a = h * fused.dropout_mask(R, l + 1, seed).cpu().double() / (1 - p) if (p > 0 and l < NL - 1) else h
+    (lin[NL](a).reshape(-1) * w.cpu().double()).sum().backward()
+    gref = torch.cat([q.grad.reshape(-1) for q in ref.parameters()])
+    off = 0
+    for q in ref.parameters():
+        n = q.numel()
+        scale = max(1.0, float(gref[off:off + n].abs().max()))
+        e6 = float((grads["1"][off:off + n] - gref[off:off + n]).abs().max())
+        e32 = float((grads["0"][off:off + n] - gref[off:off + n]).abs().max())
+        # Both kernels read the SAME stored activations, so a pre-activation at rounding distance of its ReLU kink (the float64 reference gates it
+        # the other way: one document's contribution to a whole weight row) moves both by the same amount: the float64 bar of
+        # tests/test_scorer_gpu.py (5e-5) applies where no gate flipped, "not worse than the fp32-MFMA backward" everywhere, and the two kernels
+        # agree with each other to fp32 rounding
+        assert e6 <= max(5e-5 * scale, 1.5 * e32 + 2e-6 * scale), (off, e6, e32, scale)
+        d = float((grads["1"][off:off + n] - grads["0"][off:off + n]).abs().max())
+        assert d <= 2e-5 * scale, (off, d, scale)
+        off += n
+
+
+def test_x6_backward_is_bit_stable_and_opt_in(monkeypatch):
+    from ptranking_amd import _lib
+    from ptranking_amd.scorer import FusedPointScorer
+    F, NL, R = 136, 3, 32768 + 11
+    fused = FusedPointScorer(F, num_layers=NL, dropout=0.1).cuda()
+    X = torch.randn(R, F, device="cuda"); w = torch.randn(R, device="cuda")
+    preds = torch.empty(R, device="cuda"); acts = torch.empty(NL, R, 112, device="cuda")
+    st = _lib.current_stream(X.device)
+    _lib.call("ptr_mlp_forward", _lib.ptr(X), _lib.ptr(fused.flat.data), R, F, NL, 1, C.c_float(0.1), C.c_uint64(5), _lib.ptr(preds), _lib.ptr(acts), st)
+    ws = torch.empty(_lib.query("ptr_mlp_backward_ws_floats", F, NL), device="cuda")
+
+    def bwd():
+        g = torch.empty_like(fused.flat.data)
+        _lib.call("ptr_mlp_backward", _lib.ptr(X), _lib.ptr(fused.flat.data), _lib.ptr(acts), _lib.ptr(w), R, F, NL, C.c_float(0.1), C.c_uint64(5), None,
+                  _lib.ptr(ws), _lib.ptr(g), st)
+        torch.cuda.synchronize()
+        return g
+    monkeypatch.delenv("PTR_BWD_X6", raising=False)
+    g_default = bwd()
+    monkeypatch.setenv("PTR_BWD_X6", "0")
+    assert torch.equal(g_default, bwd()), "unset PTR_BWD_X6 must mean the fp32-MFMA backward"
+    monkeypatch.setenv("PTR_BWD_X6", "1")
+    a, b = bwd(), bwd()
+    assert torch.equal(a, b), "fixed tile ownership and document order: two launches give identical bits"
+    assert not torch.equal(a, g_default)              # a different summation, so the kernel really ran
