@@ -37,7 +37,8 @@ sort_desc_kernel(const float *__restrict__ preds, const int32_t *__restrict__ le
         if (i < Lp) keys[i] = own[m];
     }
     __syncthreads();
-    count_ranks_fast<G, DPT>(keys, si_, n, t, own, rk);      // si_ doubles as the permutation-check scratch before it is filled
+    if constexpr (G == kWave) count_ranks_wave<DPT>(keys, sv, n, Lp, t, own, rk);   // leaves sv = keys in descending order
+    else count_ranks_fast<G, DPT>(keys, si_, n, t, own, rk);      // si_ doubles as the permutation-check scratch before it is filled
     if constexpr (G == kWave) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
     else __syncthreads();
 #pragma unroll
@@ -68,15 +69,24 @@ __global__ void __launch_bounds__(kBlock)
 batch_max_kernel(const float *__restrict__ labels, const int32_t *__restrict__ lens, int B, int L, int *__restrict__ out_key) {
     __shared__ float red[4];
     float mx = -INFINITY;
-    for (int q = blockIdx.x; q < B; q += gridDim.x) {
-        const int n = query_len(lens, q, L);
-        for (int i = threadIdx.x; i < n; i += kBlock) mx = fmaxf(mx, labels[(size_t)q * L + i]);
+    // flat, coalesced walk over the B x L label matrix (the per-query form left 3/4 of a workgroup idle at L = 64); the (query, position)
+    // pair of an element advances incrementally with the grid stride
+    const size_t total = (size_t)B * L, stride = (size_t)gridDim.x * kBlock;
+    const int dq = (int)(stride / L), di = (int)(stride % L);
+    size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    int q = (int)(e / L), i = (int)(e % L);
+    for (; e < total; e += stride) {
+        if (!lens || i < query_len(lens, q, L)) mx = fmaxf(mx, labels[e]);
+        q += dq; i += di;
+        if (i >= L) { i -= L; ++q; }
     }
     mx = group_max<kBlock>(mx, red, threadIdx.x);
     if (threadIdx.x == 0) atomicMax(out_key, float_to_ordered(mx));
 }
 
 // ------------------------------------------------------------------------------------------------ metrics
+// 2^l - 1 on the transcendental pipe alone (v_exp_f32: exact for the integer grades, 1 ulp otherwise; labels are far from its denormal range)
+__device__ __forceinline__ float gain_fast(float label) { return __builtin_amdgcn_exp2f(label) - 1.0f; }
 // LDS per group (floats): S_id[Lp] | Y_id[Lp] | Y_sys[Lp]
 template <int G, int DPT>
 __global__ void __launch_bounds__(kBlock)
@@ -111,20 +121,44 @@ metrics_kernel(const float *__restrict__ preds, const float *__restrict__ labels
     int rk[DPT];
     // ranks by packed fma-clamp counting (one VALU slot per compare; ties / overflow fall back to the exact compares) — the O(L^2) count
     // is what the kernel's time is made of: 0.54 -> 0.2 ms for 65 536 x 256.  Y_id (not staged yet) is the permutation-check scratch.
-    count_ranks_fast<G, DPT>(S_id, reinterpret_cast<int *>(Y_id), n, t, si, rk);
+    if constexpr (G == kWave) count_ranks_wave<DPT>(S_id, Y_id, n, Lp, t, si, rk);  // bitonic sort + binary search (Y_id: scratch)
+    else count_ranks_fast<G, DPT>(S_id, reinterpret_cast<int *>(Y_id), n, t, si, rk);
 #pragma unroll
     for (int m = 0; m < DPT; ++m) {
         const int i = t + m * G;
         if (i < n) Y_sys[rk[m]] = li[m];                    // torch.gather(labels, idx), ranker.py:52
     }
     __syncthreads();
-    stage_ideal_order<G, DPT>(S_id, Y_id, n, Lp, t, presort != 0, si, li, ipos);   // ends with a barrier
+    if constexpr (G == kWave) {
+        // only the ideal LABELS are walked below, and equal labels are interchangeable: a value-only sort, no tie handling
+        (void)ipos;
+#pragma unroll
+        for (int m = 0; m < DPT; ++m) {
+            const int i = t + m * G;
+            if (i < Lp) Y_id[i] = i < n ? li[m] : (presort ? 0.0f : -INFINITY);
+        }
+        if (!presort) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float v[DPT];
+#pragma unroll
+            for (int r = 0; r < DPT; ++r) v[r] = t * DPT + r < Lp ? Y_id[t * DPT + r] : -INFINITY;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            wave_sort_desc<DPT>(v, t);
+#pragma unroll
+            for (int r = 0; r < DPT; ++r) { if (t * DPT + r < Lp) Y_id[t * DPT + r] = t * DPT + r < n ? v[r] : 0.0f; }
+        }
+        __syncthreads();
+    } else {
+        stage_ideal_order<G, DPT>(S_id, Y_id, n, Lp, t, presort != 0, si, li, ipos);   // ends with a barrier
+    }
 
     // ---- wave 0 of the group walks the two rankings
     if (valid && t < kWave) {
         const int lane = t;
         const float max_label = max_label_dev ? ordered_to_float(reinterpret_cast<const int *>(max_label_dev)[0]) : max_label_host;
-        const float pow_max = exp2f(max_label);              // adhoc_metric.py:133
+        const float rpow_max = 1.0f / exp2f(max_label);      // adhoc_metric.py:133 (2^max_label: the reciprocal of a power of two is exact)
         float *r_ndcg = o_ndcg ? o_ndcg + (size_t)q * ck.nk : nullptr;
         float *r_nerr = o_nerr ? o_nerr + (size_t)q * ck.nk : nullptr;
         float *r_ap = o_ap ? o_ap + (size_t)q * ck.nk : nullptr;
@@ -145,22 +179,22 @@ metrics_kernel(const float *__restrict__ preds, const float *__restrict__ labels
             const int r = ch * 64 + lane;
             const bool in = r < kmax;
             const float ys = in ? Y_sys[r] : 0.0f, yi = in ? Y_id[r] : 0.0f;
-            const float disc = log2f((float)r + 2.0f);
+            const float rdisc = __builtin_amdgcn_rcpf(__builtin_amdgcn_logf((float)r + 2.0f));   // 1 / log2(rank + 2): v_log_f32, v_rcp_f32 (1 ulp each)
             // DCG gain: 2^l - 1 for graded labels, the raw label for LABEL_TYPE.Permutation (adhoc_metric.py:207-212,225-230)
-            const float gs = in ? (linear_gain ? ys : gain_of(ys)) : 0.0f, gi = in ? (linear_gain ? yi : gain_of(yi)) : 0.0f;
-            const float sdcg = wave_incl_sum(in ? gs / disc : 0.0f, lane) + c_sdcg;     // adhoc_metric.py:233-234
-            const float idcg = wave_incl_sum(in ? gi / disc : 0.0f, lane) + c_idcg;
+            const float gs = in ? (linear_gain ? ys : gain_fast(ys)) : 0.0f, gi = in ? (linear_gain ? yi : gain_fast(yi)) : 0.0f;
+            const float sdcg = wave_incl_sum(in ? gs * rdisc : 0.0f, lane) + c_sdcg;     // adhoc_metric.py:233-234
+            const float idcg = wave_incl_sum(in ? gi * rdisc : 0.0f, lane) + c_idcg;
             const float rel = in ? fminf(fmaxf(ys, 0.0f), 1.0f) : 0.0f;                // binary relevance (:106)
             const float cumrel = wave_incl_sum(rel, lane) + c_rel;
-            const float pr = cumrel / ((float)r + 1.0f);                                // rank-wise precision (:111)
+            const float rr = __builtin_amdgcn_rcpf((float)r + 1.0f);
+            const float pr = cumrel * rr;                                // rank-wise precision (:111)
             const float cumprec = wave_incl_sum(pr * rel, lane) + c_prec;               // (:112)
             const float cumideal = wave_incl_sum(yi, lane) + c_ideal;                   // GRADED ideal labels (:114)
-            const float ssat = gs / pow_max, isat = gi / pow_max;                       // (:133)
+            const float ssat = gs * rpow_max, isat = gi * rpow_max;                       // (:133)
             // cascade: product of (1 - sat) over EARLIER ranks (:135-143) = exclusive prefix product
             const float s_incl = wave_incl_prod(in ? 1.0f - ssat : 1.0f, lane), i_incl = wave_incl_prod(in ? 1.0f - isat : 1.0f, lane);
             float s_excl = __shfl_up(s_incl, 1, 64), i_excl = __shfl_up(i_incl, 1, 64);
             if (lane == 0) { s_excl = 1.0f; i_excl = 1.0f; }
-            const float rr = 1.0f / ((float)r + 1.0f);
             const float serr = wave_incl_sum(in ? rr * ssat * (s_excl * c_sun) : 0.0f, lane) + c_serr;
             const float ierr = wave_incl_sum(in ? rr * isat * (i_excl * c_iun) : 0.0f, lane) + c_ierr;
             if (in) {
@@ -192,9 +226,9 @@ extern "C" int ptr_sort_desc(const float *preds, const int32_t *lens, int B, int
     if (int rc = check_batch(preds, vals, B, L, who)) return rc;
     if (B > 0 && !idx) { set_error("%s: NULL output pointer", who); return PTR_ERR_INVALID_ARG; }
     if (B == 0) return 0;
-    const int Lp = round_up(L, 4);
-    return dispatch_tiling(L, [&]<int G, int DPT>() -> int {
+    return dispatch_wave_tiling(L, [&]<int G, int DPT>() -> int {
         constexpr int QPB = kBlock / G;
+        const int Lp = G == kWave ? kWave * DPT : round_up(L, 4);      // one wavefront per query sorts 64*DPT padded keys
         auto kern = sort_desc_kernel<G, DPT>;
         const size_t lds = (size_t)QPB * 3 * Lp * sizeof(float);
         if (int e = allow_lds(kern, lds)) return e;
@@ -228,14 +262,15 @@ extern "C" int ptr_metrics_at_ks(const float *preds, const float *labels, const 
     const float *ml_dev = nullptr;
     if (nerr && max_label < 0.0f) {
         if (int rc = check_hip(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(max_label_ws), (int)0x80000000, 1, st), who)) return rc;
-        hipLaunchKernelGGL(batch_max_kernel, dim3(B < 2048 ? B : 2048), dim3(kBlock), 0, st, labels, lens, B, L,
+        const size_t cells = ((size_t)B * L + kBlock - 1) / kBlock;
+        hipLaunchKernelGGL(batch_max_kernel, dim3((unsigned)(cells < 2048 ? cells : 2048)), dim3(kBlock), 0, st, labels, lens, B, L,
                            reinterpret_cast<int *>(max_label_ws));
         if (int rc = check_hip(hipGetLastError(), who)) return rc;
         ml_dev = max_label_ws;
     }
-    const int Lp = round_up(L, 4);
-    return dispatch_tiling(L, [&]<int G, int DPT>() -> int {
+    return dispatch_wave_tiling(L, [&]<int G, int DPT>() -> int {
         constexpr int QPB = kBlock / G;
+        const int Lp = G == kWave ? kWave * DPT : round_up(L, 4);
         auto kern = metrics_kernel<G, DPT>;
         const size_t lds = (size_t)QPB * 3 * Lp * sizeof(float);
         if (int e = allow_lds(kern, lds)) return e;

@@ -48,6 +48,18 @@ template <class F> inline int dispatch_tiling(int L, F &&f) {
     return f.template operator()<256, 16>();
 }
 
+// Tiling of the sort / metric kernels: ONE wavefront per query up to 1024 documents (the rank step is a register bitonic sort of
+// 64*DPT keys, ptr_device.h wave_sort_desc), the four-wave counting form beyond.
+template <class F> inline int dispatch_wave_tiling(int L, F &&f) {
+    if (L <= 64) return f.template operator()<64, 1>();
+    if (L <= 128) return f.template operator()<64, 2>();
+    if (L <= 256) return f.template operator()<64, 4>();
+    if (L <= 512) return f.template operator()<64, 8>();
+    if (L <= 1024) return f.template operator()<64, 16>();
+    if (L <= 2048) return f.template operator()<256, 8>();
+    return f.template operator()<256, 16>();
+}
+
 // Raises the dynamic-LDS cap of `kernel` when a launch needs more than the 64 KiB default.
 template <class K> inline int allow_lds(K kernel, size_t bytes) {
     if (bytes <= 64 * 1024) return 0;
@@ -284,6 +296,100 @@ __device__ __forceinline__ void count_ranks_fast(const float *keys, int *mark, i
     if constexpr (G == kWave) any = __any(redo);
     else any = __syncthreads_or(redo);
     if (any) count_ranks<G, DPT>(keys, n, t, own, rk);
+}
+
+// ---- one wavefront sorts 64*E keys held E per lane (bitonic network in registers)
+// Value of lane (lane ^ X): DPP inside the 16-lane rows where a control exists (quad_perm, row_half_mirror, row_mirror, row_ror:8),
+// the LDS crossbar otherwise (ds_swizzle bit mode inside 32 lanes, ds_bpermute across the halves).
+template <int X> __device__ __forceinline__ float lane_xor(float v, int lane) {
+    const int s = __builtin_bit_cast(int, v);
+    int r;
+    if constexpr (X == 1) r = __builtin_amdgcn_update_dpp(s, s, 0xB1, 0xF, 0xF, false);            // quad_perm:[1,0,3,2]
+    else if constexpr (X == 2) r = __builtin_amdgcn_update_dpp(s, s, 0x4E, 0xF, 0xF, false);       // quad_perm:[2,3,0,1]
+    else if constexpr (X == 3) r = __builtin_amdgcn_update_dpp(s, s, 0x1B, 0xF, 0xF, false);       // quad_perm:[3,2,1,0]
+    else if constexpr (X == 7) r = __builtin_amdgcn_update_dpp(s, s, 0x141, 0xF, 0xF, false);      // row_half_mirror
+    else if constexpr (X == 15) r = __builtin_amdgcn_update_dpp(s, s, 0x140, 0xF, 0xF, false);     // row_mirror
+    else if constexpr (X == 8) r = __builtin_amdgcn_update_dpp(s, s, 0x128, 0xF, 0xF, false);      // row_ror:8
+    else if constexpr (X == 4 || X == 16 || X == 31) r = __builtin_amdgcn_ds_swizzle(s, (X << 10) | 0x1F);   // bit mode: and 0x1F, xor X
+    else r = __builtin_amdgcn_ds_bpermute((lane ^ X) << 2, s);
+    return __builtin_bit_cast(float, r);
+}
+constexpr int top_bit(int x) { int b = 1; while (b * 2 <= x) b *= 2; return b; }
+// Compare-exchange of positions p and p ^ X inside the lane's registers (X < E); the lower position keeps the larger key.
+// v_med3_f32 against +-inf is max / min without the canonicalising extra instruction fmaxf / fminf bring, and returns one of its inputs
+// bit for bit (NaNs are screened before the sort).
+template <int E, int X> __device__ __forceinline__ void bitonic_local(float (&v)[E]) {
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        if ((r & top_bit(X)) == 0) {
+            const float a = v[r], b = v[r ^ X];
+            v[r] = __builtin_amdgcn_fmed3f(a, b, INFINITY);
+            v[r ^ X] = __builtin_amdgcn_fmed3f(a, b, -INFINITY);
+        }
+    }
+}
+// Compare-exchange with lane (lane ^ LX); FLIP: against the partner's register E-1-r (the mirror step of a merge), else register r.
+// The lane whose top differing bit is clear keeps the maximum: one v_med3_f32 against a per-lane +-inf.
+template <int E, int LX, bool FLIP> __device__ __forceinline__ void bitonic_cross(float (&v)[E], int lane) {
+    const float bound = __builtin_bit_cast(float, 0x7F800000 | ((lane & top_bit(LX)) ? (int)0x80000000 : 0));
+    float p[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) p[r] = lane_xor<LX>(v[FLIP ? E - 1 - r : r], lane);
+#pragma unroll
+    for (int r = 0; r < E; ++r) v[r] = __builtin_amdgcn_fmed3f(v[r], p[r], bound);
+}
+template <int E, int J> __device__ __forceinline__ void bitonic_halves(float (&v)[E], int lane) {   // half-cleaners J, J/2, ..., 1
+    if constexpr (J >= 1) {
+        if constexpr (J < E) bitonic_local<E, J>(v);
+        else bitonic_cross<E, J / E, false>(v, lane);
+        bitonic_halves<E, J / 2>(v, lane);
+    }
+}
+template <int E, int K> __device__ __forceinline__ void bitonic_phases(float (&v)[E], int lane) {   // merges of size K, 2K, ..., 64E
+    if constexpr (K <= 64 * E) {
+        if constexpr (K <= E) bitonic_local<E, K - 1>(v);                   // mirror step p <-> p ^ (K-1): every direction is "descending"
+        else bitonic_cross<E, K / E - 1, true>(v, lane);
+        bitonic_halves<E, K / 4>(v, lane);
+        bitonic_phases<E, K * 2>(v, lane);
+    }
+}
+// Sorts the 64*E keys v[r] = key at position lane*E + r into descending order (position 0 = maximum).  No NaNs.  36 compare-exchange
+// stages for 256 keys = ~230 VALU / crossbar instructions per wavefront, against 65 536 / 64 packed compares of the counting form.
+template <int E> __device__ __forceinline__ void wave_sort_desc(float (&v)[E], int lane) { bitonic_phases<E, 2>(v, lane); }
+
+// count_ranks_fast() for a group of ONE wavefront: sort the keys, then each document finds its rank in the sorted row by binary search
+// (rank = #{k_j > k_i}); ties among the n valid keys (adjacent equal entries) and NaNs send the wave to the exact count_ranks().
+// keys[]: LDS, entries [0, Lp) (Lp = round_up(n.., 4), padded with -inf beyond n); sorted[]: LDS scratch of 64*DPT floats, left holding
+// the keys in descending order (-inf beyond n).  own[m] / index t + m*64 as everywhere.  Wave-level barriers only.
+template <int DPT>
+__device__ __forceinline__ void count_ranks_wave(const float *keys, float *sorted, int n, int Lp, int t, const float (&own)[DPT], int (&rk)[DPT]) {
+    constexpr int N = kWave * DPT;
+    float v[DPT];
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < DPT; ++r) {
+        const int p = t * DPT + r;
+        v[r] = p < Lp ? keys[p] : -INFINITY;
+        bad |= v[r] != v[r];
+    }
+    wave_sort_desc<DPT>(v, t);
+    const float nxt = __shfl_down(v[0], 1, 64);                              // first key of the next lane (lane 63: unused, its pairs end past n)
+#pragma unroll
+    for (int r = 0; r < DPT; ++r) {
+        const int p = t * DPT + r;
+        sorted[p] = v[r];
+        bad |= p + 1 < n && v[r] == (r + 1 < DPT ? v[(r + 1) % DPT] : nxt);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (__any(bad)) { count_ranks<kWave, DPT>(keys, n, t, own, rk); return; }
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) rk[m] = 0;
+#pragma unroll
+    for (int step = N / 2; step >= 1; step >>= 1) {
+#pragma unroll
+        for (int m = 0; m < DPT; ++m) rk[m] += sorted[rk[m] + step - 1] > own[m] ? step : 0;
+    }
 }
 
 // Ideal-order staging shared by LambdaLoss / ApproxNDCG / the metric kernel.
