@@ -60,7 +60,9 @@ lambdaloss_kernel(const float *__restrict__ preds, const float *__restrict__ lab
         yp[m] = p < Lp ? Y_id[p] : 0.0f;
         if (p < n) part += gain_of(yp[m]) / log2f((float)p + 2.0f);     // adhoc_metric.py:205-217 on the ideal ranking
     }
-    count_ranks_fast<G, DPT>(S_id, reinterpret_cast<int *>(pk), n, t, sp, rk);   // lambdaloss.py:89 (pk, filled below, is the check scratch)
+    // lambdaloss.py:89 (pk, filled below, is the scratch of either form: 4*Lp floats >= the 64*DPT sorted keys of the one-wave form)
+    if constexpr (G == kWave) count_ranks_wave<DPT>(S_id, reinterpret_cast<float *>(pk), n, Lp, t, sp, rk);
+    else count_ranks_fast<G, DPT>(S_id, reinterpret_cast<int *>(pk), n, t, sp, rk);
     const float idcg = group_sum<G>(part, red, t);
 #pragma unroll
     for (int m = 0; m < DPT; ++m) {
@@ -222,9 +224,10 @@ extern "C" int ptr_lambdaloss_fwd_bwd(const float *preds, const float *labels, c
     }
     hipStream_t st = as_stream(stream);
     if (B > 0) {
-        const int Lp = round_up(L, 4);
-        int rc = dispatch_tiling(L, [&]<int G, int DPT>() -> int {
+        // one wavefront per query up to 256 documents (ranks from a register bitonic sort, one accumulator row), four beyond
+        int rc = dispatch_wave256_tiling(L, [&]<int G, int DPT>() -> int {
             constexpr int QPB = kBlock / G, NW = G / kWave;
+            const int Lp = G == kWave ? kWave * DPT : round_up(L, 4);
             auto kern = lambdaloss_kernel<G, DPT>;
             const size_t lds = QPB * lambdaloss_group_floats(Lp, NW) * sizeof(float);
             if (int e = allow_lds(kern, lds)) return e;

@@ -308,7 +308,9 @@ shuffle_ties_kernel(const float *__restrict__ labels, const int32_t *__restrict_
     __syncthreads();
     int rk[DPT];
     if (fast) {
-        count_ranks_fast<G, DPT>(keys, out, n, t, key, rk);      // integer keys below 2^24: differences >= 1; field collisions recount
+        // integer keys below 2^24; field collisions (equal keys) recount exactly inside either form
+        if constexpr (G == kWave) count_ranks_wave<DPT>(keys, reinterpret_cast<float *>(out), n, Lp, t, key, rk);
+        else count_ranks_fast<G, DPT>(keys, out, n, t, key, rk);
     } else {
 #pragma unroll
         for (int m = 0; m < DPT; ++m) {
@@ -447,9 +449,9 @@ extern "C" int ptr_shuffle_ties_order(const float *labels, const int32_t *lens, 
     const char *who = "ptr_shuffle_ties_order";
     if (int rc = check_batch(labels, perm, B, L, who)) return rc;
     if (B == 0) return 0;
-    const int Lp = round_up(L, 4);
-    return dispatch_tiling(L, [&]<int G, int DPT>() -> int {
+    return dispatch_wave_tiling(L, [&]<int G, int DPT>() -> int {
         constexpr int QPB = kBlock / G;
+        const int Lp = G == kWave ? kWave * DPT : round_up(L, 4);      // one wavefront per query: 64*DPT padded keys through the register sort
         auto kern = shuffle_ties_kernel<G, DPT>;
         const size_t lds = ((size_t)QPB * 3 * Lp + 4) * sizeof(float);
         if (int e = allow_lds(kern, lds)) return e;

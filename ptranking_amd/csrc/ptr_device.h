@@ -60,6 +60,13 @@ template <class F> inline int dispatch_wave_tiling(int L, F &&f) {
     return f.template operator()<256, 16>();
 }
 
+template <class F> inline int dispatch_wave256_tiling(int L, F &&f) {
+    if (L <= 64) return f.template operator()<64, 1>();
+    if (L <= 128) return f.template operator()<64, 2>();
+    if (L <= 256) return f.template operator()<64, 4>();
+    return dispatch_tiling(L, f);
+}
+
 // Raises the dynamic-LDS cap of `kernel` when a launch needs more than the 64 KiB default.
 template <class K> inline int allow_lds(K kernel, size_t bytes) {
     if (bytes <= 64 * 1024) return 0;
