@@ -216,6 +216,170 @@ approxndcg_kernel(const float *__restrict__ preds, const float *__restrict__ lab
     }
 }
 
+// =====================================================================================================================
+// ApproxNDCG "ring" kernel (list lengths up to 512): ONE wavefront per query, both O(L^2) passes out of registers — the scheme of
+// lambdarank_ring_kernel (pairwise.hip).  Lane a owns documents a, a+64, ... in INPUT order (nothing in the loss depends on the ideal
+// ORDER, only the IDCG does: a value-only sort of the labels, or the labels as they are under `presort`); every own record {s} / {s, c}
+// stays put, every slot has two travelling copies {s, acc} / {s, c, acc} (the records 1..16 and 17..32 lanes ahead, one packed
+// instruction stream for both), rotated one lane per step with v_mov_b32_dpp wave_rol:1.  The partner's share of a pair accumulates in the
+// travelling record instead of an LDS read-modify-write, and the partner's score / coefficient arrive by rotation instead of LDS reads:
+// per pair and pass ~10 / ~15 VALU slots against ~23 / ~30 of approxndcg_kernel.  Padding slots carry s = -1e30, c = 0: e = 0, y in
+// {0, 1}, y(1-y) = 0 — every pair with a padding record contributes exactly 0 to real documents (scores are assumed far above -1e30).
+template <int DPT, int PASS>
+__device__ __forceinline__ void approx_ring(const float (&s)[DPT], const float (&c)[DPT], float c2, float alpha, int lane, float (&out)[DPT]) {
+    f32x2 so2[DPT], co2[DPT], acc2[DPT];                          // own records {v, v}; own accumulators of the two copies
+    f32x2 Ts[DPT], Tc[DPT], Ta[DPT];                              // travelling {copy A, copy B}
+    const int ahead16 = (lane + 16) & 63;
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) {
+        so2[k] = f32x2{s[k], s[k]};
+        Ts[k] = f32x2{s[k], __shfl(s[k], ahead16, 64)};
+        acc2[k] = f32x2{0.f, 0.f}; Ta[k] = f32x2{0.f, 0.f};
+        if constexpr (PASS == 2) { co2[k] = f32x2{c[k], c[k]}; Tc[k] = f32x2{c[k], __shfl(c[k], ahead16, 64)}; }
+    }
+    const f32x2 c22 = {c2, c2}, one2 = {1.0f, 1.0f}, al2 = {alpha, alpha};
+    auto pair2 = [&](int k, int t, f32x2 mask, bool use_mask) __attribute__((always_inline)) {
+        // Robust_Sigmoid (base/utils.py:57-95) of +-alpha*delta from ONE exponential, as robust_pair() above: r = 1/(1+e), sm = e/(1+e)
+        const f32x2 dl = pk_sub(Ts[t], so2[k]);                   // delta = s_b - s_a
+        const f32x2 x = dl * c22;                                 // alpha*log2(e) folded
+        const f32x2 e = {__builtin_amdgcn_exp2f(-fabsf(x.x)), __builtin_amdgcn_exp2f(-fabsf(x.y))};
+        const f32x2 dd = one2 + e;      // compiler-emitted: an inline-asm reader right behind v_exp_f32 would miss the trans-use wait state
+        f32x2 r = {__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y)};
+        r = __builtin_elementwise_fma(r, __builtin_elementwise_fma(-dd, r, one2), r);
+        const f32x2 sm = e * r;
+        f32x2 ya, yb;                                             // delta == 0: e = 1, r = sm = 0.5 on its own
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const bool pos = dl[h] > 0.0f;
+            ya[h] = pos ? r[h] : sm[h];
+            yb[h] = pos ? sm[h] : r[h];
+        }
+        if constexpr (PASS == 1) {
+            if (use_mask) { ya = ya * mask; yb = yb * mask; }
+            acc2[k] = pk_add(acc2[k], ya);                        // b's contribution to pi_hat_a
+            Ta[t] = pk_add(Ta[t], yb);                            // a's contribution to pi_hat_b
+        } else {
+            const f32x2 dab = (ya * al2) * pk_sub(one2, ya), dba = (yb * al2) * pk_sub(one2, yb);      // base/utils.py:78
+            f32x2 flow = __builtin_elementwise_fma(-co2[k], dab, Tc[t] * dba);                         // d loss / d s_a from this pair
+            if (use_mask) flow = flow * mask;
+            acc2[k] = pk_add(acc2[k], flow);
+            Ta[t] = pk_sub(Ta[t], flow);
+        }
+    };
+    auto rotate = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < DPT; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                Ts[t][h] = dpp_rol1(Ts[t][h]); Ta[t][h] = dpp_rol1(Ta[t][h]);
+                if constexpr (PASS == 2) Tc[t][h] = dpp_rol1(Tc[t][h]);
+            }
+    };
+    // offset 0: pairs inside a lane (travelling slot t > own slot k), copy A only
+#pragma unroll
+    for (int k = 0; k < DPT; ++k)
+#pragma unroll
+        for (int t = k + 1; t < DPT; ++t) pair2(k, t, f32x2{1.0f, 0.0f}, true);
+    // steps 1..15: lane offsets r (copy A) and r + 16 (copy B)
+    for (int r = 1; r < 16; ++r) {
+        rotate();
+#pragma unroll
+        for (int k = 0; k < DPT; ++k)
+#pragma unroll
+            for (int t = 0; t < DPT; ++t) pair2(k, t, one2, false);
+    }
+    // step 16: offset 16 (A) and the half step 32 (B), where lanes a and a+32 see each other from both ends — the lower half keeps them
+    {
+        rotate();
+        const float lm = lane < 32 ? 1.0f : 0.0f;
+#pragma unroll
+        for (int k = 0; k < DPT; ++k)
+#pragma unroll
+            for (int t = 0; t < DPT; ++t) pair2(k, t, f32x2{1.0f, lm}, true);
+    }
+    // the travelling accumulators sit 16 (copy A) / 32 (copy B) lanes behind their owners
+    const int behind16 = (lane - 16) & 63;
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) out[k] = (acc2[k].x + acc2[k].y) + (__shfl(Ta[k].x, behind16, 64) + __shfl(Ta[k].y, lane ^ 32, 64));
+}
+
+constexpr int approx_ring_sort_width(int dpt) { int e = 1; while (e < dpt) e *= 2; return e; }
+
+template <int DPT>
+__global__ void __launch_bounds__(kBlock)
+approxndcg_ring_kernel(const float *__restrict__ preds, const float *__restrict__ labels, const int32_t *__restrict__ lens, int B, int L,
+                       float alpha, int presort, int couple_batch, float *__restrict__ dcg_q, float *__restrict__ inv_idcg_q,
+                       float *__restrict__ grad) {
+    constexpr int E = approx_ring_sort_width(DPT), NS = 64 * E;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int q = blockIdx.x * (kBlock / kWave) + wv;
+    const bool valid = q < B;
+    const int n = __builtin_amdgcn_readfirstlane(valid ? query_len(lens, q, L) : 0);
+    float *lab = smem + (size_t)wv * NS;                          // label staging of the ideal sort (presort == 0 only)
+
+    float si[DPT], gi[DPT], li[DPT];
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const int i = lane + 64 * m;
+        const bool in = i < n;
+        si[m] = in ? preds[(size_t)q * L + i] : -1e30f;
+        li[m] = in ? labels[(size_t)q * L + i] : -INFINITY;
+        gi[m] = in ? gain_of(li[m]) : 0.0f;
+    }
+    // IDCG (approxNDCG.py:52-53): gains of the labels in descending order over 1/log2(position + 2)
+    float part = 0.0f;
+    if (presort) {
+#pragma unroll
+        for (int m = 0; m < DPT; ++m) part = fmaf(gi[m], inv_log2_pos(lane + 64 * m), part);
+    } else {
+#pragma unroll
+        for (int m = 0; m < E; ++m) lab[lane + 64 * m] = m < DPT ? li[m < DPT ? m : 0] : -INFINITY;
+        wave_lds_sync();
+        float v[E];
+#pragma unroll
+        for (int r = 0; r < E; ++r) v[r] = lab[lane * E + r];
+        wave_sort_desc<E>(v, lane);                               // equal labels are interchangeable: no tie handling
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const int p = lane * E + r;
+            part = fmaf(p < n ? gain_of(v[r]) : 0.0f, inv_log2_pos(p), part);
+        }
+    }
+    const float idcg = wave_sum_dpp(part);
+
+    const float c2 = alpha * 1.4426950408889634f;
+    float pia[DPT], ca[DPT], tot[DPT];
+    approx_ring<DPT, 1>(si, si, c2, alpha, lane, pia);
+    const float ln2 = 0.6931471805599453f;
+    float dpart = 0.0f;
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) {
+        const bool in = lane + 64 * m < n;
+        const float pi = pia[m] + 1.0f;                           // 0.5 (diagonal term) + 0.5 (approxNDCG.py:25)
+        const float lg = log2f(pi + 1.0f);
+        dpart += in ? gi[m] / lg : 0.0f;                          // approxNDCG.py:58
+        ca[m] = in ? gi[m] / (ln2 * (1.0f + pi) * lg * lg) : 0.0f;   // d(-g/log2(1+pi))/d(pi)
+    }
+    const float dcg = wave_sum_dpp(dpart);
+    approx_ring<DPT, 2>(si, ca, c2, alpha, lane, tot);
+    const float inv_idcg = 1.0f / idcg;
+    const float scale = couple_batch ? 1.0f : inv_idcg;
+    if (valid) {
+#pragma unroll
+        for (int m = 0; m < DPT; ++m) {
+            const int i = lane + 64 * m;
+            if (i < L) grad[(size_t)q * L + i] = i < n ? tot[m] * scale : 0.0f;
+        }
+        if (lane == 0) { dcg_q[q] = dcg; inv_idcg_q[q] = inv_idcg; }
+    }
+}
+
+static int approx_ring_enabled() {                   // PTR_APPROX_RING=0 selects the LDS kernel (A/B measurements, tests); read per call
+    const char *e = getenv("PTR_APPROX_RING");
+    return !(e && e[0] == '0');
+}
+
 // One workgroup: S = sum 1/IDCG, loss, the factor kernel 3 applies.  out_scale[0] = applied factor, out_scale[1] = local S.
 __global__ void __launch_bounds__(kBlock)
 approx_finish_kernel(const float *__restrict__ dcg_q, const float *__restrict__ inv_q, int B, int couple_batch,
@@ -250,7 +414,19 @@ extern "C" int ptr_approxndcg_fwd_bwd(const float *preds, const float *labels, c
     if (!loss_out || !scale_out || (B > 0 && (!dcg_q || !inv_idcg_q || !grad))) { set_error("%s: NULL output pointer", who); return PTR_ERR_INVALID_ARG; }
     if (!(alpha > 0.0f)) { set_error("%s: alpha must be > 0 (got %g)", who, (double)alpha); return PTR_ERR_INVALID_ARG; }
     hipStream_t st = as_stream(stream);
-    if (B > 0) {
+    if (B > 0 && L <= 512 && approx_ring_enabled()) {
+        auto go = [&](auto kern, int dpt) -> int {
+            constexpr int QPB = kBlock / kWave;
+            const size_t lds = (size_t)QPB * 64 * approx_ring_sort_width(dpt) * sizeof(float);
+            hipLaunchKernelGGL(kern, dim3((B + QPB - 1) / QPB), dim3(kBlock), lds, st, preds, labels, lens, B, L, alpha, presort, couple_batch,
+                               dcg_q, inv_idcg_q, grad);
+            return check_hip(hipGetLastError(), who);
+        };
+        const int rc = L <= 64 ? go(approxndcg_ring_kernel<1>, 1) : L <= 128 ? go(approxndcg_ring_kernel<2>, 2)
+                     : L <= 192 ? go(approxndcg_ring_kernel<3>, 3) : L <= 256 ? go(approxndcg_ring_kernel<4>, 4)
+                     : L <= 384 ? go(approxndcg_ring_kernel<6>, 6) : go(approxndcg_ring_kernel<8>, 8);
+        if (rc) return rc;
+    } else if (B > 0) {
         const int Lp = round_up(L, 4);
         int rc = dispatch_tiling(L, [&]<int G, int DPT>() -> int {
             constexpr int QPB = kBlock / G, NW = G / kWave;

@@ -305,6 +305,53 @@ __device__ __forceinline__ void count_ranks_fast(const float *keys, int *mark, i
     if (any) count_ranks<G, DPT>(keys, n, t, own, rk);
 }
 
+// ---- helpers of the register "ring" pair loops (pairwise.hip lambdarank_ring_kernel, approxndcg.hip approxndcg_ring_kernel)
+// a - b as ONE packed instruction (the compiler splits a v2f32 subtraction whose lanes are consumed separately)
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// Wavefront sum out of the VALU alone (DPP row operations + one v_readlane; the butterfly wave_sum() goes through the LDS
+// crossbar six times, latency the four co-resident waves cannot hide because they run the same phase).  Fixed order; every lane
+// receives the same value.
+#define PTR_DPP_ADD(v, ctrl, rows) \
+    (v) += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (rows), 0xF, false))
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    PTR_DPP_ADD(v, 0xB1, 0xF);        // quad_perm [1,0,3,2]
+    PTR_DPP_ADD(v, 0x4E, 0xF);        // quad_perm [2,3,0,1]
+    PTR_DPP_ADD(v, 0x141, 0xF);       // row_half_mirror
+    PTR_DPP_ADD(v, 0x140, 0xF);       // row_mirror: every lane holds its row's sum
+    PTR_DPP_ADD(v, 0x142, 0xA);       // row_bcast:15 into rows 1 and 3
+    PTR_DPP_ADD(v, 0x143, 0xC);       // row_bcast:31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+#undef PTR_DPP_ADD
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// 1 / log2(pos + 2)
+__device__ __forceinline__ float inv_log2_pos(int pos) {
+    const float d = __builtin_amdgcn_logf((float)(pos + 2));
+    const float r = __builtin_amdgcn_rcpf(d);
+    return fmaf(r, fmaf(-d, r, 1.0f), r);
+}
+// LDS hand-over between the lanes of ONE wavefront (its own LDS region): LDS operations of a wave execute in order, only the
+// compiler has to be kept from reordering them — no workgroup barrier, the four waves of a block stay independent
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+#ifndef PTR_RING_DPP
+#define PTR_RING_DPP 0x134
+#endif
+__device__ __forceinline__ float dpp_rol1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), PTR_RING_DPP /* wave_rol:1 */, 0xF, 0xF, false));
+}
+
+
 // ---- one wavefront sorts 64*E keys held E per lane (bitonic network in registers)
 // Value of lane (lane ^ X): DPP inside the 16-lane rows where a control exists (quad_perm, row_half_mirror, row_mirror, row_ror:8),
 // the LDS crossbar otherwise (ds_swizzle bit mode inside 32 lanes, ds_bpermute across the halves).
