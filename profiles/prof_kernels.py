@@ -4,7 +4,7 @@
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --kernel-trace --stats -d OUT --output-format csv -- python profiles/prof_kernels.py run [B]
     python profiles/prof_kernels.py summarise OUT/**/_kernel_stats.csv profiles/r03_kernels_B65536.json [B]
-    (PMC passes, each on its own:  rocprofv3 --pmc FETCH_SIZE -d OUT2 ... ;  rocprofv3 --pmc WRITE_SIZE -d OUT3 ...)
+    (PMC passes, each on its own:  rocprofv3 --pmc FETCH_SIZE -d OUT2 ... ;  rocprofv3 --pmc WRITE_SIZE -d OUT3 ... ;  rocprofv3 --pmc SQ_INSTS_VALU -d OUT4 ...)
 
 `run` launches each entry point ITERS times at B queries (default 65 536; inputs far larger than the 256 MB Infinity Cache) on the MSLR label
 mix.  `summarise` joins the rocprofv3 kernel averages with the ALGORITHMIC bytes of SURVEY.md 8(d) — 12L+4 per query for the fused loss
@@ -68,7 +68,11 @@ def run(B):
     torch.cuda.synchronize()
 
 
-def summarise(stats_csv, out_json, B, fetch_csv=None, write_csv=None):
+# VALU issue peak: 256 CUs x 4 SIMDs, one wave-wide VALU instruction per SIMD every 4 cycles at the 2.4 GHz peak engine clock
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0
+
+
+def summarise(stats_csv, out_json, B, fetch_csv=None, write_csv=None, valu_csv=None):
     import csv
     rows = list(csv.DictReader(open(stats_csv)))
     traffic = {}
@@ -78,9 +82,16 @@ def summarise(stats_csv, out_json, B, fetch_csv=None, write_csv=None):
         f, w = pmc_traffic.per_kernel(fetch_csv, "FETCH_SIZE"), pmc_traffic.per_kernel(write_csv, "WRITE_SIZE")
         for k in set(f) | set(w):
             traffic[k] = int(round((2.0 * f.get(k, 0.0) + w.get(k, 0.0)) * 1024))
+    valu = {}
+    if valu_csv:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import pmc_traffic
+        valu = pmc_traffic.per_kernel(valu_csv, "SQ_INSTS_VALU")
     out = {"note": "rocprofv3 --kernel-trace --stats averages of stand-alone launches (profiles/prof_kernels.py run), MSLR label mix, 1xMI355X; "
                    "achieved = SURVEY 8(d) algorithmic bytes / average kernel time; peak = 8000 GB/s (HBM3E spec); traffic = PMC "
-                   "FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch when collected",
+                   "FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch when collected; valu_roofline (the pair / sort kernels are VALU-bound, not HBM-bound) = PMC "
+                   "SQ_INSTS_VALU (wave-wide VALU instructions per launch) / average kernel time against 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles "
+                   "= 614.4 G wave-instructions/s",
            "queries": B, "kernels": {}}
     for label, sub, L, bytes_per_q in CASES:
         Bq = B if L <= 256 else B // 2
@@ -95,7 +106,14 @@ def summarise(stats_csv, out_json, B, fetch_csv=None, write_csv=None):
         out["kernels"][label] = {"kernel": r["Name"].split("(")[0], "calls": int(r["Calls"]), "avg_us": avg_us, "queries": Bq, "list_len": L,
                                  "algorithmic_bytes": bytes_, "achieved_GBps": gbps, "frac_of_hbm_peak": gbps / 8000.0,
                                  "traffic_bytes": tr}
-        print(f"{label:24s} {avg_us:9.1f} us  {gbps:8.1f} GB/s  {gbps / 80:5.1f} % of HBM peak" + (f"  traffic {tr / 1e6:.1f} MB vs {bytes_ / 1e6:.1f} MB" if tr else ""))
+        vi = next((v for k, v in valu.items() if sub.split("<")[0] in k and (("<" not in sub) or sub in k)), None)
+        if vi:
+            ach = vi / (avg_us * 1e-6) / 1e9
+            out["kernels"][label]["valu_roofline"] = {"bound": "valu", "wave_instructions_per_launch": int(vi), "achieved": ach, "peak": VALU_PEAK_GINST,
+                                                      "unit": "G wave-instructions/s", "frac": ach / VALU_PEAK_GINST,
+                                                      "per_pair": (vi * 64.0 / (Bq * L * (L - 1) / 2.0)) if "L=" in label and ("rank" in label or "approx" in label) else None}
+        print(f"{label:24s} {avg_us:9.1f} us  {gbps:8.1f} GB/s  {gbps / 80:5.1f} % of HBM peak" + (f"  traffic {tr / 1e6:.1f} MB vs {bytes_ / 1e6:.1f} MB" if tr else "")
+              + (f"  VALU {out['kernels'][label]['valu_roofline']['frac'] * 100:.0f} % of issue peak" if vi else ""))
     json.dump(out, open(out_json, "w"), indent=1)
 
 
@@ -103,4 +121,4 @@ if __name__ == "__main__":
     if sys.argv[1] == "run":
         run(int(sys.argv[2]) if len(sys.argv) > 2 else 65536)
     else:
-        summarise(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 65536, *(sys.argv[5:7] if len(sys.argv) > 6 else []))
+        summarise(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 65536, *(sys.argv[5:8] if len(sys.argv) > 6 else []))

@@ -242,3 +242,60 @@ def test_x6_backward_is_bit_stable_and_opt_in(monkeypatch):
     a, b = bwd(), bwd()
     assert torch.equal(a, b), "fixed tile ownership and document order: two launches give identical bits"
     assert not torch.equal(a, g_default)              # a different summation, so the kernel really ran
+
+
+# ---- the bf16x6 first-layer dW of wide inputs (csrc/scorer_dw_x6.hip; default from 32768 rows on, PTR_DW_X6=2 forces it, 0 disables it)
+@pytest.mark.parametrize("F,NL,R", [(700, 3, 1111), (256, 3, 640), (400, 2, 333), (200, 4, 500), (700, 3, 8 * 32 * 3 + 5), (196, 3, 31), (700, 3, 40000)])
+@pytest.mark.parametrize("p", [0.1, 0.0])
+def test_x6_wide_dw_matches_float64_modules_and_the_fp32_kernel(F, NL, R, p, monkeypatch):
+    """The layer-wise backward of inputs wider than 192 features (two passes of 384 columns at F = 700): every parameter gradient against
+    float64 CPU modules with the kernel's dropout masks, and bf16x6 against fp32-MFMA first-layer dW on identical inputs — the other
+    gradients come from the same kernels in both runs and must be bit-identical."""
+    from ptranking_amd import _lib
+    from ptranking_amd.scorer import FusedPointScorer
+    from ptranking_amd.host import build_pointsf
+    torch.manual_seed(R + F)
+    fused = FusedPointScorer(F, num_layers=NL, dropout=p).cuda()
+    fused.train()
+    X = torch.randn(R, F, device="cuda")
+    w = torch.randn(R, device="cuda")
+    seed = 4242 + R
+    preds = torch.empty(R, device="cuda")
+    acts = torch.empty(NL, R, 112, device="cuda")
+    st = _lib.current_stream(X.device)
+    _lib.call("ptr_mlp_forward", _lib.ptr(X), _lib.ptr(fused.flat.data), R, F, NL, 1, C.c_float(p), C.c_uint64(seed), _lib.ptr(preds), _lib.ptr(acts), st)
+    ws = torch.empty(_lib.query("ptr_mlp_backward_ws_floats", F, NL), device="cuda")
+    dz = torch.empty(max(1, _lib.query("ptr_mlp_backward_dz_floats", R, F, NL)), device="cuda")
+    grads = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("PTR_DW_X6", mode)
+        g = torch.full_like(fused.flat.data, float("nan"))
+        ws.fill_(float("nan"))
+        _lib.call("ptr_mlp_backward", _lib.ptr(X), _lib.ptr(fused.flat.data), _lib.ptr(acts), _lib.ptr(w), R, F, NL, C.c_float(p), C.c_uint64(seed),
+                  _lib.ptr(dz), _lib.ptr(ws), _lib.ptr(g), st)
+        torch.cuda.synchronize()
+        assert not torch.isnan(g).any(), "every parameter's gradient must be written"
+        grads[mode] = g.cpu().double()
+    ref = build_pointsf(num_features=F, num_layers=NL, AF="R", BN=False, apply_tl_af=False, dropout=0.0).double()
+    ref.load_state_dict({k: v.cpu().double() for k, v in fused.state_dict().items()})
+    lin = [m for m in ref if isinstance(m, torch.nn.Linear)]
+    a = X.cpu().double()
+    if p > 0:
+        a = a * fused.dropout_mask(R, 0, seed).cpu().double() / (1 - p)
+    for l in range(NL):
+        h = torch.relu(lin[l](a))
+        a = h * fused.dropout_mask(R, l + 1, seed).cpu().double() / (1 - p) if (p > 0 and l < NL - 1) else h
+    (lin[NL](a).reshape(-1) * w.cpu().double()).sum().backward()
+    gref = torch.cat([q.grad.reshape(-1) for q in ref.parameters()])
+    off = 0
+    for i, q in enumerate(ref.parameters()):
+        n = q.numel()
+        scale = max(1.0, float(gref[off:off + n].abs().max()))
+        e6 = float((grads["2"][off:off + n] - gref[off:off + n]).abs().max())
+        e32 = float((grads["0"][off:off + n] - gref[off:off + n]).abs().max())
+        assert e6 <= max(5e-5 * scale, 1.5 * e32 + 2e-6 * scale), (i, e6, e32, scale)      # same bar as the fused x6 backward above
+        if i <= 1:                                                                            # first-layer weight and bias: the swapped kernel
+            assert float((grads["2"][off:off + n] - grads["0"][off:off + n]).abs().max()) <= 2e-5 * scale
+        else:
+            assert torch.equal(grads["2"][off:off + n], grads["0"][off:off + n]), i           # untouched kernels: the same bits
+        off += n
