@@ -93,6 +93,8 @@ def summarise(stats_csv, out_json, B, fetch_csv=None, write_csv=None, valu_csv=N
                    "SQ_INSTS_VALU (wave-wide VALU instructions per launch) / average kernel time against 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles "
                    "= 614.4 G wave-instructions/s",
            "queries": B, "kernels": {}}
+    slot_sum = [r for r in rows if "sum_f32_kernel" in r["Name"]]
+    slot_sum_us = float(slot_sum[0]["AverageNs"]) / 1e3 if slot_sum else None      # the loss-slot sum every *_fwd_bwd entry point ends with
     for label, sub, L, bytes_per_q in CASES:
         Bq = B if L <= 256 else B // 2
         match = [r for r in rows if sub in r["Name"] and "ptr::" in r["Name"]]
@@ -106,6 +108,9 @@ def summarise(stats_csv, out_json, B, fetch_csv=None, write_csv=None, valu_csv=N
         out["kernels"][label] = {"kernel": r["Name"].split("(")[0], "calls": int(r["Calls"]), "avg_us": avg_us, "queries": Bq, "list_len": L,
                                  "algorithmic_bytes": bytes_, "achieved_GBps": gbps, "frac_of_hbm_peak": gbps / 8000.0,
                                  "traffic_bytes": tr}
+        if slot_sum_us is not None and not any(x in label for x in ("metrics", "sort", "shuffle", "approx")):
+            e_us = avg_us + slot_sum_us                 # whole entry point = loss kernel + slot sum (ApproxNDCG: its own finish kernel instead)
+            out["kernels"][label]["entry_point"] = {"avg_us": e_us, "achieved_GBps": bytes_ / (e_us * 1e-6) / 1e9, "frac_of_hbm_peak": bytes_ / (e_us * 1e-6) / 1e9 / 8000.0}
         vi = next((v for k, v in valu.items() if sub.split("<")[0] in k and (("<" not in sub) or sub in k)), None)
         if vi:
             ach = vi / (avg_us * 1e-6) / 1e9

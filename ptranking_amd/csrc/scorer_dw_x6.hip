@@ -13,7 +13,11 @@
 //   * both MFMA operands are "documents down the contraction": ds_read_b64_tr_b16 delivers the 16-feature x 32-document fragment of a tile out of
 //     the row-major image (same reads as scorer_bwd_x6.hip);
 //   * wave w owns the column tiles w, w + 8, w + 16 of the pass and all 7 output tiles: 21 accumulator tiles, 126 MFMAs per slab.
-// HBM traffic is the floor here, not the matrix pipe: X is read once (1.47 GB at 524288 x 700), dZ once per pass of 384 columns.
+// HBM traffic is the floor here, not the matrix pipe: X is read once (1.47 GB at 524288 x 700), dZ once per pass of 384 columns — 1.94 GB in
+// ~630 us = 3.1 TB/s, 80 % of what a read-only stream reaches on this part (3.9 TB/s, scratch/x6probe/bw.py).  Two variants measured and dropped
+// (round 4): the two wave groups skewed by half an iteration so that one converts while the other multiplies (half images, one barrier per
+// phase: 1.47 vs 1.27 ms for the whole backward — a lone wave per SIMD hides neither its LDS reads nor its load waits), and term-major MFMA
+// order (dependent matrix instructions three issues apart: 1.32 vs 1.27 ms).
 // Interface, partial layout (ws[block][flat parameter layout]) and bias gradient are those of mlp_bwd_dw_lds_kernel: the reduction is unchanged.
 #include "ptr_device.h"
 #include "ptr_dropout.h"
