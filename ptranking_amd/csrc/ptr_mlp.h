@@ -43,6 +43,11 @@ int bwd_fused_grid(int R);
 int launch_bwd_fused(const float *X, const float *params, const float *acts, const float *dpreds, const MlpArgs &a, float *ws,
                      hipStream_t st, const char *who);
 
+// the TAIL form for wide inputs: everything but the first layer's weight gradient, dZ of the first layer to dz0 [R][112]; same grid / partials
+bool bwd_tail_supported(int NL, const void *acts);
+int launch_bwd_tail(const float *params, const float *acts, const float *dpreds, const MlpArgs &a, float *ws, float *dz0, hipStream_t st,
+                    const char *who);
+
 // ---- the same on bf16 matrix instructions with fp32 results (scorer_bwd_x6.hip); same grid, same partial layout
 bool bwd_x6_supported(int R, int F, int NL, const void *X, const void *acts);
 int launch_bwd_x6(const float *X, const float *params, const float *acts, const float *dpreds, const MlpArgs &a, float *ws, hipStream_t st,

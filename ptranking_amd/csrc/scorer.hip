@@ -1249,7 +1249,14 @@ int ptr::mlp_backward_impl(const char *who, const float *X, const float *params,
     const int ntiles = (R + 15) / 16;
     int grid_dz = ntiles < wpb * ncu ? (ntiles + wpb - 1) / wpb : ncu;
     if (grid_dz < 1) grid_dz = 1;
-    {
+    // r4, NL = 2 / 3: ONE pass over the stored activations does the dZ chain AND every hidden-layer gradient (the fused kernel's TAIL form,
+    // scorer_bwd.hip: no X image, no first-layer tiles) and leaves dZ of the first layer in dz[0]; only the first layer's dW below still
+    // runs as a row-contraction kernel of its own.  Partials: the first layer's entries [0, off_W(1)) come from the dW kernels' grid, everything
+    // behind them from the tail kernel's.
+    const bool tail = R > 0 && bwd_tail_supported(NL, acts);
+    if (tail) {
+        if (int e = launch_bwd_tail(params, acts, dpreds, a, ws, dz, st, who)) return e;
+    } else {
         const size_t lds = dz_lds_floats(NL) * sizeof(float);
         auto go = [&](auto kern) -> int {
             if (int e = allow_lds(kern, lds)) return e;
@@ -1259,7 +1266,7 @@ int ptr::mlp_backward_impl(const char *who, const float *X, const float *params,
         if (int e = wide ? go(mlp_bwd_dz_kernel<1, 1024>) : go(mlp_bwd_dz_kernel<1, 512>)) return e;
     }
     // 2. dW per layer (row contraction), every block writes its partial into ws[block][flat parameter layout]
-    for (int l = 0; l < NL; ++l) {
+    for (int l = 0; l < (tail ? 1 : NL); ++l) {
         const int K = l == 0 ? F : kH;
         const float *A = l == 0 ? X : acts + (size_t)(l - 1) * R * kAL;
         const int lda = l == 0 ? F : kAL;
@@ -1294,8 +1301,8 @@ int ptr::mlp_backward_impl(const char *who, const float *X, const float *params,
         if (e) return e;
     }
     // 3. one deterministic reduction of all partials into the flat gradient
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((NP + 63) / 64) + (opt.loss_out ? 1 : 0)), dim3(1024), 0, st, ws, nblk, grid_dz,
-                       off_wout(NL, F), NP, NP, grad, opt);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((NP + 63) / 64) + (opt.loss_out ? 1 : 0)), dim3(1024), 0, st, ws, nblk,
+                       tail ? bwd_fused_grid(R) : grid_dz, tail ? off_W(1, F) : off_wout(NL, F), NP, NP, grad, opt);
     return check_hip(hipGetLastError(), who);
 }
 

@@ -216,10 +216,13 @@ __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 template <int NL, int NT1, int W>
 __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const float *__restrict__ P, const float *__restrict__ acts,
                                          const float *__restrict__ dpreds, const MlpArgs a, float *__restrict__ ws, size_t np_stride,
-                                         float *smem) {
+                                         float *smem, float *__restrict__ dz0) {
     using TMt = TileMap<NL, NT1>;
     constexpr int CH = NL - 1, LDX = ldx_of(NT1), NTMAX = NT1 > 7 ? NT1 : 7;
-    constexpr int NACC = kTM<NL, NT1>.ntiles[W];
+    constexpr int NACC = kTM<NL, NT1>.ntiles[W] > 0 ? kTM<NL, NT1>.ntiles[W] : 1;
+    // NT1 == 0 is the TAIL form for inputs too wide for the first layer's accumulators (r4): no X image, no dW_0 tiles; the chain's last
+    // image dZ_0 goes to HBM (dz0) for the separate wide-input dW kernel (scorer_dw_x6.hip), which also takes db_0 off its column sums
+    constexpr bool TAIL = NT1 == 0;
     constexpr bool loader = W < 4;                        // X staging + early DMA issue; the others: late DMA issue
     constexpr bool topper = W >= 4 && W < 8;              // top-layer pass (252 threads of waves 4..7)
     const int F = a.F, R = a.R;
@@ -263,15 +266,15 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
         for (int i = 0; i < 25; ++i) asm volatile("" : "+v"(wf[c][i]));
 
     // ---- X staging (waves 0-3, 256 threads): slot u of thread t -> (slab row, float4 column), recomputed at use
-    constexpr int XTOT = kSR * 4 * NT1, XSL = (XTOT + 255) / 256;
+    constexpr int XTOT = kSR * 4 * NT1, XSL = (XTOT + 255) / 256, XW4 = TAIL ? 1 : 4 * NT1;
     auto x_slot = [&](int t, int u, int &xr, int &xc) -> bool {
         const int idx = t + 256 * u;
         const bool in = idx < XTOT;
-        xr = in ? idx / (4 * NT1) : 0;
-        xc = in ? idx - xr * (4 * NT1) : 0;
+        xr = in ? idx / XW4 : 0;
+        xc = in ? idx - xr * XW4 : 0;
         return in;
     };
-    f32x4 xraw[loader ? XSL : 1];
+    f32x4 xraw[(loader && XSL > 0) ? XSL : 1];
     float dsraw = 0.0f;
 
     // this wave's share of the activation DMA (chunks of 64 lanes x 16 B)
@@ -529,7 +532,17 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
         });
 
         // ---- phase C: all-wave dW of slab s; preparation of slab s+1 by the wave half that is off the matrix pipe
-        if constexpr (loader) { PREP_BEGIN(); finish_x(next, p ^ 1, tid_o); PREP_END(); }
+        if constexpr (loader && !TAIL) { PREP_BEGIN(); finish_x(next, p ^ 1, tid_o); PREP_END(); }
+        if constexpr (loader && TAIL) {                  // the dZ_0 image of this slab (complete since the last chain barrier) -> dz0, rows < R
+            const int row0 = slab * kSR;
+#pragma unroll
+            for (int u = 0; u < (kSR * (kAL / 4) + 255) / 256; ++u) {
+                const int idx = tid_o + 256 * u;
+                const int r = idx / (kAL / 4), c4 = idx - r * (kAL / 4);
+                if (idx < kSR * (kAL / 4) && row0 + r < R)
+                    *reinterpret_cast<f32x4 *>(dz0 + (size_t)(row0 + r) * kAL + 4 * c4) = *reinterpret_cast<const f32x4 *>(Zb + r * kAL + 4 * c4);
+            }
+        }
         BWD_STAMP(1 + 2 * CH);
         dw_phase(std::integral_constant<int, W>{}, std::integral_constant<int, CH>{}, cur, XSb + p * kSR * LDX);
         BWD_STAMP(2 + 2 * CH);
@@ -624,25 +637,25 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
 template <int NL, int NT1>
 __global__ void __launch_bounds__(kBT)
 mlp_bwd_fused_kernel(const float *__restrict__ X, const float *__restrict__ P, const float *__restrict__ acts,
-                     const float *__restrict__ dpreds, MlpArgs a, float *__restrict__ ws, size_t np_stride) {
+                     const float *__restrict__ dpreds, MlpArgs a, float *__restrict__ ws, size_t np_stride, float *__restrict__ dz0) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     switch (wave) {
-        case 0: bwd_body<NL, NT1, 0>(X, P, acts, dpreds, a, ws, np_stride, smem); break;
-        case 1: bwd_body<NL, NT1, 1>(X, P, acts, dpreds, a, ws, np_stride, smem); break;
-        case 2: bwd_body<NL, NT1, 2>(X, P, acts, dpreds, a, ws, np_stride, smem); break;
-        case 3: bwd_body<NL, NT1, 3>(X, P, acts, dpreds, a, ws, np_stride, smem); break;
-        case 4: bwd_body<NL, NT1, 4>(X, P, acts, dpreds, a, ws, np_stride, smem); break;
-        case 5: bwd_body<NL, NT1, 5>(X, P, acts, dpreds, a, ws, np_stride, smem); break;
-        case 6: bwd_body<NL, NT1, 6>(X, P, acts, dpreds, a, ws, np_stride, smem); break;
+        case 0: bwd_body<NL, NT1, 0>(X, P, acts, dpreds, a, ws, np_stride, smem, dz0); break;
+        case 1: bwd_body<NL, NT1, 1>(X, P, acts, dpreds, a, ws, np_stride, smem, dz0); break;
+        case 2: bwd_body<NL, NT1, 2>(X, P, acts, dpreds, a, ws, np_stride, smem, dz0); break;
+        case 3: bwd_body<NL, NT1, 3>(X, P, acts, dpreds, a, ws, np_stride, smem, dz0); break;
+        case 4: bwd_body<NL, NT1, 4>(X, P, acts, dpreds, a, ws, np_stride, smem, dz0); break;
+        case 5: bwd_body<NL, NT1, 5>(X, P, acts, dpreds, a, ws, np_stride, smem, dz0); break;
+        case 6: bwd_body<NL, NT1, 6>(X, P, acts, dpreds, a, ws, np_stride, smem, dz0); break;
 #if BWD_WAVES == 12
-        case 7: bwd_body<NL, NT1, 7>(X, P, acts, dpreds, a, ws, np_stride, smem); break;
-        case 8: bwd_body<NL, NT1, 8>(X, P, acts, dpreds, a, ws, np_stride, smem); break;
-        case 9: bwd_body<NL, NT1, 9>(X, P, acts, dpreds, a, ws, np_stride, smem); break;
-        case 10: bwd_body<NL, NT1, 10>(X, P, acts, dpreds, a, ws, np_stride, smem); break;
-        default: bwd_body<NL, NT1, 11>(X, P, acts, dpreds, a, ws, np_stride, smem); break;
+        case 7: bwd_body<NL, NT1, 7>(X, P, acts, dpreds, a, ws, np_stride, smem, dz0); break;
+        case 8: bwd_body<NL, NT1, 8>(X, P, acts, dpreds, a, ws, np_stride, smem, dz0); break;
+        case 9: bwd_body<NL, NT1, 9>(X, P, acts, dpreds, a, ws, np_stride, smem, dz0); break;
+        case 10: bwd_body<NL, NT1, 10>(X, P, acts, dpreds, a, ws, np_stride, smem, dz0); break;
+        default: bwd_body<NL, NT1, 11>(X, P, acts, dpreds, a, ws, np_stride, smem, dz0); break;
 #else
-        default: bwd_body<NL, NT1, 7>(X, P, acts, dpreds, a, ws, np_stride, smem); break;
+        default: bwd_body<NL, NT1, 7>(X, P, acts, dpreds, a, ws, np_stride, smem, dz0); break;
 #endif
     }
 }
@@ -673,10 +686,31 @@ int launch_bwd_fused(const float *X, const float *params, const float *acts, con
     auto go = [&](auto kern, int NT1) -> int {
         const size_t lds = bwd_fused_lds_floats(a.NL, NT1) * sizeof(float);
         if (int e = allow_lds(kern, lds)) return e;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kBT), lds, st, X, params, acts, dpreds, a, ws, NP);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kBT), lds, st, X, params, acts, dpreds, a, ws, NP, (float *)nullptr);
         return check_hip(hipGetLastError(), who);
     };
     return go(mlp_bwd_fused_kernel<3, 9>, 9);
+}
+
+// The TAIL form (NT1 = 0): chain + every hidden-layer gradient + d w_out / d b_out in one pass over the stored activations, dZ of the first
+// layer written to dz0 [R][112] for the wide-input dW kernel.  PTR_BWD_TAIL=0 keeps the layer-wise dZ / dW kernels (A/B measurements, tests).
+bool bwd_tail_supported(int NL, const void *acts) {
+    const char *e = getenv("PTR_BWD_TAIL");
+    if (e && atoi(e) == 0) return false;
+    return (NL == 2 || NL == 3) && (reinterpret_cast<uintptr_t>(acts) & 15) == 0;
+}
+
+int launch_bwd_tail(const float *params, const float *acts, const float *dpreds, const MlpArgs &a, float *ws, float *dz0, hipStream_t st,
+                    const char *who) {
+    const int grid = bwd_fused_grid(a.R);
+    const size_t NP = n_params(a.NL, a.F);
+    auto go = [&](auto kern) -> int {
+        const size_t lds = bwd_fused_lds_floats(a.NL, 0) * sizeof(float);
+        if (int e = allow_lds(kern, lds)) return e;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kBT), lds, st, (const float *)nullptr, params, acts, dpreds, a, ws, NP, dz0);
+        return check_hip(hipGetLastError(), who);
+    };
+    return a.NL == 2 ? go(mlp_bwd_fused_kernel<2, 0>) : go(mlp_bwd_fused_kernel<3, 0>);
 }
 
 }  // namespace ptr

@@ -13,8 +13,9 @@ for F, NL, R in ((700, 3, 524288), (256, 3, 524288), (400, 3, 262144)):
     ws = torch.empty(_lib.query("ptr_mlp_backward_ws_floats", F, NL), device="cuda")
     dz = torch.empty(max(1, _lib.query("ptr_mlp_backward_dz_floats", R, F, NL)), device="cuda")
     g = torch.empty_like(fused.flat.data)
-    for mode in ("0", "2", "0", "2"):
+    for mode, tail in (("0", "0"), ("2", "0"), ("2", "1"), ("0", "0"), ("2", "0"), ("2", "1")):
         os.environ["PTR_DW_X6"] = mode
+        os.environ["PTR_BWD_TAIL"] = tail
         def run():
             _lib.call("ptr_mlp_backward", _lib.ptr(X), _lib.ptr(fused.flat.data), _lib.ptr(acts), _lib.ptr(w), R, F, NL, C.c_float(0.1), C.c_uint64(5),
                       _lib.ptr(dz), _lib.ptr(ws), _lib.ptr(g), st)
@@ -24,4 +25,4 @@ for F, NL, R in ((700, 3, 524288), (256, 3, 524288), (400, 3, 262144)):
         e0.record()
         for _ in range(10): run()
         e1.record(); torch.cuda.synchronize()
-        print(f"F={F} NL={NL} R={R} PTR_DW_X6={mode}: backward {e0.elapsed_time(e1) * 100:8.1f} us", flush=True)
+        print(f"F={F} NL={NL} R={R} PTR_DW_X6={mode} PTR_BWD_TAIL={tail}: backward {e0.elapsed_time(e1) * 100:8.1f} us", flush=True)

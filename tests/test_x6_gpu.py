@@ -267,10 +267,14 @@ def test_x6_wide_dw_matches_float64_modules_and_the_fp32_kernel(F, NL, R, p, mon
     ws = torch.empty(_lib.query("ptr_mlp_backward_ws_floats", F, NL), device="cuda")
     dz = torch.empty(max(1, _lib.query("ptr_mlp_backward_dz_floats", R, F, NL)), device="cuda")
     grads = {}
-    for mode in ("0", "2"):
-        monkeypatch.setenv("PTR_DW_X6", mode)
+    # "0": layer-wise fp32 kernels; "2": bf16x6 first-layer dW beside them; "tail": the same dW behind the fused TAIL pass (chain + hidden-layer
+    # gradients in one kernel, NL = 3 only — other depths keep the layer-wise kernels, so "tail" equals "2" there)
+    for mode, dw, tail in (("0", "0", "0"), ("2", "2", "0"), ("tail", "2", "1")):
+        monkeypatch.setenv("PTR_DW_X6", dw)
+        monkeypatch.setenv("PTR_BWD_TAIL", tail)
         g = torch.full_like(fused.flat.data, float("nan"))
         ws.fill_(float("nan"))
+        dz.fill_(float("nan"))
         _lib.call("ptr_mlp_backward", _lib.ptr(X), _lib.ptr(fused.flat.data), _lib.ptr(acts), _lib.ptr(w), R, F, NL, C.c_float(p), C.c_uint64(seed),
                   _lib.ptr(dz), _lib.ptr(ws), _lib.ptr(g), st)
         torch.cuda.synchronize()
@@ -291,11 +295,11 @@ def test_x6_wide_dw_matches_float64_modules_and_the_fp32_kernel(F, NL, R, p, mon
     for i, q in enumerate(ref.parameters()):
         n = q.numel()
         scale = max(1.0, float(gref[off:off + n].abs().max()))
-        e6 = float((grads["2"][off:off + n] - gref[off:off + n]).abs().max())
         e32 = float((grads["0"][off:off + n] - gref[off:off + n]).abs().max())
-        assert e6 <= max(5e-5 * scale, 1.5 * e32 + 2e-6 * scale), (i, e6, e32, scale)      # same bar as the fused x6 backward above
-        if i <= 1:                                                                            # first-layer weight and bias: the swapped kernel
-            assert float((grads["2"][off:off + n] - grads["0"][off:off + n]).abs().max()) <= 2e-5 * scale
-        else:
-            assert torch.equal(grads["2"][off:off + n], grads["0"][off:off + n]), i           # untouched kernels: the same bits
+        for mode in ("2", "tail"):
+            e6 = float((grads[mode][off:off + n] - gref[off:off + n]).abs().max())
+            assert e6 <= max(5e-5 * scale, 1.5 * e32 + 2e-6 * scale), (mode, i, e6, e32, scale)      # same bar as the fused x6 backward above
+            assert float((grads[mode][off:off + n] - grads["0"][off:off + n]).abs().max()) <= 2e-5 * scale, (mode, i)
+        if i >= 2:                                                                                # untouched kernels: the same bits
+            assert torch.equal(grads["2"][off:off + n], grads["0"][off:off + n]), i
         off += n
