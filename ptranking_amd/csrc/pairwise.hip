@@ -31,7 +31,10 @@ template <int G, int DPT, bool WEIGHTED>
 __global__ void __launch_bounds__(kBlock)
 pairwise_bce_kernel(const float *__restrict__ preds, const float *__restrict__ labels, const int32_t *__restrict__ lens,
                     int B, int L, int Lp, float sigma, float *__restrict__ loss_q, float *__restrict__ grad) {
-    constexpr int QPB = kBlock / G, NW = G / kWave;
+    // G == 32 (RankNet, lists up to 32 documents — BASELINE config 1): TWO queries per wavefront, one per 32-lane half; each half owns its
+    // LDS rows, so "all lanes of a wave hit distinct positions within a step" still holds and nothing else changes
+    constexpr int QPB = kBlock / G, NW = G >= kWave ? G / kWave : 1;
+    static_assert(G >= kWave || !WEIGHTED, "the half-wave form has no rank count");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, grp = tid / G, t = tid % G, wv = t >> 6;
     const int q = blockIdx.x * QPB + grp;
@@ -548,6 +551,15 @@ static int launch_pairwise(const float *preds, const float *labels, const int32_
         };
         int rc = L <= 64 ? go(lambdarank_ring_kernel<1>, 1) : L <= 128 ? go(lambdarank_ring_kernel<2>, 2) : go(lambdarank_ring_kernel<4>, 4);
         if (rc) return rc;
+    } else if (!WEIGHTED && B > 0 && L <= 32) {
+        if constexpr (!WEIGHTED) {               // RankNet on short lists: two queries per wavefront
+            const int Lp = round_up(L, 4);
+            constexpr int QPB = kBlock / 32;
+            auto kern = pairwise_bce_kernel<32, 1, false>;
+            const size_t lds = QPB * pairwise_group_floats(Lp, 1) * sizeof(float);
+            hipLaunchKernelGGL(kern, dim3((B + QPB - 1) / QPB), dim3(kBlock), lds, st, preds, labels, lens, B, L, Lp, sigma, loss_q, grad);
+            if (int rc = check_hip(hipGetLastError(), who)) return rc;
+        }
     } else if (B > 0) {
         const int Lp = round_up(L, 4);
         int rc = dispatch_tiling(L, [&]<int G, int DPT>() -> int {

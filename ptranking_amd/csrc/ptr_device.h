@@ -98,6 +98,12 @@ __device__ __forceinline__ float wave_max(float v) {
 // Sum over the G threads of one group, fixed order (deterministic).  For G == 256 the group IS the workgroup, so the
 // barriers inside are workgroup barriers: every thread of the block must call it.  `red` = 4 floats of LDS.
 template <int G> __device__ __forceinline__ float group_sum(float v, float *red, int t) {
+    if constexpr (G == 32) {               // two groups per wavefront: butterfly inside the 32-lane half, every lane of the half gets the sum
+        (void)red; (void)t;
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        return v;
+    }
     v = wave_sum(v);
     if constexpr (G == kWave) {
         return v;
