@@ -280,3 +280,38 @@ def test_flat_adagrad_and_rmsprop_match_torch(opt):
         before = [q.detach().clone() for q in r.get_parameters()]
         loss, _ = r.train_op(X, Y, epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
         assert torch.isfinite(loss) and any(not torch.equal(a, b) for a, b in zip(before, r.get_parameters()))
+
+
+# ---- r4: the layer-wise backward in two passes (the fused kernel's TAIL form + the first-layer dW kernel; NL = 2 / 3) against the NL + 2 kernels
+@pytest.mark.parametrize("F,NL,R", [(24, 3, 1), (24, 3, 31), (24, 2, 33), (8, 3, 100), (46, 3, 515), (144, 3, 1111), (128, 2, 900), (180, 2, 300), (700, 3, 97),
+                                    (136, 3, 4097), (200, 3, 2048 + 5)])
+@pytest.mark.parametrize("p", [0.1, 0.0])
+def test_two_pass_backward_equals_the_layer_wise_kernels(F, NL, R, p, monkeypatch):
+    """Every parameter gradient through `ptr_mlp_backward` with PTR_BWD_TAIL=1 (default) and =0 on identical stored activations (PTR_BWD_FUSED=0 so
+    that F = 136 takes this path too): equal to fp32 rounding (summation order differs), every entry written, no NaN from the rows past R
+    of the last 32-document slab."""
+    import ctypes as C
+    from ptranking_amd import _lib
+    from ptranking_amd.scorer import FusedPointScorer
+    monkeypatch.setenv("PTR_BWD_FUSED", "0")
+    torch.manual_seed(F + R)
+    fused = FusedPointScorer(F, num_layers=NL, dropout=p).cuda()
+    X = torch.randn(R, F, device="cuda"); w = torch.randn(R, device="cuda")
+    preds = torch.empty(R, device="cuda"); acts = torch.empty(NL, R, 112, device="cuda")
+    st = _lib.current_stream(X.device)
+    seed = 77 + R
+    _lib.call("ptr_mlp_forward", _lib.ptr(X), _lib.ptr(fused.flat.data), R, F, NL, 1, C.c_float(p), C.c_uint64(seed), _lib.ptr(preds), _lib.ptr(acts), st)
+    ws = torch.empty(_lib.query("ptr_mlp_backward_ws_floats", F, NL), device="cuda")
+    dz = torch.empty(NL * R * 112, device="cuda")
+    grads = {}
+    for tail in ("1", "0"):
+        monkeypatch.setenv("PTR_BWD_TAIL", tail)
+        g = torch.full_like(fused.flat.data, float("nan"))
+        ws.fill_(float("nan")); dz.fill_(float("nan"))
+        _lib.call("ptr_mlp_backward", _lib.ptr(X), _lib.ptr(fused.flat.data), _lib.ptr(acts), _lib.ptr(w), R, F, NL, C.c_float(p), C.c_uint64(seed),
+                  _lib.ptr(dz), _lib.ptr(ws), _lib.ptr(g), st)
+        torch.cuda.synchronize()
+        assert torch.isfinite(g).all(), tail
+        grads[tail] = g.double().cpu()
+    scale = max(1.0, float(grads["0"].abs().max()))
+    assert float((grads["1"] - grads["0"]).abs().max()) <= 2e-5 * scale
