@@ -519,6 +519,11 @@ static int launch_linear(const float *X, int ldx, const float *W, const float *b
 // backward-weight tiling: a block covers 16*MTO outputs x 64*NTW inputs (wave w owns the input tiles w, w+4, ...).  Both are chosen to
 // minimise padding: K = 136 is 9 input tiles -> ONE block of NTW = 3 (a fixed 128-column block needed two, the second 94 % empty:
 // 27 TFLOP/s measured); N = 136 is 9 output tiles -> two blocks of MTO = 5.  MTO * NTW <= 24 accumulator tiles (96 registers) per wave.
+// linear_bw_x6.hip: the weight gradient on the bf16 instructions when one side of the product is narrow (plan 0 = not served)
+int lin_bw_x6_plan(int R, int K, int N, int ldx, int ldy, const void *X, const void *dY);
+int lin_bw_x6_chunks(int R);
+int launch_lin_bw_x6(int plan, const float *X, int ldx, const float *dY, int ldy, int R, int K, int N, float *ws, int chunks, hipStream_t st, const char *who);
+
 static void bw_tiling(int K, int N, int &MTO, int &NTW) {
     const int n_out = (N + 15) / 16, n_in = (K + 15) / 16;
     const int nbn = (n_out + 7) / 8;               // (r3: 9 tiles per block — N = 136 in one block, 172 VGPRs — measured SLOWER: 191 -> 216 us)
@@ -558,7 +563,9 @@ extern "C" int ptr_linear_backward_input(const float *dY, int ldy, const float *
 }
 
 extern "C" size_t ptr_linear_backward_weight_ws_floats(int R, int K, int N) {
-    return (size_t)ptr::bw_chunks(R, K, N) * ((size_t)N * K + N);
+    // the larger of the two kernels' needs (the bf16x6 form, linear_bw_x6.hip, runs one row chunk per CU)
+    const int c32 = ptr::bw_chunks(R, K, N), c6 = (K <= 140 || N <= 144) ? ptr::lin_bw_x6_chunks(R) : 0;
+    return (size_t)(c32 > c6 ? c32 : c6) * ((size_t)N * K + N);
 }
 
 // dW[N][K] = dY^T X,  db[N] = column sums of dY (db may be NULL)
@@ -573,6 +580,12 @@ extern "C" int ptr_linear_backward_weight(const float *X, int ldx, const float *
     if (R == 0) {
         if (int e = check_hip(hipMemsetAsync(dW, 0, nw * sizeof(float), st), who)) return e;
         return db ? check_hip(hipMemsetAsync(db, 0, N * sizeof(float), st), who) : 0;
+    }
+    if (const int plan = lin_bw_x6_plan(R, K, N, ldx, ldy, X, dY)) {
+        const int chunks6 = lin_bw_x6_chunks(R);
+        if (int e = launch_lin_bw_x6(plan, X, ldx, dY, ldy, R, K, N, ws, chunks6, st, who)) return e;
+        hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, ws, chunks6, n, n, dW, nw, db);
+        return check_hip(hipGetLastError(), who);
     }
     int MTO, NTW;
     bw_tiling(K, N, MTO, NTW);

@@ -201,3 +201,36 @@ def test_bn_stats_single_pass_is_accurate_with_large_offsets(R, N, group):
     r_ref = 1.0 / torch.sqrt(v_ref + BN_EPS)
     assert float(((mean.double().cpu() - m_ref).abs() / m_ref.abs()).max()) < 5e-7       # a few fp32 ulps of the mean itself
     assert float(((rstd.double().cpu() - r_ref).abs() / r_ref).max()) < 2e-4, float(((rstd.double().cpu() - r_ref).abs() / r_ref).max())
+
+
+# ---- r4: the weight gradient on the bf16 instructions when one side is narrow (csrc/linear_bw_x6.hip; default from 32768 rows on, PTR_LIN_BW_X6=2 forces it)
+@pytest.mark.parametrize("R,K,N", [(2049, 136, 408), (640, 136, 136), (1000, 136, 128), (777, 128, 256), (333, 100, 100), (65, 100, 4), (4097, 140, 1536),
+                                   (31, 8, 400), (1, 136, 136), (515, 512, 136), (300, 700, 100), (900, 44, 100), (40000, 136, 408), (70003, 100, 100),
+                                   (257, 256, 112), (130, 4, 8), (1000, 140, 144)])
+@pytest.mark.parametrize("bias", [True, False])
+def test_weight_gradient_bf16x6_matches_float64_and_the_fp32_kernel(R, K, N, bias, monkeypatch):
+    """dW = dY^T X and db through `ptr_linear_backward_weight` with the bf16x6 kernel forced (narrow dY / narrow X + ones column, 7- and 9-tile
+    narrow images, one and several passes over the wide side, ragged last slab) against float64 and against the fp32-MFMA kernel: its error is
+    not above the fp32 kernel's, and every entry of dW / db is written."""
+    from ptranking_amd.linear import _bwd_weight
+    torch.manual_seed(R + K + N)
+    x = torch.randn(R, K, device="cuda")
+    dy = torch.randn(R, N, device="cuda")
+    ref_w = dy.double().cpu().t() @ x.double().cpu()
+    ref_b = dy.double().cpu().sum(0)
+    out = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("PTR_LIN_BW_X6", mode)
+        dw = torch.full((N, K), float("nan"), device="cuda")
+        db = torch.full((N,), float("nan"), device="cuda") if bias else None
+        _bwd_weight(x, K, dy, bias, dw_out=dw, db_out=db)
+        torch.cuda.synchronize()
+        assert torch.isfinite(dw).all() and (db is None or torch.isfinite(db).all()), mode
+        out[mode] = (dw.double().cpu(), None if db is None else db.double().cpu())
+    sw = max(1.0, float(ref_w.abs().max()))
+    e32, e6 = float((out["0"][0] - ref_w).abs().max()), float((out["2"][0] - ref_w).abs().max())
+    assert e6 <= max(2e-5 * sw, 1.5 * e32), (e6, e32, sw)
+    if bias:
+        sb = max(1.0, float(ref_b.abs().max()))
+        b32, b6 = float((out["0"][1] - ref_b).abs().max()), float((out["2"][1] - ref_b).abs().max())
+        assert b6 <= max(2e-5 * sb, 1.5 * b32), (b6, b32, sb)
