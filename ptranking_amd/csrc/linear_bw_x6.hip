@@ -228,9 +228,11 @@ int lin_bw_x6_plan(int R, int K, int N, int ldx, int ldy, const void *X, const v
     return a_ok ? 1 : 2;
 }
 int lin_bw_x6_chunks(int R) {
-    int dev = 0, ncu = 256;
-    hipDeviceProp_t pr;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+    static const int ncu = [] {                          // one row chunk per CU (queried once: hipGetDeviceProperties is not a per-call cost)
+        int dev = 0;
+        hipDeviceProp_t pr;
+        return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+    }();
     const int maxc = (R + 255) / 256;
     return maxc < ncu ? (maxc < 1 ? 1 : maxc) : ncu;
 }
