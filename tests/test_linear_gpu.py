@@ -234,3 +234,20 @@ def test_weight_gradient_bf16x6_matches_float64_and_the_fp32_kernel(R, K, N, bia
         sb = max(1.0, float(ref_b.abs().max()))
         b32, b6 = float((out["0"][1] - ref_b).abs().max()), float((out["2"][1] - ref_b).abs().max())
         assert b6 <= max(2e-5 * sb, 1.5 * b32), (b6, b32, sb)
+
+
+@pytest.mark.parametrize("K,N", [(136, 408), (100, 100), (408, 136)])
+def test_weight_gradient_bf16x6_reads_strided_rows(K, N, monkeypatch):
+    """X as a column slice of a wider matrix (row stride > K): the narrow-side kernel takes leading dimensions like the fp32 kernel does."""
+    from ptranking_amd.linear import _bwd_weight
+    monkeypatch.setenv("PTR_LIN_BW_X6", "2")
+    torch.manual_seed(K + N)
+    R, pad = 3000, 12
+    big = torch.randn(R, K + pad, device="cuda")
+    x = big[:, 4:4 + K]                                      # 16-byte aligned column offset, row stride K + 12
+    dy = torch.randn(R, N, device="cuda")
+    dw = torch.full((N, K), float("nan"), device="cuda"); db = torch.full((N,), float("nan"), device="cuda")
+    _bwd_weight(x, K + pad, dy, True, dw_out=dw, db_out=db)
+    ref_w = dy.double().cpu().t() @ x.double().cpu()
+    close(dw, ref_w, tol=2e-5, what="dw")
+    close(db, dy.double().cpu().sum(0), tol=2e-5, what="db")
