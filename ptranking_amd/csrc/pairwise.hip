@@ -135,12 +135,32 @@ pairwise_bce_kernel(const float *__restrict__ preds, const float *__restrict__ l
             const float S = fminf(fmaxf(dy, -1.0f), 1.0f);      // lambda_utils.py:20
             const float tt = 0.5f * (1.0f + S);
             const float x = sigma * ds;
-            const float p = 1.0f / (1.0f + expf(-x));           // IEEE division: p may legitimately hit 0 / 1
-            const float qv = 1.0f - p;
-            const float l1 = fmaxf(logf(p), -100.0f), l0 = fmaxf(logf(qv), -100.0f);
+            float p, qv, l1, l0, gp;                            // gp = (p - t) * sigmoid'(x) / max(p (1 - p), 1e-12)
+            if (__any(!(fabsf(x) <= 80.0f))) {
+                // score gaps this wide reach the reference's edge arithmetic (p denormal or rounded to 0 / 1, BCE's -100 clamp, the
+                // 1e-12 floor under p(1-p)): the library functions and IEEE divisions, as the reference's ATen kernels compute it
+                p = 1.0f / (1.0f + expf(-x));
+                qv = 1.0f - p;
+                l1 = fmaxf(logf(p), -100.0f); l0 = fmaxf(logf(qv), -100.0f);
+                const float den = qv * p;
+                gp = ((p - tt) / fmaxf(den, 1e-12f)) * den;
+            } else {
+                // |x| <= 80 for every pair of this wavefront step: e = exp(-|x|) is a normal float, the larger probability is 1/(1+e) by
+                // v_rcp + one Newton step (the LambdaRank kernels' form), the smaller one its product with e; logs on the transcendental
+                // pipe (1 ulp: 1e-7 absolute near 1, against per-query losses of 10^2); the 1e-12 floor under p (1 - p) (reached from
+                // |x| > 27.6 on) becomes a factor instead of a division
+                const float e = __expf(-fabsf(x));
+                const float dd = 1.0f + e;
+                float pb = __builtin_amdgcn_rcpf(dd);
+                pb = fmaf(pb, fmaf(-dd, pb, 1.0f), pb);
+                p = x >= 0.0f ? pb : e * pb;
+                qv = 1.0f - p;
+                l1 = fmaxf(fast_ln(p), -100.0f); l0 = fmaxf(fast_ln(qv), -100.0f);
+                const float den = qv * p;
+                gp = (p - tt) * (den >= 1e-12f ? 1.0f : den * 1e12f);
+            }
             lacc += ((tt - 1.0f) * l0 - tt * l1) * act;
-            const float den = qv * p;
-            lam = (sigma * (((p - tt) / fmaxf(den, 1e-12f)) * den)) * act;
+            lam = (sigma * gp) * act;
         }
         const float sl = fwd ? lam : -lam;
         ga[m] += sl;
