@@ -79,6 +79,25 @@ def test_argument_errors_need_no_gpu(lib_path):
     assert rc == 1001 and b"label_type" in lib.ptr_last_error()
 
 
+def test_x6_entry_point_validates_without_a_gpu():
+    """ABI v3: `ptr_mlp_x6_ws_bytes` / `ptr_mlp_forward_x6` — the configurations the bf16x6 forward does not serve report 0 bytes /
+    PTR_ERR_UNSUPPORTED, bad arguments PTR_ERR_INVALID_ARG, an empty batch succeeds, all before any launch."""
+    from ptranking_amd import _lib
+    lib = _lib.load()
+    lib.ptr_mlp_x6_ws_bytes.restype = ctypes.c_size_t
+    assert lib.ptr_mlp_x6_ws_bytes(136, 3) == 13 * 21504 + 16384          # 5 + 4 + 4 slices of the weight image + the trace area
+    assert lib.ptr_mlp_x6_ws_bytes(46, 3) == 0 and lib.ptr_mlp_x6_ws_bytes(136, 1) == 0 and lib.ptr_mlp_x6_ws_bytes(136, 9) == 0
+    one = ctypes.c_void_p(4096)
+    args = lambda R, F, NL, p, X=one, acts=one: (X, one, R, F, NL, 1, ctypes.c_float(p), ctypes.c_uint64(1), one, acts, one, None)
+    assert lib.ptr_mlp_forward_x6(*args(8, 46, 3, 0.1)) == 1002 and b"bf16x6" in lib.ptr_last_error()
+    assert lib.ptr_mlp_forward_x6(*args(8, 136, 3, 1.5)) == 1001 and b"dropout" in lib.ptr_last_error()
+    assert lib.ptr_mlp_forward_x6(*args(8, 136, 3, 0.1, X=None)) == 1001 and b"NULL" in lib.ptr_last_error()
+    assert lib.ptr_mlp_forward_x6(*args(8, 136, 3, 0.1, X=ctypes.c_void_p(4100))) == 1001 and b"aligned" in lib.ptr_last_error()
+    assert lib.ptr_mlp_forward_x6(*args(8, 136, 3, 0.1, acts=None)) == 1001           # a training forward stores its activations
+    assert lib.ptr_mlp_forward_x6(*args(2 ** 23, 136, 3, 0.1)) == 1002 and b"4 GB" in lib.ptr_last_error()
+    assert lib.ptr_mlp_forward_x6(*args(0, 136, 3, 0.1)) == 0
+
+
 def test_product_path_fails_loudly_on_cpu_tensors():
     import ptranking_amd as pa
     p, y = torch.zeros(2, 8), torch.zeros(2, 8)
