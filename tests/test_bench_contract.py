@@ -84,3 +84,17 @@ def test_ring_pair_statistics():
     assert abs(st["blocks_skipped_frac"] - ((1 + 0 + 4) / 3) / 4) < 1e-6
     eq = [(10 * 9 + 118 * 117) / (128 * 127), (70 * 69 + 58 * 57) / (128 * 127), 1.0]
     assert abs(st["zero_weight_pairs_frac"] - sum(eq) / 3) < 1e-6
+
+
+def test_self_launch_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` with no rank environment launches its own N ranks (one per GPU over RCCL); on a node with fewer GPUs it
+    must stop with a message instead of running one rank and reporting n_gpus = 1 (the round-3 behaviour the driver's scaling tier tripped on)."""
+    import os, subprocess, sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["HIP_VISIBLE_DEVICES"] = ""                                   # a GPU box too: no device visible to this child
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
+                         capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode != 0 and out.stdout.strip() == ""
+    assert "one rank per GPU is required" in out.stderr
