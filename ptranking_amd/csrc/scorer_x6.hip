@@ -136,6 +136,22 @@ constexpr uint32_t kX6Oob = 0xFFFFF000u;       // an offset no buffer of ours re
 // next layer's B fragments) of the tile that has just finished.  Registers: nothing may spill — a scratch reload waits with vmcnt for
 // everything older, i.e. for the DMA pieces and X loads in flight (r4 trace: 9 K instead of 3.4 K cycles per step around the spills).
 #define X6_SB() __builtin_amdgcn_sched_barrier(0)
+#ifdef PTR_X6_TILEMAJOR
+#define X6_TSTRIDE 1024
+#ifdef PTR_X6_TM_HALF6
+#define X6_TBLOCK 6656u          /* tile 6 = 16 rows x 32 B (features 96..103) */
+#else
+#define X6_TBLOCK 7168u
+#endif
+#else
+#define X6_TSTRIDE 64
+#endif
+#if defined(PTR_X6_TILEMAJOR) && defined(PTR_X6_TM_HALF6)
+// tile 6 of a 16-row block: lanes g < 2 write 16 B at j * 32 + g * 16, the others nothing
+#define X6_T6FIX(o, mt) ((mt) == kMT - 1 ? ((g < 2 && (o) != kX6Oob) ? (o) - (uint32_t)lane * 16u + (uint32_t)(j * 32 + g * 16) : kX6Oob) : (o))
+#else
+#define X6_T6FIX(o, mt) (o)
+#endif
 // interleave hint for the region in front of it: NM x (1 MFMA, then NV VALU)
 #define X6_MIX(NM, NV)                                                                                     \
     do {                                                                                                   \
@@ -268,23 +284,40 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
     };
     // one slice step (see the schedule above).  In: af[AP] = tile 0 of this slice; out: af[AP ^ 1] = tile 0 of the next slice (its base
     // returned).  work(r): the VALU work beside the MFMAs of tile r; Ks: VALU instructions per MFMA of the interleave hint (0 = none)
-    auto slice_step = [&](auto ap_, uint32_t abase, const Frag (&bf)[DT][3], auto &&work, auto ks_) __attribute__((always_inline)) -> uint32_t {
+    // LATE (the epilogue-carrying steps of the training kernel): the next tile's A fragments are read BEHIND the work of the current tile instead
+    // of one tile ahead, so the read-ahead set is not live beside the epilogue's temporaries — the 12 registers that decide between spilling and
+    // not spilling there (r5: a scratch reload waits with vmcnt for the activation stores in flight; the exposed LDS latency is hidden by the
+    // partner wave, a drained store queue is not)
+    auto slice_step = [&](auto ap_, uint32_t abase, const Frag (&bf)[DT][3], auto &&work, auto ks_, auto late_) __attribute__((always_inline)) -> uint32_t {
         constexpr int AP = decltype(ap_)::value;
+        constexpr bool LATE = decltype(late_)::value;
         uint32_t nb = 0;
         static_for<kMT>([&](auto r_) __attribute__((always_inline)) {
             constexpr int r = decltype(r_)::value;
             constexpr int K = x6_kget<r>(decltype(ks_){});
             if constexpr (r == 3) nb = slice_sync();
-            if constexpr (r < kMT - 1) read_a(af[AP ^ ((r + 1) & 1)], abase, r + 1);
-            else read_a(af[AP ^ 1], nb, 0);
-            X6_SB();
+            if constexpr (!LATE) {
+                if constexpr (r < kMT - 1) read_a(af[AP ^ ((r + 1) & 1)], abase, r + 1);
+                else read_a(af[AP ^ 1], nb, 0);
+                X6_SB();
+            }
             mma_tile(af[AP ^ (r & 1)], r_, bf);
             work(r_);
             if constexpr (K > 0) X6_MIX(6 * DT, K);
             X6_SB();
+            if constexpr (LATE) {
+                if constexpr (r < kMT - 1) read_a(af[AP ^ ((r + 1) & 1)], abase, r + 1);
+                else read_a(af[AP ^ 1], nb, 0);
+                X6_SB();
+            }
         });
         return nb;
     };
+#ifndef PTR_X6_LATE
+#define PTR_X6_LATE 2
+#endif
+    using Early = std::false_type;
+    using LateE = std::bool_constant<TRAIN && PTR_X6_LATE != 0>;      // steps whose work is an epilogue
     using KNone = X6K<0, 0, 0, 0, 0, 0, 0>;
     auto nowork = [](auto) __attribute__((always_inline)) {};
 
@@ -343,7 +376,13 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
     uint32_t abase = lane_a;
     read_a(af[0], abase, 0);
     // VALU per MFMA of the hints: an X-fragment quarter is ~22 (eval) / ~50 (training) instructions, a tile's epilogue ~52 / ~110
-    constexpr int KX = TRAIN ? 4 : 2, KE = TRAIN ? 9 : 5;
+#ifndef PTR_X6_KE_TRAIN
+#define PTR_X6_KE_TRAIN 9
+#endif
+#ifndef PTR_X6_KX_TRAIN
+#define PTR_X6_KX_TRAIN 4
+#endif
+    constexpr int KX = TRAIN ? PTR_X6_KX_TRAIN : 2, KE = TRAIN ? PTR_X6_KE_TRAIN : 5;
 
 #pragma unroll 1
     for (int it = 0; it < npass; ++it) {
@@ -352,6 +391,8 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
         auto store_off = [&](int layer, int dt) __attribute__((always_inline)) {       // opaque: `+ 64 mt` stays an immediate instead of seven hoisted select operands
 #ifdef PTR_X6_L2STORE      // ablation: the same store instructions, aimed at an L2-resident part of the buffer
             uint32_t o = j < R - t32 - 16 * dt ? jA + ((uint32_t)((t32 + 16 * dt) & 2047) * (kAL * 4)) : kX6Oob;
+#elif defined(PTR_X6_TILEMAJOR)   // timing experiment: every store instruction writes ONE contiguous KB (tile-major [R/16][7][16 rows][16 features])
+            uint32_t o = j < R - t32 - 16 * dt ? (uint32_t)lane * 16u + ((uint32_t)((t32 + 16 * dt) >> 4) * X6_TBLOCK + (uint32_t)layer * layer_bytes) : kX6Oob;
 #else
             uint32_t o = j < R - t32 - 16 * dt ? jA + ((uint32_t)(t32 + 16 * dt) * (kAL * 4) + (uint32_t)layer * layer_bytes) : kX6Oob;
 #endif
@@ -375,10 +416,13 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
                     f32x4 o = h;
                     if (mt == kMT - 1 && g == 1) o[0] = 1.0f;              // the ones column (100) of the fused backward
 #ifndef PTR_X6_NOSTORE
-                    x6_store16(asrd, store_off(site - 1, dt) + 64 * mt, o);
+                    x6_store16(asrd, X6_T6FIX(store_off(site - 1, dt), mt) + X6_TSTRIDE * mt, o);
 #endif
                 }
                 split_pack4(h, bp[mt >> 1][dt], 2 * (mt & 1));
+#ifdef PTR_X6_EPI_SB
+                if constexpr (TRAIN) X6_SB();
+#endif
                 if (mt == kMT - 1) {
 #pragma unroll
                     for (int p = 0; p < 3; ++p) { bp[3][dt][p].u[2] = 0u; bp[3][dt][p].u[3] = 0u; }
@@ -404,7 +448,7 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
                 for (int c = 0; c < 4; ++c) { h[c] = relu1(h[c]); sc[dt] = fmaf(h[c], w4[c], sc[dt]); }
                 if constexpr (STORE) {
 #ifndef PTR_X6_NOSTORE
-                    x6_store16(asrd, store_off(NL - 1, dt) + 64 * mt, h);
+                    x6_store16(asrd, X6_T6FIX(store_off(NL - 1, dt), mt) + X6_TSTRIDE * mt, h);
 #endif
                 }
             }
@@ -425,7 +469,7 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
                 } else {                            // eight quarters: two beside tile 0, one beside each other tile
                     if constexpr (r == 0) { quarter(0); quarter(1); } else quarter(r + 1);
                 }
-            }, std::conditional_t<DT == 2, X6K<KX, KX, 0, KX, KX, 0, 0>, X6K<KX, KX / 2, KX / 2, KX / 2, KX / 2, KX / 2, KX / 2>>{});
+            }, std::conditional_t<DT == 2, X6K<KX, KX, 0, KX, KX, 0, 0>, X6K<KX, KX / 2, KX / 2, KX / 2, KX / 2, KX / 2, KX / 2>>{}, Early{});
         };
         // the last slice of layer 1: the epilogue of a tile rides beside the MFMAs of the next one
         auto l1_last = [&](auto par_) __attribute__((always_inline)) {
@@ -433,7 +477,7 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
             abase = slice_step(par_, abase, bfx[PAR], [&](auto r_) __attribute__((always_inline)) {
                 constexpr int r = decltype(r_)::value;
                 if constexpr (r > 0) epilogue(std::integral_constant<int, r - 1>{}, 1);
-            }, X6K<0, KE, KE, KE, KE, KE, KE>{});
+            }, X6K<0, KE, KE, KE, KE, KE, KE>{}, LateE{});
             epilogue(std::integral_constant<int, kMT - 1>{}, 1);
             if constexpr (PAR == 0) {               // an odd number of layer-1 slices: the hidden layers expect the next A fragment in set 0
 #pragma unroll
@@ -449,14 +493,14 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
         // ---- hidden layers 2 .. NL: B fragments = the registers the previous epilogue left
         auto hidden = [&](auto lastlayer_, int l) __attribute__((always_inline)) {
             constexpr bool LAST = decltype(lastlayer_)::value;
-            abase = slice_step(I0{}, abase, bp[0], nowork, KNone{});
-            abase = slice_step(I1{}, abase, bp[1], nowork, KNone{});
+            abase = slice_step(I0{}, abase, bp[0], nowork, KNone{}, Early{});
+            abase = slice_step(I1{}, abase, bp[1], nowork, KNone{}, Early{});
             if constexpr (LAST) {                    // the next tile's first two X slices, in front of this layer's store burst
 #pragma unroll
                 for (int q = 0; q < 2 * DT; ++q) { load_xq(raw[0], t32n, 0, q); load_xq(raw[1], t32n, n1 > 1 ? 1 : 0, q); }      // (past the end: zeros, never used)
                 X6_SB();
             }
-            abase = slice_step(I0{}, abase, bp[2], nowork, KNone{});
+            abase = slice_step(I0{}, abase, bp[2], nowork, KNone{}, Early{});
             if constexpr (LAST) {
                 abase = slice_step(I1{}, abase, bp[3], [&](auto r_) __attribute__((always_inline)) {
                     constexpr int r = decltype(r_)::value;
@@ -464,13 +508,13 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
                     auto quarter = [&](int q) __attribute__((always_inline)) { make_bq(raw[0], t32n, 0, bfx[0], q); load_xq(raw[0], t32n, n1 > 2 ? 2 : 0, q); };
                     if constexpr (r < 4) { if constexpr (DT == 2) quarter(r); else { quarter(2 * r); quarter(2 * r + 1); } }
                     if constexpr (r > 0) epilogue_out(std::integral_constant<int, r - 1>{});
-                }, X6K<KX, KX + 1, KX + 1, KX + 1, 1, 1, 1>{});
+                }, X6K<KX, KX + 1, KX + 1, KX + 1, 1, 1, 1>{}, std::bool_constant<TRAIN && PTR_X6_LATE == 2>{});
                 epilogue_out(std::integral_constant<int, kMT - 1>{});
             } else {
                 abase = slice_step(I1{}, abase, bp[3], [&](auto r_) __attribute__((always_inline)) {
                     constexpr int r = decltype(r_)::value;
                     if constexpr (r > 0) epilogue(std::integral_constant<int, r - 1>{}, l + 1);
-                }, X6K<0, KE, KE, KE, KE, KE, KE>{});
+                }, X6K<0, KE, KE, KE, KE, KE, KE>{}, LateE{});
                 epilogue(std::integral_constant<int, kMT - 1>{}, l + 1);
             }
         };

@@ -62,6 +62,21 @@ def x6_mode():
     return os.environ.get("PTR_MLP_X6", "1")
 
 
+X6_BUFFER_LIMIT = 0xFFFFF000      # bytes a buffer resource of ptr_mlp_forward_x6 addresses (scorer_x6.hip: X and the stored activations)
+
+
+def x6_serves(X2d, R, F, NL, train):
+    """The run-time limits of ptr_mlp_forward_x6 beyond (F, NL): 16-byte aligned X, R * F * 4 and (training) NL * R * 448 bytes below 4 GB.
+    Inputs outside take ptr_mlp_forward, which has none of them (big evaluation batches, e.g. F = 700 x 1.6 M rows)."""
+    if X2d.data_ptr() % 16:
+        return False
+    if R * F * 4 >= X6_BUFFER_LIMIT:
+        return False
+    if train and NL * R * ACT_LD * 4 >= X6_BUFFER_LIMIT:
+        return False
+    return True
+
+
 _X6_WS = {}
 
 
@@ -81,6 +96,8 @@ def mlp_forward(X2d, flat, R, F, NL, train, p, seed, preds, acts, dev):
     """Scorer forward through the C ABI: the bf16x6 entry point when it serves (F, NL), the fp32-MFMA one otherwise."""
     mode = x6_mode()
     ws = x6_workspace(dev, F, NL) if (mode == "2" or (mode != "0" and R >= X6_MIN_ROWS)) else None
+    if ws is not None and not x6_serves(X2d, R, F, NL, train):
+        ws = None                            # the fp32-MFMA entry point serves what the bf16x6 one refuses (4 GB buffer resources, alignment)
     if ws is not None:
         _lib.call("ptr_mlp_forward_x6", _lib.ptr(X2d), _lib.ptr(flat), R, F, NL, int(train), C.c_float(p), C.c_uint64(seed),
                   _lib.ptr(preds), _lib.ptr(acts), _lib.ptr(ws), _lib.current_stream(dev))

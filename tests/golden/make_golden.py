@@ -345,6 +345,90 @@ def gen_big():
     print(f"losses_big.npz: {len(store)} arrays")
 
 
+def gen_knife():
+    """The sigmoid-saturation knife edge: pairwise gaps with sigma * s_ij swept over [14, 19] in steps of 2^-6, both target
+    orientations.  In this band ATen's fp32 sigmoid rounds to exactly 1.0 (from sigma * s_ij ~ 16.64 on: 1 - p < 2^-25), where the reference's BCE
+    jumps from -log(1 - p) ~ 16.6 to the -100 clamp and its gradient to exactly 0 (lambdarank.py:52, lambda_utils.py:15, lambdaloss.py:118-119;
+    Robust_Sigmoid, base/utils.py:57-95, for ApproxNDCG with alpha * (s_i - s_j)).  One query per gap value x: six documents with the scores
+    (0, x, 1/4, x + 1/4, 1/2, x + 1/2) / sigma under the sorted labels (2, 2, 1, 1, 0, 0), so that every gap x + {-1/2 .. 1/2} occurs with the
+    better document above AND below.  Kept in a file of its own so that losses.npz stays byte-identical."""
+    store = {}
+    xs = np.arange(14.0, 19.0 + 1e-9, 2.0 ** -6, dtype=np.float64)
+
+    def lists(scale):
+        base = np.stack([np.zeros_like(xs), xs, 0.25 + 0 * xs, xs + 0.25, 0.5 + 0 * xs, xs + 0.5], axis=1) / scale
+        return base.astype(np.float32), np.tile(np.array([2, 2, 1, 1, 0, 0], np.float32), (len(xs), 1))
+
+    for sigma in (1.0, 2.5):
+        preds, labels = lists(sigma)
+        tag = f"knife_s{sigma:g}"
+        loss, grad = run_loss(LambdaRank(sf_para_dict=SF, model_para_dict={"sigma": sigma}, device="cpu"), preds, labels)
+        add(store, f"lambdarank/{tag}", preds=preds, labels=labels, sigma=np.float32(sigma), loss=loss, grad=grad, sort_idx=pred_sort_idx(preds))
+        loss, grad = run_loss(RankNet(sf_para_dict=SF, model_para_dict={"sigma": sigma}, device="cpu"), preds, labels)
+        add(store, f"ranknet/{tag}", preds=preds, labels=labels, sigma=np.float32(sigma), loss=loss, grad=grad)
+    preds, labels = lists(1.0)
+    for lt, code in (("NDCG_Loss2", 1), ("NDCG_Loss2++", 2)):
+        mpd = dict(k=6, sigma=1.0, loss_type=lt, mu=5.0)
+        loss, grad = run_loss(LambdaLoss(sf_para_dict=SF, model_para_dict=mpd, device="cpu"), preds, labels)
+        add(store, f"lambdaloss/knife_t{code}", preds=preds, labels=labels, sigma=np.float32(1.0), k=np.int32(6), mu=np.float32(5.0),
+            loss_type=np.int32(code), loss=loss, grad=grad)
+    # ApproxNDCG: the pair term is Robust_Sigmoid(alpha * (s_i - s_j)); alpha = 10 (the default) and alpha = 1 (the sigma == 1 branch)
+    for alpha in (10.0, 1.0):
+        preds, labels = lists(alpha)
+        loss, grad = run_loss(ApproxNDCG(sf_para_dict=SF, model_para_dict={"alpha": alpha}, device="cpu"), preds, labels)
+        add(store, f"approxndcg/knife_a{alpha:g}", preds=preds, labels=labels, alpha=np.float32(alpha), loss=loss, grad=grad)
+    # "hug": the band's actual discontinuities.  For x in [14.6, 17.4] the reference's 1 - p is k * 2^-24 with k = .., 4, 2, 0 (p is an fp32 in
+    # [0.5, 1]); -log(1 - p) and the gradient factor jump wherever k changes, and k = 0 is the -100 clamp / the exactly-zero gradient.  The four
+    # thresholds x_k (smallest fp32 x at which ATen's sigmoid returns 1 - k * 2^-24) are found HERE by bisection on the reference's own
+    # torch.sigmoid; the lists put gaps at x_k -/+ {2^-9, 2^-11, 2^-13} — 10^3 times further out than the ~1e-7 window in which two correctly
+    # rounded exp implementations may disagree about k, close enough that a kernel whose p is off by more than a few ulp takes the wrong side
+    def threshold(k):
+        target = np.float32(1.0) - np.float32(k) * np.float32(2.0 ** -24)
+        lo, hi = np.float32(14.0), np.float32(19.0)
+        while np.nextafter(lo, hi) < hi:
+            mid = np.float32((np.float64(lo) + np.float64(hi)) / 2)
+            if torch.sigmoid(torch.tensor([mid]))[0].item() >= target: hi = mid
+            else: lo = mid
+        return float(hi)
+    th = sorted({threshold(k) for k in range(0, 9)}, reverse=True)[:4]     # ATen evaluates 1 / (1 + exp(-x)): 1 + e is a multiple of 2^-23, so k is even
+    hug = np.array([t + sg * 2.0 ** -e for t in th for e in (9, 11, 13) for sg in (-1.0, 1.0)], np.float64)
+
+    def hug_lists(scale):
+        base = np.stack([np.zeros_like(hug), hug, 0.25 + 0 * hug, hug + 0.25, 0.5 + 0 * hug, hug + 0.5], axis=1) / scale
+        return base.astype(np.float32), np.tile(np.array([2, 2, 1, 1, 0, 0], np.float32), (len(hug), 1))
+    preds, labels = hug_lists(1.0)
+    loss, grad = run_loss(LambdaRank(sf_para_dict=SF, model_para_dict={"sigma": 1.0}, device="cpu"), preds, labels)
+    add(store, "lambdarank/knife_hug", preds=preds, labels=labels, sigma=np.float32(1.0), loss=loss, grad=grad, sort_idx=pred_sort_idx(preds),
+        thresholds=np.asarray(th, np.float64))
+    loss, grad = run_loss(RankNet(sf_para_dict=SF, model_para_dict={"sigma": 1.0}, device="cpu"), preds, labels)
+    add(store, "ranknet/knife_hug", preds=preds, labels=labels, sigma=np.float32(1.0), loss=loss, grad=grad)
+    mpd = dict(k=6, sigma=1.0, loss_type="NDCG_Loss2", mu=5.0)
+    loss, grad = run_loss(LambdaLoss(sf_para_dict=SF, model_para_dict=mpd, device="cpu"), preds, labels)
+    add(store, "lambdaloss/knife_hug", preds=preds, labels=labels, sigma=np.float32(1.0), k=np.int32(6), mu=np.float32(5.0),
+        loss_type=np.int32(1), loss=loss, grad=grad)
+    loss, grad = run_loss(ApproxNDCG(sf_para_dict=SF, model_para_dict={"alpha": 1.0}, device="cpu"), preds, labels)
+    add(store, "approxndcg/knife_hug", preds=preds, labels=labels, alpha=np.float32(1.0), loss=loss, grad=grad)
+    # a longer list: 64 documents whose neighbours are 17/63 apart, so the gaps k * 17/63 cross the band at many (i, j) with mixed labels
+    rng = np.random.default_rng(SEED + 23)
+    L = 64
+    preds = (np.arange(L, dtype=np.float64)[None, :] * (17.0 / 63.0) + rng.uniform(-0.02, 0.02, (4, L))).astype(np.float32)
+    preds = np.take_along_axis(preds, np.stack([rng.permutation(L) for _ in range(4)]), axis=1)
+    labels = -np.sort(-rng.choice(5, size=(4, L), p=MSLR_P).astype(np.float32), axis=1)
+    labels[:, 0] = np.maximum(labels[:, 0], 1)
+    loss, grad = run_loss(LambdaRank(sf_para_dict=SF, model_para_dict={"sigma": 1.0}, device="cpu"), preds, labels)
+    add(store, "lambdarank/knife_L64", preds=preds, labels=labels, sigma=np.float32(1.0), loss=loss, grad=grad, sort_idx=pred_sort_idx(preds))
+    loss, grad = run_loss(RankNet(sf_para_dict=SF, model_para_dict={"sigma": 1.0}, device="cpu"), preds, labels)
+    add(store, "ranknet/knife_L64", preds=preds, labels=labels, sigma=np.float32(1.0), loss=loss, grad=grad)
+    mpd = dict(k=64, sigma=1.0, loss_type="NDCG_Loss2", mu=5.0)
+    loss, grad = run_loss(LambdaLoss(sf_para_dict=SF, model_para_dict=mpd, device="cpu"), preds, labels)
+    add(store, "lambdaloss/knife_L64", preds=preds, labels=labels, sigma=np.float32(1.0), k=np.int32(64), mu=np.float32(5.0),
+        loss_type=np.int32(1), loss=loss, grad=grad)
+    loss, grad = run_loss(ApproxNDCG(sf_para_dict=SF, model_para_dict={"alpha": 1.0}, device="cpu"), preds, labels)
+    add(store, "approxndcg/knife_L64", preds=preds, labels=labels, alpha=np.float32(1.0), loss=loss, grad=grad)
+    np.savez_compressed(os.path.join(HERE, "losses_knife.npz"), **store)
+    print(f"losses_knife.npz: {len(store)} arrays")
+
+
 def gen_metrics():
     store = {}
     # --- the reference's own known-answer vectors, testing/metric/testing_metric.py:17-61 ---
@@ -401,6 +485,8 @@ def gen_metrics():
 if __name__ == "__main__":
     if "--only-big" in sys.argv:
         gen_big()
+    elif "--only-knife" in sys.argv:
+        gen_knife()
     elif "--only-siblings" in sys.argv:
         gen_siblings()
     else:
@@ -408,4 +494,5 @@ if __name__ == "__main__":
         gen_metrics()
         gen_siblings()
         gen_big()
+        gen_knife()
     print("torch", torch.__version__, "numpy", np.__version__)

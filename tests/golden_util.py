@@ -52,13 +52,14 @@ _CACHE = {}
 
 
 def losses():
-    """losses.npz (edge cases, small shapes) merged with losses_big.npz (reference outputs at BASELINE.json's config shapes)."""
+    """losses.npz (edge cases, small shapes) merged with losses_big.npz (reference outputs at BASELINE.json's config shapes) and
+    losses_knife.npz (the sigmoid-saturation band, reference outputs)."""
     if "l" not in _CACHE:
         d = _load("losses.npz")
-        big = os.path.join(GOLDEN_DIR, "losses_big.npz")
-        if os.path.exists(big):
-            for fam, cases in _load("losses_big.npz").items():
-                d.setdefault(fam, {}).update(cases)
+        for extra in ("losses_big.npz", "losses_knife.npz"):       # reference outputs at BASELINE's shapes; the sigmoid-saturation knife edge
+            if os.path.exists(os.path.join(GOLDEN_DIR, extra)):
+                for fam, cases in _load(extra).items():
+                    d.setdefault(fam, {}).update(cases)
         _CACHE["l"] = d
     return _CACHE["l"]
 
