@@ -72,6 +72,24 @@ def synth_batch(gen, B, L, F, device):
     return X, Y.contiguous()
 
 
+def padded_lens(gen, B, L, device):
+    """Documents per query of a padded batch: MSLR-WEB30K-like (1 .. 1251 documents, mean ~120, ptranking/data/data_utils.py:118-123) clipped to
+    the padded length L — a Gamma(2.2) with mean 120, clipped to [1, L] (int32, on the device)."""
+    g = torch._standard_gamma(torch.full((B,), 2.2, device=device), generator=gen) * (120.0 / 2.2)
+    return g.round().clamp_(1, L).to(torch.int32)
+
+
+def pad_batch(gen, X, Y, L):
+    """(X, Y) of full lists -> the padded form PaddedQueryBatches produces: rows past lens[q] are zero features / zero labels, the real
+    documents keep their label order (sorted descending), at least one relevant document per query."""
+    lens = padded_lens(gen, X.shape[0], L, X.device)
+    real = torch.arange(L, device=X.device)[None, :] < lens[:, None]
+    Y = torch.where(real, Y, torch.zeros_like(Y))
+    Y[:, 0] = torch.clamp(Y[:, 0], min=1.0)
+    X = X * real[:, :, None]
+    return X.contiguous(), Y.contiguous(), lens
+
+
 def sf_para_dict(F, lr=1e-3):
     return {"sf_id": "pointsf", "opt": "Adam", "lr": lr,
             "pointsf": dict(num_features=F, num_layers=3, AF="R", TL_AF="S", apply_tl_af=False, BN=False, bn_type=None,
@@ -130,12 +148,75 @@ def cpu_baseline(L, F, budget_s):
     torch.set_num_threads(all_threads)
     best = max(by_batch.values(), key=lambda d: d["queries_per_s"])
     return {"value": best["queries_per_s"], "unit": "queries/s", "cores": best["threads"], "host_threads_available": all_threads,
-            "kind": "port",
+            "kind": "port", "reference_on_box": False,      # the reference tree exists only in the build container: the GPU box times the port
             "sample": f"torch-CPU restatement of the reference train_op (pointsf scorer + LambdaRank + Adam) on {L} docs x {F} feats: "
                       f"thread sweep {cands} at batch 256, then batch 1 / 64 at the best thread count, {total:.1f} s in total, "
                       f"value = best; plus {lel:.1f} s loss-only.  The reference itself vs this port on the build container: "
                       f"profiles/r02_reference_vs_port_cpu.json",
             "thread_sweep": sweep, "by_batch": by_batch, "loss_only_queries_per_s": lq}
+
+
+def metric_path(ranker, B, L, F, device, rank, ks=(1, 3, 5, 10, 20, 50), cpu_seconds=3.0):
+    """Evaluator.ndcg_at_ks + Evaluator.ap_at_k over a synthetic loader (8 batches of B queries, device-resident, presort=True): the
+    device path (DeviceEvaluator: predict -> ptr_metrics_at_ks) against the port of the reference's CPU loop (ptranking/base/ranker.py:67-95,
+    130-160: predict -> sort -> gather -> torch_ndcg_at_ks / torch_ap_at_k), timed on a bounded sample.  Also the metric kernel alone
+    against its 8L + 4|ks| bytes per query."""
+    import ptranking_amd as pa
+    from oracle import torch_ref as T
+    ks = list(ks)
+    gen = torch.Generator(device=device).manual_seed(SEED + 31 + rank)
+    base = [synth_batch(gen, B, L, F, device) for _ in range(4)]
+    loader = [(range(B), X, Y) for X, Y in base] * 2
+    nq = B * len(loader)
+    ranker.eval_mode()
+    ranker.ndcg_at_ks(test_data=loader[:2], ks=ks, label_type=pa.LABEL_TYPE.MultiLabel, presort=True)
+    ranker.ap_at_k(test_data=loader[:2], k=10, presort=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nd = ranker.ndcg_at_ks(test_data=loader, ks=ks, label_type=pa.LABEL_TYPE.MultiLabel, presort=True)
+    apk = ranker.ap_at_k(test_data=loader, k=10, presort=True)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    # the metric kernel alone (nDCG at the six cut-offs), 20 launches inside one HIP-event pair on the launch stream
+    preds = torch.randn((B, L), generator=gen, device=device)
+    Y = base[0][1]
+    for _ in range(3):
+        pa.functional.metrics_at_ks(preds, Y, ks, presort=True, which=("ndcg",))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(20):
+        pa.functional.metrics_at_ks(preds, Y, ks, presort=True, which=("ndcg",))
+    e1.record()
+    torch.cuda.synchronize()
+    k_ms = e0.elapsed_time(e1) / 20
+    k_bytes = B * (8 * L + 4 * len(ks))
+    ranker.train_mode()
+    # CPU: the port's loop on a bounded sample (batches of 64 queries, the reference's own evaluation batching is per query length)
+    net = T.build_pointsf(F, seed=SEED)
+    net.eval()
+    Xc, Yc = base[0][0][:64].cpu(), base[0][1][:64].cpu()
+    done, t0 = 0, time.perf_counter()
+    with torch.no_grad():
+        while True:
+            p = net(Xc).view(64, L)
+            _, idx = T.sort_desc(p)
+            sys_sorted = torch.gather(Yc, 1, idx)
+            T.ndcg_at_ks(sys_sorted, Yc, ks)
+            T.ap_at_ks(sys_sorted, Yc, [10])
+            done += 64
+            cel = time.perf_counter() - t0
+            if cel >= cpu_seconds:
+                break
+    del base, loader
+    return {"value": nq / el, "unit": "queries/s", "queries": nq, "seconds": el, "ks": ks, "list_len": L,
+            "what": "DeviceEvaluator.ndcg_at_ks(ks) + ap_at_k(10) over a loader of 8 x B device-resident batches (eval-mode scorer forward + ptr_metrics_at_ks per batch and call)",
+            "ndcg_at_ks": [float(v) for v in nd], "ap_at_10": float(apk[0]),
+            "metrics_kernel": {"bound": "hbm", "avg_launch_ms": k_ms, "algorithmic_bytes_per_launch": k_bytes, "achieved": k_bytes / (k_ms * 1e-3) / 1e9,
+                               "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": k_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                               "note": "ptr_metrics_at_ks entry (nDCG only) at B x L, 8L + 4|ks| bytes per query"},
+            "cpu_port": {"value": done / cel, "unit": "queries/s", "kind": "port", "reference_on_box": False, "threads": torch.get_num_threads(),
+                         "sample": f"{done} queries in {cel:.1f} s: torch-CPU scorer forward + sort + gather + nDCG@ks + AP@10 on batches of 64 queries"}}
 
 
 PMC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")
@@ -211,6 +292,9 @@ def main():
     ap.add_argument("--scorer", default="pointsf", choices=["pointsf", "pointsf_default", "listsf"],
                     help="listsf = BASELINE.json config 5: 2-head / 6-layer DASALC encoder (fused MFMA attention), use with --loss LambdaLoss "
                          "--list-len 256 --batch 1024")
+    ap.add_argument("--extras", default="auto", choices=["auto", "on", "off"],
+                    help="SURVEY 8(d)'s further measurements in the same JSON line: the padded variant, the metric path (DeviceEvaluator vs the "
+                         "port's CPU loop) and a short window of BASELINE configs 1 / 3 / 4 / 5 (auto: headline workload on one GPU)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="N = 1 only: initialise a one-rank RCCL process group and run the data-parallel step through it (backward -> "
                          "all-reduce -> optimiser step instead of the fused single-device step); what a 1-GPU box can execute of the RCCL path")
@@ -263,23 +347,24 @@ def main():
     B, L, F = args.batch, args.list_len, args.features
     headline = (args.loss, L, F, args.scorer) == ("LambdaRank", 128, 136, "pointsf")
 
-    def build_ranker():
+    def build_ranker(loss=None, scorer=None, F=F):
+        loss, scorer = loss or args.loss, scorer or args.scorer
         torch.manual_seed(SEED)                       # identical initial weights on every rank
-        cls = getattr(pa, args.loss)
-        if args.scorer == "listsf":      # ptranking/ltr_adhoc/eval/parameter.py:152-166 defaults
+        cls = getattr(pa, loss)
+        if scorer == "listsf":      # ptranking/ltr_adhoc/eval/parameter.py:152-166 defaults
             sfd = {"sf_id": "listsf", "opt": "Adagrad", "lr": 1e-3,
                    "listsf": dict(num_features=F, ff_dims=[128, 256, 512], AF="R", TL_AF="GE", apply_tl_af=False, BN=False, bn_type="BN2",
                                   bn_affine=False, n_heads=2, encoder_layers=6, encoder_type="DASALC")}
-        elif args.scorer == "pointsf_default":      # the driver's default scoring function, parameter.py:145-146
+        elif scorer == "pointsf_default":      # the driver's default scoring function, parameter.py:145-146
             sfd = {"sf_id": "pointsf", "opt": "Adam", "lr": 1e-3,
                    "pointsf": dict(num_features=F, num_layers=5, AF="GE", TL_AF="S", apply_tl_af=True, BN=True, bn_type="BN", bn_affine=True)}
         else:
             sfd = sf_para_dict(F)
-        if args.loss == "ListNet":
+        if loss == "ListNet":
             r = cls(sf_para_dict=sfd, gpu=True, device=device)
         else:
-            r = cls(sf_para_dict=sfd, model_para_dict=dict(pa.DEFAULT_PARAS[args.loss]), gpu=True, device=device)
-        if args.loss == "ListMLE":
+            r = cls(sf_para_dict=sfd, model_para_dict=dict(pa.DEFAULT_PARAS[loss]), gpu=True, device=device)
+        if loss == "ListMLE":
             assert r.tie_shuffle == "device"     # the product default (the reference's B host-side randperm calls per step would dominate)
         r.init()
         r.train_mode()                           # dropout 0.1 active, exactly like the reference's train()
@@ -292,11 +377,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(ranker, Bq, steps, warmup, prewarm_rounds):
+    def measure(ranker, Bq, steps, warmup, prewarm_rounds, L=L, F=F, nbatches=None, padded=False, prewarm_steps=20):
         """Times `steps` train steps at Bq queries per GPU.  Returns (seconds [max over ranks], per-entry-point event timings,
-        all-reduce event timings, final accumulated loss)."""
+        all-reduce event timings, final accumulated loss).  padded: every query gets an MSLR-like number of real documents
+        (padded_lens) and the step runs with `lens`, the way PaddedQueryBatches feeds it."""
         gen = torch.Generator(device=device).manual_seed(SEED + 1000 * rank + Bq)   # every rank owns different queries
-        batches = [synth_batch(gen, Bq, L, F, device) for _ in range(max(1, args.nbatches))]
+        batches = [synth_batch(gen, Bq, L, F, device) + (None,) for _ in range(max(1, nbatches or args.nbatches))]
+        if padded:
+            batches = [pad_batch(gen, X, Y, L) for X, Y, _ in batches]
+            measure.mean_len = float(torch.cat([b[2] for b in batches]).float().mean().item())
 
         def run_steps(n, hooks=None):
             """n train steps, accumulating the loss on the device exactly like DeviceTrainLoop.train does (no host sync).
@@ -304,11 +393,14 @@ def main():
             step (two events per call are not free: at 64 queries per step they would be a fifth of the step)."""
             acc = torch.zeros((), device=device)
             for i in range(n):
-                X, Y = batches[i % len(batches)]
+                X, Y, ln = batches[i % len(batches)]
                 on = hooks is not None and i % EVENT_EVERY == 0
                 if on:
                     _lib.TIMING, dp.TIMING = hooks
-                loss, _ = ranker.train_op(X, Y, epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
+                if ln is None:
+                    loss, _ = ranker.train_op(X, Y, epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
+                else:
+                    loss, _ = ranker.train_op(X, Y, epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel, lens=ln)
                 if on:
                     _lib.TIMING, dp.TIMING = None, None
                 acc += loss.detach()
@@ -321,7 +413,7 @@ def main():
         gc.collect()
         gc.disable()                      # no collector pauses inside the timed region
         for _ in range(prewarm_rounds):   # a FIXED count: every rank must issue the same number of all-reduces
-            float(run_steps(20, ({}, [])).item())
+            float(run_steps(prewarm_steps, ({}, [])).item())
         run_steps(warmup)
         sync()
         timing, ar_timing = {}, []
@@ -361,6 +453,35 @@ def main():
             el, _, _, _ = measure(ranker, bq, args.sweep_steps, args.warmup, 1)
             by_batch[str(bq)] = {"queries_per_s_per_gpu": bq * args.sweep_steps / el, "ms_per_step": 1e3 * el / args.sweep_steps,
                                  "steps": args.sweep_steps, "is_value": False}
+
+    # ---- SURVEY 8(d)'s further measurements, in the same line
+    extras = {}
+    if world == 1 and args.scorer == "pointsf" and (args.extras == "on" or (args.extras == "auto" and headline and B >= 1024)):
+        # (i) the padded variant: the same step on lists of MSLR-like lengths padded to L, through `lens` (what PaddedQueryBatches feeds)
+        el, _, _, _ = measure(ranker, B, args.sweep_steps, args.warmup, 1, padded=True)
+        extras["padded"] = {"value": B * args.sweep_steps / el, "unit": "queries/s", "ms_per_step": 1e3 * el / args.sweep_steps,
+                            "mean_len": measure.mean_len, "padded_len": L, "documents_per_s": B * measure.mean_len * args.sweep_steps / el,
+                            "steps": args.sweep_steps,
+                            "note": "lens ~ Gamma(2.2) with mean 120 clipped to [1, list_len] (MSLR-WEB30K: 1..1251 documents, mean ~120); the scorer "
+                                    "runs on all padded rows, the loss kernel skips padded documents"}
+        # (ii) the metric path: Evaluator.ndcg_at_ks + ap_at_k (ptranking/base/ranker.py:67-95,130-160) over a synthetic loader, device-resident
+        # (predict -> metrics kernel, nothing leaves the GPU but [len(ks)] numbers) vs the port's CPU loop (predict -> sort -> gather -> metric)
+        extras["metric_path"] = metric_path(ranker, B, L, F, device, rank)
+        # (iii) BASELINE.json configs 1, 3, 4, 5: one short window each (10 steps) so that the driver's record carries them
+        cfgs = [("C1_ranknet_L32", "RankNet", "pointsf", 32, 136, 4096), ("C3_listnet_L256", "ListNet", "pointsf", 256, 136, 4096),
+                ("C3_listmle_L256", "ListMLE", "pointsf", 256, 136, 4096), ("C4_approxndcg_L512_F700", "ApproxNDCG", "pointsf", 512, 700, 1024),
+                ("C5_listsf_lambdaloss_L256", "LambdaLoss", "listsf", 256, 136, 1024)]
+        extras["configs"] = {}
+        del ranker
+        for tag, loss_c, scorer_c, Lc, Fc, Bc in cfgs:
+            Bc = min(Bc, B)
+            torch.cuda.empty_cache()
+            rc = build_ranker(loss_c, scorer_c, F=Fc)
+            el, _, _, _ = measure(rc, Bc, 10, 2, 1, L=Lc, F=Fc, nbatches=2, prewarm_steps=6)
+            extras["configs"][tag] = {"value": Bc * 10 / el, "unit": "queries/s", "ms_per_step": 1e3 * el / 10, "steps": 10, "loss": loss_c,
+                                      "scorer": scorer_c, "list_len": Lc, "features": Fc, "queries_per_step": Bc}
+            del rc
+        torch.cuda.empty_cache()
 
     # the loss kernel alone, at the headline list length and at the north-star's stated one (BASELINE.json: list_len=256), same
     # number of queries: 40 launches of the C entry back to back (no loss_out: the kernel only, no slot sum) inside ONE HIP-event
@@ -574,6 +695,7 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
             "by_batch": by_batch,
+            **extras,
             "windows": windows,
             "final_epoch_loss": final_loss,
             "pmc_traffic_source": pmc_source,

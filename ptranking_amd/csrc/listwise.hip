@@ -5,6 +5,7 @@
 // Reference: ptranking/ltr_adhoc/listwise/listnet.py:39; ptranking/ltr_adhoc/listwise/listmle.py:82,92-97;
 //            ptranking/ltr_adhoc/util/sampling_utils.py:13-28 (arg_shuffle_ties).
 #include "ptr_device.h"
+#include "ptr_dropout.h"          // f32x4
 
 namespace ptr {
 
@@ -64,6 +65,116 @@ listnet_kernel(const float *__restrict__ preds, const float *__restrict__ labels
     float *g = grad + (size_t)q * L;
     for (int i = lane; i < L; i += 64) g[i] = i < n ? (expf(s[i]) * sumpy - y[i]) * inv_temp : 0.0f;   // log_softmax backward
     if (lane == 0) loss_q[q] = loss;
+}
+
+// r5: the same ListNet out of REGISTERS for 16-byte aligned rows (L % 4 == 0) up to 1024 documents.  G = 16 / 32 / 64 lanes own one query
+// (4 / 2 / 1 queries per wavefront), a lane owns the float4 chunks t, t + G, ...: one global_load_dwordx4 per operand and chunk, one
+// global_store_dwordx4 of the gradient — no LDS round trip (the LDS kernel staged values only the writing lane ever re-read), no scalar
+// 4-byte accesses.  Arithmetic on the transcendental pipe where the 1e-5 bar allows (the ring kernel's policy): e^x = v_exp_f32(x log2 e)
+// on arguments <= 0, ln by v_log_f32, 1/z once per query by an IEEE division and a multiply per element; softmax(preds) in the backward
+// is e^{s - m} / z from the forward's own exponentials (the reference re-evaluates exp(log_softmax), listnet.py:39 through autograd).
+// Group reductions are xor butterflies inside the G lanes (DPP / ds_swizzle / ds_bpermute, lane_xor<>): every lane ends with the
+// bit-identical sum, fixed order.
+template <int G, class Op> __device__ __forceinline__ float group_butterfly(float v, int lane, Op op) {
+    v = op(v, lane_xor<1>(v, lane));
+    v = op(v, lane_xor<2>(v, lane));
+    v = op(v, lane_xor<4>(v, lane));
+    v = op(v, lane_xor<8>(v, lane));
+    if constexpr (G >= 32) v = op(v, lane_xor<16>(v, lane));
+    if constexpr (G >= 64) v = op(v, lane_xor<32>(v, lane));
+    return v;
+}
+template <int G, int V>
+__global__ void __launch_bounds__(kBlock)
+listnet_vec_kernel(const float *__restrict__ preds, const float *__restrict__ labels, const int32_t *__restrict__ lens, int B, int L,
+                   float *__restrict__ loss_q, float *__restrict__ grad) {
+    constexpr int QW = kWave / G;                                   // queries per wavefront
+    const int lane = threadIdx.x & 63, t = lane & (G - 1);
+    const int q = (blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) * QW + lane / G;
+    const bool valid = q < B;
+    const int qc = valid ? q : B - 1;                               // lanes past the batch recompute the last query and store nothing
+    const int n = query_len(lens, qc, L);
+    const f32x4 *ps = reinterpret_cast<const f32x4 *>(preds + (size_t)qc * L), *py = reinterpret_cast<const f32x4 *>(labels + (size_t)qc * L);
+    const int L4 = L >> 2;
+    f32x4 a[V], b[V];
+#pragma unroll
+    for (int m = 0; m < V; ++m) {
+        const int c = t + m * G;
+        const int cc = c < L4 ? c : 0;                              // chunks past the row: re-read chunk 0, masked below
+        a[m] = ps[cc]; b[m] = py[cc];
+    }
+    const auto fmax2 = [](float x, float y) { return fmaxf(x, y); };
+    const auto fadd2 = [](float x, float y) { return x + y; };
+    float ms = -INFINITY, my = -INFINITY;
+#pragma unroll
+    for (int m = 0; m < V; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool in = 4 * (t + m * G) + e < n;
+            a[m][e] = in ? a[m][e] : -INFINITY;                     // e^{-inf} = 0: padding leaves every sum
+            b[m][e] = in ? b[m][e] : -INFINITY;
+            ms = fmaxf(ms, a[m][e]); my = fmaxf(my, b[m][e]);
+        }
+    ms = group_butterfly<G>(ms, lane, fmax2); my = group_butterfly<G>(my, lane, fmax2);
+    constexpr float kLog2e = 1.4426950408889634f;
+    float zs = 0.0f, zy = 0.0f;
+#pragma unroll
+    for (int m = 0; m < V; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a[m][e] -= ms;                                          // s - max (kept: log_softmax = (s - max) - ln z); -inf for padding (n > 0)
+            const float ea = __builtin_amdgcn_exp2f(a[m][e] * kLog2e), eb = __builtin_amdgcn_exp2f((b[m][e] - my) * kLog2e);
+            b[m][e] = eb;
+            zs += ea; zy += eb;
+        }
+    zs = group_butterfly<G>(zs, lane, fadd2); zy = group_butterfly<G>(zy, lane, fadd2);
+    const float lzs = fast_ln(zs), rzs = 1.0f / zs, rzy = 1.0f / zy;
+    float loss = 0.0f, sumpy = 0.0f;
+#pragma unroll
+    for (int m = 0; m < V; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool in = 4 * (t + m * G) + e < n;
+            const float pyv = b[m][e] * rzy;                        // softmax(labels)
+            const float lsm = a[m][e] - lzs;                        // log_softmax(preds)
+            loss -= in ? pyv * lsm : 0.0f;                          // (0 * -inf on padding otherwise)
+            sumpy += pyv;
+            b[m][e] = pyv;
+        }
+    loss = group_butterfly<G>(loss, lane, fadd2); sumpy = group_butterfly<G>(sumpy, lane, fadd2);
+    f32x4 *g = reinterpret_cast<f32x4 *>(grad + (size_t)qc * L);
+#pragma unroll
+    for (int m = 0; m < V; ++m) {
+        const int c = t + m * G;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float sm = __builtin_amdgcn_exp2f(a[m][e] * kLog2e) * rzs;       // softmax(preds); 0 on padding
+            o[e] = 4 * c + e < n ? sm * sumpy - b[m][e] : 0.0f;
+        }
+        if (valid && c < L4) g[c] = o;
+    }
+    if (valid && t == 0) loss_q[q] = n > 0 ? loss : 0.0f;
+}
+
+// true when the register kernel serves the batch; launches it
+static int launch_listnet_vec(const float *preds, const float *labels, const int32_t *lens, int B, int L, float *loss_q, float *grad,
+                              hipStream_t st, bool *served) {
+    *served = false;
+    static const bool off = [] { const char *e = getenv("PTR_LISTNET_VEC"); return e && atoi(e) == 0; }();
+    if (off || L % 4 != 0 || L > 1024) return 0;
+    if ((reinterpret_cast<uintptr_t>(preds) | reinterpret_cast<uintptr_t>(labels) | reinterpret_cast<uintptr_t>(grad)) & 15) return 0;
+    *served = true;
+    auto go = [&]<int G, int V>() -> int {
+        constexpr int QPB = (kBlock / kWave) * (kWave / G);
+        hipLaunchKernelGGL((listnet_vec_kernel<G, V>), dim3((B + QPB - 1) / QPB), dim3(kBlock), 0, st, preds, labels, lens, B, L, loss_q, grad);
+        return check_hip(hipGetLastError(), "ptr_listnet_fwd_bwd");
+    };
+    if (L <= 64) return go.template operator()<16, 1>();
+    if (L <= 128) return go.template operator()<32, 1>();
+    if (L <= 256) return go.template operator()<64, 1>();
+    if (L <= 512) return go.template operator()<64, 2>();
+    return go.template operator()<64, 4>();
 }
 
 // ------------------------------------------------------------------------------------------------ ListMLE
@@ -126,6 +237,128 @@ listmle_kernel(const float *__restrict__ preds, const int64_t *__restrict__ perm
     float *g = grad + (size_t)q * L;
     for (int i = lane; i < L; i += 64) g[i] = i < n ? s[i] : 0.0f;
     if (lane == 0) loss_q[q] = loss;
+}
+
+// r5: ListMLE with 16-byte accesses and the scans out of registers (L % 4 == 0, L <= 1024; one wavefront per query).  Lane t owns the 4 V
+// CONSECUTIVE positions from 4 V t on: scores by one float4 per 4 positions, the int64 permutation by two dwordx4, the gradient written as
+// float4.  The only LDS traffic left is what the permutation needs: the scores are parked once (ds_write_b128) for the gather u_k = s[pi_k],
+// and the gradient is scattered through the same tile.  Tail sums T_k: sequential inside the lane's positions, then ONE cross-lane suffix
+// scan of the lane totals shifted by a lane (an exclusive scan — inclusive minus own would cancel on the small tails); 1 / T_k prefix sums
+// likewise (DPP).  exp / log on the transcendental pipe while the list's score range is below 24 (argument error <= 24 * 2^-24: 1.4e-6
+// relative), libm otherwise (EXACT: denormal tail sums, ranges up to the fp32 exponent) — decided per wavefront.
+using i64x2 = __attribute__((ext_vector_type(2))) long long;
+__device__ __forceinline__ float dpp_wave_shl1(float v) {      // lane t <- lane t + 1, lane 63 <- 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_wave_shr1(float v) {      // lane t <- lane t - 1, lane 0 <- 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138 /* wave_shr:1 */, 0xF, 0xF, true));
+}
+template <int V, bool EXACT>
+__device__ __forceinline__ void listmle_vec_body(const f32x4 (&a)[V], const int (&pi)[4 * V], int n, int lane, float m, float *S,
+                                                 float &loss_out, f32x4 (&gout)[V]) {
+    constexpr int E = 4 * V;
+    constexpr float kLog2e = 1.4426950408889634f;
+    const int p0 = E * lane;
+    float u[E], e[E], T[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const bool in = p0 + i < n;
+        u[i] = in ? S[pi[i]] : 0.0f;
+        e[i] = in ? (EXACT ? expf(u[i] - m) : __builtin_amdgcn_exp2f((u[i] - m) * kLog2e)) : 0.0f;
+    }
+    float run = 0.0f;
+#pragma unroll
+    for (int i = E - 1; i >= 0; --i) { run += e[i]; T[i] = run; }
+    const float later = dpp_wave_shl1(wave_incl_suffix_sum(run, lane));          // sum over the lanes behind this one
+    float loss = 0.0f, inv[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const bool in = p0 + i < n;
+        T[i] += later;
+        const float lg = EXACT ? logf(T[i]) : fast_ln(T[i]);
+        loss += in ? (lg + m) - u[i] : 0.0f;
+        if constexpr (EXACT) inv[i] = in ? 1.0f / T[i] : 0.0f;
+        else { const float r = __builtin_amdgcn_rcpf(T[i]); inv[i] = in ? fmaf(r, fmaf(-T[i], r, 1.0f), r) : 0.0f; }
+    }
+    loss_out = wave_sum_dpp(loss);
+    run = 0.0f;
+#pragma unroll
+    for (int i = 0; i < E; ++i) { run += inv[i]; inv[i] = run; }
+    const float before = dpp_wave_shr1(wave_incl_sum(run, lane));
+    wave_lds_sync();                                            // every gather of S is done: the tile becomes the gradient
+#pragma unroll
+    for (int i = 0; i < E; ++i)
+        if (p0 + i < n) S[pi[i]] = e[i] * (inv[i] + before) - 1.0f;
+    wave_lds_sync();
+#pragma unroll
+    for (int mm = 0; mm < V; ++mm) {
+        const f32x4 g4 = *reinterpret_cast<const f32x4 *>(S + p0 + 4 * mm);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) gout[mm][c] = p0 + 4 * mm + c < n ? g4[c] : 0.0f;
+    }
+    (void)a;
+}
+template <int V>
+__global__ void __launch_bounds__(kBlock)
+listmle_vec_kernel(const float *__restrict__ preds, const int64_t *__restrict__ perm, const int32_t *__restrict__ lens, int B, int L,
+                   float *__restrict__ loss_q, float *__restrict__ grad) {
+    constexpr int E = 4 * V, LT = kWave * E;                        // positions per lane / per tile
+    __shared__ __attribute__((aligned(16))) float tiles[(kBlock / kWave) * LT];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q = blockIdx.x * (kBlock / kWave) + wv;
+    if (q >= B) return;                                             // waves are independent: no workgroup barrier below
+    const int n = query_len(lens, q, L);
+    float *S = tiles + wv * LT;
+    const int p0 = E * lane;
+    const f32x4 *ps = reinterpret_cast<const f32x4 *>(preds + (size_t)q * L);
+    const i64x2 *pp = reinterpret_cast<const i64x2 *>(perm + (size_t)q * L);
+    f32x4 a[V];
+    i64x2 k2[2 * V];
+#pragma unroll
+    for (int mm = 0; mm < V; ++mm) {
+        const int c = p0 + 4 * mm < L ? (p0 >> 2) + mm : 0;        // chunks past the row re-read chunk 0 (masked by n <= L)
+        a[mm] = ps[c]; k2[2 * mm] = pp[2 * c]; k2[2 * mm + 1] = pp[2 * c + 1];
+    }
+    float mx = -INFINITY, mn = INFINITY;
+    int pi[E];
+#pragma unroll
+    for (int mm = 0; mm < V; ++mm) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = p0 + 4 * mm + c;
+            const bool in = i < n;
+            mx = fmaxf(mx, in ? a[mm][c] : -INFINITY); mn = fminf(mn, in ? a[mm][c] : INFINITY);
+            const long long k = k2[2 * mm + (c >> 1)][c & 1];
+            pi[4 * mm + c] = (k < 0 || k >= n) ? (in ? i : 0) : (int)k;      // malformed input cannot index out of the tile
+        }
+        *reinterpret_cast<f32x4 *>(S + p0 + 4 * mm) = a[mm];
+    }
+    mx = wave_max(mx); mn = -wave_max(-mn);
+    wave_lds_sync();
+    float loss;
+    f32x4 g[V];
+    if (mx - mn < 24.0f) listmle_vec_body<V, false>(a, pi, n, lane, mx, S, loss, g);
+    else listmle_vec_body<V, true>(a, pi, n, lane, mx, S, loss, g);
+    f32x4 *go = reinterpret_cast<f32x4 *>(grad + (size_t)q * L);
+#pragma unroll
+    for (int mm = 0; mm < V; ++mm)
+        if (p0 + 4 * mm < L) go[(p0 >> 2) + mm] = g[mm];
+    if (lane == 0) loss_q[q] = loss;
+}
+static int launch_listmle_vec(const float *preds, const int64_t *perm, const int32_t *lens, int B, int L, float *loss_q, float *grad,
+                              hipStream_t st, bool *served) {
+    *served = false;
+    static const bool off = [] { const char *e = getenv("PTR_LISTMLE_VEC"); return e && atoi(e) == 0; }();
+    if (off || L % 4 != 0 || L > 1024) return 0;
+    if ((reinterpret_cast<uintptr_t>(preds) | reinterpret_cast<uintptr_t>(perm) | reinterpret_cast<uintptr_t>(grad)) & 15) return 0;
+    *served = true;
+    auto go = [&]<int V>() -> int {
+        hipLaunchKernelGGL((listmle_vec_kernel<V>), dim3((B + 3) / 4), dim3(kBlock), 0, st, preds, perm, lens, B, L, loss_q, grad);
+        return check_hip(hipGetLastError(), "ptr_listmle_fwd_bwd");
+    };
+    if (L <= 256) return go.template operator()<1>();
+    if (L <= 512) return go.template operator()<2>();
+    return go.template operator()<4>();
 }
 
 // MDPRank (ptranking/ltr_adhoc/listwise/mdprank.py:24-78): a policy-gradient ListMLE.  pi is a ranking SAMPLED from the
@@ -349,13 +582,17 @@ extern "C" int ptr_listnet_fwd_bwd(const float *preds, const float *labels, cons
     if (int rc = check_batch(preds, labels, B, L, who)) return rc;
     if (B > 0 && (!loss_q || !grad)) { set_error("%s: NULL output pointer", who); return PTR_ERR_INVALID_ARG; }
     if (B > 0) {
-        const int Lp = round_up(L, 4);
-        const size_t per_q = 2 * (size_t)Lp * sizeof(float);
-        const int wpb = waves_per_block(per_q);
-        if (int e = allow_lds(listnet_kernel, wpb * per_q)) return e;
-        hipLaunchKernelGGL(listnet_kernel, dim3((B + wpb - 1) / wpb), dim3(wpb * kWave), wpb * per_q, as_stream(stream), preds, labels,
-                           (const float *)nullptr, lens, B, L, Lp, 1.0f, loss_q, grad);
-        if (int rc = check_hip(hipGetLastError(), who)) return rc;
+        bool served = false;
+        if (int rc = launch_listnet_vec(preds, labels, lens, B, L, loss_q, grad, as_stream(stream), &served)) return rc;
+        if (!served) {                                        // unaligned rows, L % 4 != 0, L > 1024: the LDS kernel
+            const int Lp = round_up(L, 4);
+            const size_t per_q = 2 * (size_t)Lp * sizeof(float);
+            const int wpb = waves_per_block(per_q);
+            if (int e = allow_lds(listnet_kernel, wpb * per_q)) return e;
+            hipLaunchKernelGGL(listnet_kernel, dim3((B + wpb - 1) / wpb), dim3(wpb * kWave), wpb * per_q, as_stream(stream), preds, labels,
+                               (const float *)nullptr, lens, B, L, Lp, 1.0f, loss_q, grad);
+            if (int rc = check_hip(hipGetLastError(), who)) return rc;
+        }
     }
     return loss_out ? ptr_sum_f32(loss_q, B, 1.0f, loss_out, stream) : 0;
 }
@@ -413,13 +650,17 @@ extern "C" int ptr_listmle_fwd_bwd(const float *preds, const int64_t *perm, cons
     if (int rc = check_batch(preds, perm, B, L, who)) return rc;
     if (B > 0 && (!loss_q || !grad)) { set_error("%s: NULL output pointer", who); return PTR_ERR_INVALID_ARG; }
     if (B > 0) {
-        const int Lp = round_up(L, 4);
-        const size_t per_q = 4 * (size_t)Lp * sizeof(float);
-        const int wpb = waves_per_block(per_q);
-        if (int e = allow_lds(listmle_kernel, wpb * per_q)) return e;
-        hipLaunchKernelGGL(listmle_kernel, dim3((B + wpb - 1) / wpb), dim3(wpb * kWave), wpb * per_q, as_stream(stream), preds, perm,
-                           lens, B, L, Lp, loss_q, grad);
-        if (int rc = check_hip(hipGetLastError(), who)) return rc;
+        bool served = false;
+        if (int rc = launch_listmle_vec(preds, perm, lens, B, L, loss_q, grad, as_stream(stream), &served)) return rc;
+        if (!served) {                                        // unaligned rows, L % 4 != 0, L > 1024: the LDS kernel
+            const int Lp = round_up(L, 4);
+            const size_t per_q = 4 * (size_t)Lp * sizeof(float);
+            const int wpb = waves_per_block(per_q);
+            if (int e = allow_lds(listmle_kernel, wpb * per_q)) return e;
+            hipLaunchKernelGGL(listmle_kernel, dim3((B + wpb - 1) / wpb), dim3(wpb * kWave), wpb * per_q, as_stream(stream), preds, perm,
+                               lens, B, L, Lp, loss_q, grad);
+            if (int rc = check_hip(hipGetLastError(), who)) return rc;
+        }
     }
     return loss_out ? ptr_sum_f32(loss_q, B, 1.0f, loss_out, stream) : 0;
 }

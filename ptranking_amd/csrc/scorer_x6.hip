@@ -255,8 +255,10 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
     // bias / w_out rows: ONE opaque base register each + immediate offsets (past the 64 KB `ds` offset range hipcc otherwise keeps a
     // loop-invariant address register per (tile) and spills them)
     using lds_f32x4 = __attribute__((address_space(3))) f32x4;
-    uint32_t bs_base = x6_lds_addr(Bs) + (uint32_t)g * 16, wo_base = x6_lds_addr(Wo) + (uint32_t)g * 16;
-    asm volatile("" : "+v"(bs_base), "+v"(wo_base));
+    uint32_t bs_base = x6_lds_addr(Bs) + (uint32_t)g * 16;
+    asm volatile("" : "+v"(bs_base));
+    uint32_t wo_delta = (uint32_t)NL * (kHP * 4);                // Wo = Bs + NL * 112 floats: a scalar added at the (seven) uses instead of a second register
+    asm volatile("" : "+s"(wo_delta));
     auto lds4 = [](uint32_t base, int byte_off) __attribute__((always_inline)) { return *reinterpret_cast<lds_f32x4 *>((uintptr_t)(base + (uint32_t)byte_off)); };
     const uint32_t layer_bytes = (uint32_t)R * (kAL * 4);                       // host: NL * R * 448 < 2^32 - 4096
     const x6_rsrc xsrd = x6_srd(const_cast<float *>(X), (uint32_t)R * (uint32_t)(F * 4));     // host: R * F * 4 < 2^32 - 4096
@@ -334,14 +336,22 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
     uint32_t jH = (uint32_t)j * kDropRowMul + (uint32_t)g * kDropFgMul + a.seed_lo, jK = jH + (uint32_t)g * kDropFgMul;
     asm volatile("" : "+v"(jX), "+v"(jA), "+v"(jH), "+v"(jK));
     // quarter q = (dt, h) of slice s of the 32 documents from row t32 on: the float4 a lane contributes to the B fragment.  X is read through
-    // a buffer resource: rows past R get an out-of-range offset (zeros); columns past F read the next row — finite numbers that meet
-    // zero weight planes
+    // a buffer resource: rows past R and columns past F get an out-of-range offset (zeros)
     auto load_xq = [&](f32x4 (&rw)[DT][2], int t32, int s, int q) __attribute__((always_inline)) {
         const int dt = q >> 1, h = q & 1;
 #ifdef PTR_X6_NOX
         const uint32_t vo = jX, so = (uint32_t)((t32 + 16 * dt) & 1023) * (uint32_t)(F * 4);
 #else
-        const uint32_t vo = j < R - t32 - 16 * dt ? jX : kX6Oob, so = (uint32_t)(t32 + 16 * dt) * (uint32_t)(F * 4);
+        // columns past F (the last slice when F % 32 != 0) are out of range like the rows past R: they read zeros, NOT the next row's first
+        // features — a NaN / Inf there would reach this row's products as 0 * Inf
+        // (the column test on the SCALAR unit: lane groups g < ng hold columns below F — a 64-bit lane mask ANDed with the row test's,
+        // one v_cndmask; a per-lane compare costs a register the training kernel does not have)
+        const int left = F * 4 - 128 * s - 16 * h;                                     // bytes of the row from this quarter's column of group 0 on
+        const int ng = left <= 0 ? 0 : (left + 31) >> 5;                               // lane groups with a column below F
+        const uint64_t cmask = ng >= 4 ? ~0ull : ((1ull << (16 * ng)) - 1ull);
+        const uint64_t m = __builtin_amdgcn_ballot_w64(j < R - t32 - 16 * dt) & cmask;
+        const uint32_t vo = __builtin_amdgcn_inverse_ballot_w64(m) ? jX : kX6Oob;
+        const uint32_t so = (uint32_t)(t32 + 16 * dt) * (uint32_t)(F * 4);
 #endif
         rw[dt][h] = x6_load16(xsrd, vo, so + (uint32_t)(128 * s + 16 * h));
     };
@@ -438,7 +448,7 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
         for (int dt = 0; dt < DT; ++dt) sc[dt] = 0.0f;
         auto epilogue_out = [&](auto mt_) __attribute__((always_inline)) {
             constexpr int mt = decltype(mt_)::value;
-            const f32x4 w4 = lds4(wo_base, 64 * mt);
+            const f32x4 w4 = lds4(bs_base + wo_delta, 64 * mt);
             const f32x4 bn = lds4(bs_base, 64 * mt);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {

@@ -27,7 +27,8 @@ def test_bench_cli_and_cpu_baseline_helpers():
 def test_bench_prints_one_contract_json_line():
     env = dict(os.environ)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--batch", "256",
-                          "--sweep", "64", "--cpu-seconds", "0.5"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+                          "--sweep", "64", "--sweep-steps", "6", "--cpu-seconds", "0.5", "--extras", "on"], capture_output=True, text=True, timeout=900,
+                         env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
@@ -45,6 +46,27 @@ def test_bench_prints_one_contract_json_line():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert "64" in d["by_batch"] and d["by_batch"]["64"]["queries_per_s_per_gpu"] > 0
+    assert cb["kind"] == "port" and cb["reference_on_box"] is False
+    # SURVEY 8(d)'s further measurements ride in the same line: padded variant, metric path, BASELINE configs 1 / 3 / 4 / 5
+    pd = d["padded"]
+    assert pd["value"] > 0 and pd["ms_per_step"] > 0 and 1.0 <= pd["mean_len"] <= 128.0 and pd["padded_len"] == 128
+    mp = d["metric_path"]
+    assert mp["value"] > 0 and mp["cpu_port"]["value"] > 0 and mp["cpu_port"]["reference_on_box"] is False
+    assert len(mp["ndcg_at_ks"]) == len(mp["ks"]) and all(0.0 <= v <= 1.0 for v in mp["ndcg_at_ks"]) and 0.0 <= mp["ap_at_10"] <= 1.0
+    mk = mp["metrics_kernel"]
+    assert mk["bound"] == "hbm" and 0.0 < mk["frac"] <= 1.0 and abs(mk["frac"] - mk["achieved"] / mk["peak"]) < 1e-9
+    assert set(d["configs"]) == {"C1_ranknet_L32", "C3_listnet_L256", "C3_listmle_L256", "C4_approxndcg_L512_F700", "C5_listsf_lambdaloss_L256"}
+    for c in d["configs"].values():
+        assert c["value"] > 0 and c["ms_per_step"] > 0 and c["steps"] == 10
+
+    def fracs(o):                         # every roofline fraction in the line is a fraction: a "bound" below the achieved rate is not a bound
+        if isinstance(o, dict):
+            for k, v in o.items():
+                if k == "frac":
+                    yield v
+                else:
+                    yield from fracs(v)
+    assert all(0.0 <= f <= 1.0 for f in fracs(d)), list(fracs(d))
 
 
 def test_pmc_traffic_is_refused_when_stale(tmp_path, monkeypatch):

@@ -73,6 +73,54 @@ def test_golden_approxndcg(F, name):
     G.assert_close(grad, c["grad"], "grad")
 
 
+# The saturation band (tests/golden/losses_knife.npz) through the kernel forms the default dispatch does not pick for these list lengths: the
+# LDS LambdaRank / ApproxNDCG kernels behind PTR_LAMBDARANK_RING=0 / PTR_APPROX_RING=0 (the switches are read per call), and the knife lists
+# padded to L = 40 / 300 with `lens`, which moves RankNet off its two-queries-per-wavefront form and LambdaRank onto the LDS kernel (L > 256).
+@pytest.mark.parametrize("name", [n for n in G.case_ids("lambdarank") if n.startswith("knife")])
+def test_knife_lambdarank_other_kernel_forms(F, name, monkeypatch):
+    c = G.losses()["lambdarank"][name]
+    monkeypatch.setenv("PTR_LAMBDARANK_RING", "0")
+    loss, grad = loss_and_grad(F.lambdarank_loss, c["preds"], dev(c["labels"]), sigma=float(c["sigma"]))
+    G.assert_close(loss, c["loss"], "loss (LDS kernel)")
+    G.assert_close(grad, c["grad"], "grad (LDS kernel)")
+    monkeypatch.delenv("PTR_LAMBDARANK_RING")
+    B, L = c["preds"].shape
+    for Lp in (40, 300):
+        if Lp <= L:
+            continue
+        P = np.zeros((B, Lp), np.float32); Y = np.zeros((B, Lp), np.float32)
+        P[:, :L] = c["preds"]; Y[:, :L] = c["labels"]; P[:, L:] = 7.0          # padding scores must not matter
+        lens = torch.full((B,), L, dtype=torch.int32, device="cuda")
+        loss, grad = loss_and_grad(F.lambdarank_loss, P, dev(Y), sigma=float(c["sigma"]), lens=lens)
+        G.assert_close(loss, c["loss"], f"loss (padded to {Lp})")
+        G.assert_close(grad[:, :L], c["grad"], f"grad (padded to {Lp})")
+        assert not grad[:, L:].any()
+
+
+@pytest.mark.parametrize("name", [n for n in G.case_ids("ranknet") if n.startswith("knife")])
+def test_knife_ranknet_unpacked_form(F, name):
+    c = G.losses()["ranknet"][name]
+    B, L = c["preds"].shape
+    for Lp in (40, 300):
+        if Lp <= L:
+            continue
+        P = np.zeros((B, Lp), np.float32); Y = np.zeros((B, Lp), np.float32)
+        P[:, :L] = c["preds"]; Y[:, :L] = c["labels"]; P[:, L:] = -3.0
+        lens = torch.full((B,), L, dtype=torch.int32, device="cuda")
+        loss, grad = loss_and_grad(F.ranknet_loss, P, dev(Y), sigma=float(c["sigma"]), lens=lens)
+        G.assert_close(loss, c["loss"], f"loss (padded to {Lp})")
+        G.assert_close(grad[:, :L], c["grad"], f"grad (padded to {Lp})")
+
+
+@pytest.mark.parametrize("name", [n for n in G.case_ids("approxndcg") if n.startswith("knife")])
+def test_knife_approxndcg_lds_kernel(F, name, monkeypatch):
+    c = G.losses()["approxndcg"][name]
+    monkeypatch.setenv("PTR_APPROX_RING", "0")
+    loss, grad = loss_and_grad(F.approxndcg_loss, c["preds"], dev(c["labels"]), alpha=float(c["alpha"]), presort=True)
+    G.assert_close(loss, c["loss"], "loss (LDS kernel)")
+    G.assert_close(grad, c["grad"], "grad (LDS kernel)")
+
+
 @pytest.mark.parametrize("name", G.case_ids("listnet"))
 def test_golden_listnet(F, name):
     c = G.losses()["listnet"][name]
@@ -214,11 +262,16 @@ def test_oracle_lambdaloss_approx(F, B, L, use_lens):
             G.assert_close(grad, g, f"approxndcg couple={couple} grad")
 
 
-@pytest.mark.parametrize("B,L", [(5, 3), (40, 64), (33, 256), (8, 700), (3, 4096)])
+# (L = 64 / 128 / 256 / 512 / 700: the register kernels' lane groupings G = 16 / 32 / 64 and 1 / 2 / 4 float4 per lane; 3, 30 (L % 4 != 0)
+# and 4096 take the LDS kernels; `scale` = 10 / 12 spreads the scores past the range of 24 behind which ListMLE switches to its libm form; far beyond that the reference
+# itself returns log(0) = -inf)
+@pytest.mark.parametrize("B,L,scale", [(5, 3, 1.0), (7, 30, 1.0), (40, 64, 1.0), (21, 128, 1.0), (33, 256, 1.0), (9, 512, 1.0), (8, 700, 1.0),
+                                       (3, 4096, 1.0), (6, 256, 12.0), (5, 64, 10.0)])
 @pytest.mark.parametrize("use_lens", [False, True])
-def test_oracle_listwise(F, B, L, use_lens):
+def test_oracle_listwise(F, B, L, scale, use_lens):
     from oracle import c_oracle as CO
     preds, labels, ln = synth(3000 + L, B, L, lens=use_lens)
+    preds = (preds * np.float32(scale)).astype(np.float32)
     lens_t = None if ln is None else dev(ln)
     loss, grad = loss_and_grad(F.listnet_loss, preds, dev(labels), lens=lens_t)
     lq, g = CO.listnet(preds, labels, lens=ln)
