@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PTR_ABI_VERSION 3
+#define PTR_ABI_VERSION 4
 #define PTR_MAX_LIST_LEN 4096
 #define PTR_MAX_CUTOFFS 32
 #define PTR_MLP_ACT_LD 112
@@ -177,6 +177,12 @@ int ptr_mlp_backward_step(const float *X, float *params, const float *acts, cons
                           uint64_t seed, float *dz, float *ws, float *grad, int opt_kind, float lr, float hyper1, float hyper2, float eps,
                           float weight_decay, int step, float *state1, float *state2, const float *loss_q, int nq, float *loss_out,
                           void *stream);
+/* ABI v4.  The optimiser step of ptr_mlp_backward_step and its loss-slot sum as ONE launch on a gradient that is already complete — the
+ * data-parallel step: ptr_mlp_backward -> RCCL all-reduce of `grad` -> this (no reference counterpart: ptranking is single-device,
+ * ptranking/ltr_adhoc/eval/ltr.py:44-48; the step itself is ptranking/base/ranker.py:512-525 + the loss accumulation of :589-603).  Same
+ * arithmetic as ptr_mlp_backward_step, bit for bit.  loss_out (optional) = sum of the nq loss slots. */
+int ptr_opt_step_loss(float *params, const float *grad, int64_t n, int opt_kind, float lr, float hyper1, float hyper2, float eps,
+                      float weight_decay, int step, float *state1, float *state2, const float *loss_q, int nq, float *loss_out, void *stream);
 /* torch.optim.Adam step (L2 weight decay added to the gradient, bias correction with `step` >= 1) on flat buffers. */
 int ptr_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, void *stream);

@@ -17,6 +17,6 @@ from . import letor                                   # noqa: F401
 from .host import LABEL_TYPE, DeviceEvaluator       # noqa: F401
 from .install import install, uninstall             # noqa: F401
 from .rankers import (ApproxNDCG, LambdaLoss, LambdaRank, ListMLE, ListNet, RankNet, STListNet, RankCosine, RankMSE, SoftRank, DASALC, MDPRank,  # noqa: F401
-                      DEFAULT_PARAS, RANKER_NAMES, make_ranker_classes)
+                      DEFAULT_PARAS, EXTRA_RANKER_NAMES, RANKER_NAMES, make_ranker_classes)
 
 __version__ = "0.1.0"

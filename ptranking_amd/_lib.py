@@ -11,7 +11,7 @@ import torch  # noqa: F401  — must be imported first so that OUR .so binds to 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PTR_LIB") or os.path.join(_PKG, "libptranking_amd.so")   # PTR_LIB: an experiment build (build.py --variant)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_LIST_LEN = 4096
 MAX_CUTOFFS = 32
 
@@ -42,6 +42,7 @@ SIGNATURES = {
     "ptr_mlp_forward": [_vp, _vp, _i, _i, _i, _i, _f, _u64, _vp, _vp, _vp],
     "ptr_mlp_backward": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _vp, _vp, _vp, _vp],
     "ptr_mlp_backward_step": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _i, _vp, _vp, _vp, _i, _vp, _vp],
+    "ptr_opt_step_loss": [_vp, _vp, C.c_int64, _i, _f, _f, _f, _f, _f, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "ptr_mlp_x6_ws_bytes": [_i, _i],
     "ptr_mlp_forward_x6": [_vp, _vp, _i, _i, _i, _i, _f, _u64, _vp, _vp, _vp, _vp],
     "ptr_adam_step": [_vp, _vp, _vp, _vp, C.c_int64, _f, _f, _f, _f, _f, _i, _vp],

@@ -542,8 +542,13 @@ shuffle_ties_kernel(const float *__restrict__ labels, const int32_t *__restrict_
     int rk[DPT];
     if (fast) {
         // integer keys below 2^24; field collisions (equal keys) recount exactly inside either form
-        if constexpr (G == kWave) count_ranks_wave<DPT>(keys, reinterpret_cast<float *>(out), n, Lp, t, key, rk);
-        else count_ranks_fast<G, DPT>(keys, out, n, t, key, rk);
+        if constexpr (G == kWave) {
+            count_ranks_wave<DPT>(keys, reinterpret_cast<float *>(out), n, Lp, t, key, rk);
+            // `out` served as the FLOAT scratch of the sorted keys; the int stores below must not move above another lane's last float
+            // loads of the binary search (type-based alias analysis would allow it): same fence as sort_desc_kernel
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else count_ranks_fast<G, DPT>(keys, out, n, t, key, rk);
     } else {
 #pragma unroll
         for (int m = 0; m < DPT; ++m) {

@@ -187,7 +187,9 @@ metrics_kernel(const float *__restrict__ preds, const float *__restrict__ labels
             const float rel = in ? fminf(fmaxf(ys, 0.0f), 1.0f) : 0.0f;                // binary relevance (:106)
             const float cumrel = wave_incl_sum(rel, lane) + c_rel;
             const float rr = __builtin_amdgcn_rcpf((float)r + 1.0f);
-            const float pr = cumrel * rr;                                // rank-wise precision (:111)
+            const float pr = cumrel / ((float)r + 1.0f);                 // rank-wise precision (:111): the reference's correctly rounded division — a
+                                                                         // perfect prefix gives P@k = AP = 1.0 exactly, not 0.99999994; rr (1 ulp) stays
+                                                                         // for the nERR cascade below
             const float cumprec = wave_incl_sum(pr * rel, lane) + c_prec;               // (:112)
             const float cumideal = wave_incl_sum(yi, lane) + c_ideal;                   // GRADED ideal labels (:114)
             const float ssat = gs * rpow_max, isat = gi * rpow_max;                       // (:133)

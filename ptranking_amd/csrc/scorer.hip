@@ -1029,7 +1029,7 @@ reduce_partials_kernel(const float *__restrict__ ws, int nblk, int nblk_tail, si
         float s = part[0][lane];
 #pragma unroll
         for (int k = 1; k < 16; ++k) s += part[k][lane];
-        grad[i] = s;
+        if (grad) grad[i] = s;                          // (ptr_opt_step_loss: ws IS the gradient, one "partial" — nothing to write back)
         // fused optimiser step on the element just reduced: the arithmetic of adam_kernel / adagrad_kernel / rmsprop_kernel, bit for bit
         if (o.kind == PTR_OPT_ADAM) {
             const float pi = o.param[i];
@@ -1219,6 +1219,32 @@ extern "C" int ptr_mlp_backward_step(const float *X, float *params, const float 
         o.lr = lr;                                                   // hyper1 = alpha
     }
     return mlp_backward_impl(who, X, params, acts, dpreds, R, F, NL, p_drop, seed, dz, ws, grad, stream, o);
+}
+
+// The optimiser step + the loss-slot sum as ONE launch on a gradient that is already reduced (data parallelism: backward -> flat gradient ->
+// RCCL all-reduce -> this): reduce_partials_kernel over ONE "partial" — the gradient itself — so the arithmetic is ptr_mlp_backward_step's,
+// bit for bit, and the data-parallel step is the single-device launch sequence + one kernel + one collective.
+extern "C" int ptr_opt_step_loss(float *params, const float *grad, int64_t n, int opt_kind, float lr, float hyper1, float hyper2, float eps,
+                                 float weight_decay, int step, float *state1, float *state2, const float *loss_q, int nq, float *loss_out,
+                                 void *stream) {
+    using namespace ptr;
+    const char *who = "ptr_opt_step_loss";
+    if (opt_kind < PTR_OPT_ADAM || opt_kind > PTR_OPT_RMSPROP) { set_error("%s: unknown optimiser %d", who, opt_kind); return PTR_ERR_INVALID_ARG; }
+    if (n < 0 || step < 1 || nq < 0 || (n > 0 && (!params || !grad || !state1 || (opt_kind == PTR_OPT_ADAM && !state2))) || (loss_out && nq > 0 && !loss_q)) {
+        set_error("%s: bad optimiser / loss arguments", who);
+        return PTR_ERR_INVALID_ARG;
+    }
+    if (n == 0 && !loss_out) return 0;
+    OptStep o{};
+    o.kind = opt_kind; o.h1 = hyper1; o.h2 = hyper2; o.eps = eps; o.wd = weight_decay;
+    o.param = params; o.s1 = state1; o.s2 = state2; o.loss_q = loss_q; o.nq = nq; o.loss_out = loss_out;
+    if (opt_kind == PTR_OPT_ADAM) { o.lr = lr; o.bc1 = 1.0f - powf(hyper1, (float)step); o.bc2_sqrt = sqrtf(1.0f - powf(hyper2, (float)step)); }
+    else if (opt_kind == PTR_OPT_ADAGRAD) o.lr = lr / (1.0f + (float)(step - 1) * hyper1);
+    else o.lr = lr;
+    const size_t nn = (size_t)n;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nn + 63) / 64) + (loss_out ? 1 : 0)), dim3(1024), 0, as_stream(stream), grad, 1, 1, nn,
+                       nn, nn, (float *)nullptr, o);
+    return check_hip(hipGetLastError(), who);
 }
 
 int ptr::mlp_backward_impl(const char *who, const float *X, const float *params, const float *acts, const float *dpreds, int R, int F, int NL,

@@ -85,7 +85,7 @@ def fold_row_offset(seed, row0):
     return ((seed >> 32) << 32) | lo
 
 
-def local_dropout_seed(seed, local_rows):
+def local_dropout_seed(seed, local_rows, local_queries=None):
     """The seed this rank passes to the dropout kernels for a batch of `local_rows` rows (documents for the pointwise scorers).  With
     every rank drawing the same base seed (same torch.manual_seed, as the reference's single process would) this makes rank r's row i
     use the mask of global row (rows of ranks < r) + i: replicas never share masks and N ranks x B/N reproduce
@@ -96,9 +96,19 @@ def local_dropout_seed(seed, local_rows):
     if not is_distributed() or world_size() == 1:
         return seed
     local_rows = int(local_rows)
-    if QUERY_SHARD is not None and QUERY_SHARD[1] > 0 and local_rows % QUERY_SHARD[1] == 0:
+    if QUERY_SHARD is not None and QUERY_SHARD[1] > 0 and local_rows % QUERY_SHARD[1] == 0 and \
+            (local_queries is None or int(local_queries) == QUERY_SHARD[1]):
+        # (local_queries, where the caller knows it, must BE the recorded slice: a later batch whose row count merely happens to divide
+        # by a stale slice's query count is placed by rank * rows like any equal split — ADVICE r4; end_step() drops the record)
         return fold_row_offset(seed, QUERY_SHARD[0] * (local_rows // QUERY_SHARD[1]))     # rows per query x queries in front of this rank
     return fold_row_offset(seed, rank() * local_rows)
+
+
+def end_step():
+    """Called by the train step once its forward passes are done (rankers.FusedStepMixin, DeviceTrainLoop): the slice recorded by
+    shard_queries() described THIS step's batch only."""
+    global QUERY_SHARD
+    QUERY_SHARD = None
 
 
 def seed_replica(seed):

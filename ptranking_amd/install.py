@@ -13,20 +13,23 @@ the train loop's host syncs and the Evaluator metric methods are replaced.  `<Mo
 """
 import importlib
 
-from .rankers import RANKER_NAMES, make_ranker_classes
+from .rankers import EXTRA_RANKER_NAMES, RANKER_NAMES, make_ranker_classes
 
 _saved = {}
 
 
-def install(names=RANKER_NAMES, ltr_module="ptranking.ltr_adhoc.eval.ltr"):
-    """Rebind `names` inside the reference's ltr module; returns {name: installed class}."""
+def install(names=RANKER_NAMES, ltr_module="ptranking.ltr_adhoc.eval.ltr", extras=False):
+    """Rebind `names` inside the reference's ltr module; returns {name: installed class}.  extras=True adds the rankers SURVEY.md 2 marks
+    out of scope (EXTRA_RANKER_NAMES: DASALC, MDPRank), which the default drop-in leaves alone."""
+    if extras:
+        names = tuple(names) + tuple(n for n in EXTRA_RANKER_NAMES if n not in names)
     mod = importlib.import_module(ltr_module)
     base = importlib.import_module("ptranking.base.adhoc_ranker").AdhocNeuralRanker
     classes = make_ranker_classes(base)
     done = {}
     for n in names:
         if n not in classes:
-            raise KeyError(f"{n} is not one of {RANKER_NAMES}")
+            raise KeyError(f"{n} is not one of {RANKER_NAMES + EXTRA_RANKER_NAMES}")
         _saved.setdefault((ltr_module, n), getattr(mod, n, None))
         setattr(mod, n, classes[n])
         done[n] = classes[n]

@@ -20,7 +20,10 @@ from .host import DeviceEvaluator, DeviceTrainLoop, PointScorerRanker, is_multil
 from .listsf import FusedListScorerMixin
 from .scorer import FlatAdagrad, FlatAdam, FlatRMSprop, FusedPointScorer, FusedScorerMixin, mlp_forward
 
-RANKER_NAMES = ("RankNet", "LambdaRank", "LambdaLoss", "ApproxNDCG", "ListNet", "ListMLE", "STListNet", "RankCosine", "RankMSE", "SoftRank", "DASALC", "MDPRank")
+RANKER_NAMES = ("RankNet", "LambdaRank", "LambdaLoss", "ApproxNDCG", "ListNet", "ListMLE", "STListNet", "RankCosine", "RankMSE", "SoftRank")
+# SURVEY.md 2 marks these OUT OF SCOPE (the reference's driver cannot reach them): kept as classes for whoever asks for them by name
+# (install(extras=True), pa.DASALC / pa.MDPRank), not part of the default drop-in surface
+EXTRA_RANKER_NAMES = ("DASALC", "MDPRank")
 
 # default hyper-parameters = the reference's `default_para_dict()`s
 DEFAULT_PARAS = {
@@ -97,7 +100,8 @@ class FusedStepMixin:
         p = sf.dropout
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0      # same CPU-generator draw as FusedPointScorer.forward
         if p > 0.0:
-            seed = dp.local_dropout_seed(seed, R)
+            seed = dp.local_dropout_seed(seed, R, local_queries=B)
+            dp.end_step()                        # the recorded query slice described this batch only
         loss = torch.empty(1, device=dev)
         entry, params = spec
         distributed = self.data_parallel and dp.is_distributed()
@@ -110,8 +114,11 @@ class FusedStepMixin:
             stop_training = False
             if 'epoch_k' in kwargs and kwargs['epoch_k'] % self.stop_check_freq == 0:
                 stop_training = self.stop_training(buf["preds"])
-            _lib.call(entry, _lib.ptr(buf["preds"]), _lib.ptr(Y), _lib.ptr(lens), B, L, *params(self, kwargs), None if fuse_step else _lib.ptr(loss),
-                      _lib.ptr(buf["loss_q"]), _lib.ptr(buf["dpreds"]), st)
+            # data parallel with a flat optimiser: backward -> flat gradient -> all-reduce -> ONE launch (optimiser step + loss-slot sum,
+            # ptr_opt_step_loss): the single-device launch sequence + one kernel + one collective, nothing returns to autograd in between
+            dp_fused = distributed and self.fuse_optimizer_step and type(self.optimizer) in (FlatAdam, FlatAdagrad, FlatRMSprop)
+            _lib.call(entry, _lib.ptr(buf["preds"]), _lib.ptr(Y), _lib.ptr(lens), B, L, *params(self, kwargs),
+                      None if (fuse_step or dp_fused) else _lib.ptr(loss), _lib.ptr(buf["loss_q"]), _lib.ptr(buf["dpreds"]), st)
             if fuse_step:
                 kind, lr, h1, h2, eps, wd, step, s1, s2 = self.optimizer.fused_step_args(flat)
                 try:
@@ -124,7 +131,17 @@ class FusedStepMixin:
                           C.c_uint64(seed), _lib.ptr(buf["dz"]), _lib.ptr(buf["ws"]), _lib.ptr(flat.grad), st)
                 if distributed:
                     dp.all_reduce_sum(flat.grad)
-                self.optimizer.step_flat(flat)
+                if dp_fused:
+                    kind, lr, h1, h2, eps, wd, step, s1, s2 = self.optimizer.fused_step_args(flat)
+                    try:
+                        _lib.call("ptr_opt_step_loss", _lib.ptr(flat), _lib.ptr(flat.grad), C.c_int64(flat.numel()), kind, C.c_float(lr), C.c_float(h1),
+                                  C.c_float(h2), C.c_float(eps), C.c_float(wd), step, _lib.ptr(s1), _lib.ptr(s2), _lib.ptr(buf["loss_q"]), B,
+                                  _lib.ptr(loss), st)
+                    except Exception:
+                        self.optimizer.state[flat]["step"] -= 1
+                        raise
+                else:
+                    self.optimizer.step_flat(flat)
         return loss.reshape(()), stop_training
 
     def _launch_backward_step(self, X, flat, buf, R, Fd, NL, p, seed, kind, lr, h1, h2, eps, wd, step, s1, s2, B, loss, st):
@@ -167,6 +184,7 @@ class FusedStepMixin:
             self.optimizer.zero_grad()
             loss.backward()
         self.optimizer.step()
+        dp.end_step()                            # a query slice recorded by dp.shard_queries() described this step's batch only
         return loss
 
 

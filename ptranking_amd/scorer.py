@@ -205,7 +205,7 @@ class FusedPointScorer(nn.Module):
         store = torch.is_grad_enabled() and self.flat.requires_grad
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0     # CPU generator: no device sync
         if p > 0.0:
-            seed = dp.local_dropout_seed(seed, X2d.shape[0])                     # replicas draw the masks of THEIR global rows (dp.py)
+            seed = dp.local_dropout_seed(seed, X2d.shape[0], local_queries=lead[0] if len(lead) == 2 else None)   # replicas draw the masks of THEIR global rows (dp.py)
         preds = _ScorerFn.apply(X2d, self.flat, self.num_features, self.num_layers, p, seed, store)
         return preds.view(*lead, 1)
 

@@ -98,6 +98,22 @@ def test_x6_entry_point_validates_without_a_gpu():
     assert lib.ptr_mlp_forward_x6(*args(0, 136, 3, 0.1)) == 0
 
 
+def test_opt_step_loss_validates_without_a_gpu():
+    """ABI v4: `ptr_opt_step_loss` (the data-parallel step's optimiser step + loss-slot sum in one launch) checks its arguments before any launch."""
+    from ptranking_amd import _lib
+    lib = _lib.load()
+    one = ctypes.c_void_p(4096)
+    f = ctypes.c_float
+    args = lambda kind=1, n=8, step=1, p=one, s2=one, lq=one, nq=4: (p, one, ctypes.c_int64(n), kind, f(1e-3), f(0.9), f(0.999), f(1e-8), f(1e-3), step,
+                                                                     one, s2, lq, nq, one, None)
+    assert lib.ptr_opt_step_loss(*args(kind=7)) == 1001 and b"optimiser" in lib.ptr_last_error()
+    assert lib.ptr_opt_step_loss(*args(step=0)) == 1001
+    assert lib.ptr_opt_step_loss(*args(p=None)) == 1001
+    assert lib.ptr_opt_step_loss(*args(s2=None)) == 1001            # Adam needs both moment buffers
+    assert lib.ptr_opt_step_loss(*args(lq=None)) == 1001            # a loss sum needs its slots
+    assert lib.ptr_opt_step_loss(one, one, ctypes.c_int64(0), 1, f(1e-3), f(0.9), f(0.999), f(1e-8), f(0.0), 1, one, one, None, 0, None, None) == 0
+
+
 def test_product_path_fails_loudly_on_cpu_tensors():
     import ptranking_amd as pa
     p, y = torch.zeros(2, 8), torch.zeros(2, 8)

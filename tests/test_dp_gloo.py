@@ -191,6 +191,14 @@ def _uneven_worker(rank, world, port, out_dir):
     lo, hi = dp.shard_queries(5)                      # 5 queries over 2 ranks: (0, 3) and (3, 5)
     got = dp.local_dropout_seed(seed, (hi - lo) * L)                 # pointwise scorer: rows = documents
     got_heads = dp.local_dropout_seed(seed, (hi - lo) * 2 * L)       # attention rows: queries x heads x documents
+    # a batch with a DIFFERENT local query count whose rows merely divide by the recorded slice's is not placed by that slice
+    other_q = 2 * (hi - lo)
+    stale = dp.local_dropout_seed(seed, other_q * L, local_queries=other_q)
+    assert stale == dp.fold_row_offset(seed, rank * other_q * L), (stale, rank)
+    assert dp.local_dropout_seed(seed, (hi - lo) * L, local_queries=hi - lo) == got
+    dp.end_step()                                                      # the record describes one step
+    assert dp.QUERY_SHARD is None and dp.local_dropout_seed(seed, (hi - lo) * L) == dp.fold_row_offset(seed, rank * (hi - lo) * L)
+    dp.shard_queries(5)
     torch.save({"lo": lo, "hi": hi, "seed": got, "want": dp.fold_row_offset(seed, lo * L), "seed_heads": got_heads,
                 "want_heads": dp.fold_row_offset(seed, lo * 2 * L), "naive": dp.fold_row_offset(seed, rank * (hi - lo) * L)},
                os.path.join(out_dir, f"u{rank}.pt"))

@@ -106,7 +106,7 @@ def test_install_drops_into_the_reference_driver():
         original = ref_ltr.LambdaRank
         installed = pa.install()
         try:
-            assert set(installed) == set(pa.RANKER_NAMES)
+            assert set(installed) == set(pa.RANKER_NAMES) and not (set(installed) & set(pa.EXTRA_RANKER_NAMES))
             for n, cls in installed.items():
                 assert getattr(ref_ltr, n) is cls and issubclass(cls, AdhocNeuralRanker)
                 assert cls.custom_loss_function is not getattr(original if n == "LambdaRank" else AdhocNeuralRanker,
@@ -225,6 +225,31 @@ def test_reference_kfold_cv_eval_runs_on_the_installed_ranker(tmp_path, monkeypa
             assert scores.shape == (3,) and bool(torch.isfinite(scores).all()) and bool((scores > 0).all()) and bool((scores <= 1).all())
             assert calls["loss"] == 2 * 3 * 3                     # folds x epochs x train batches went through OUR custom_loss_function
             assert calls["metrics"] >= 2 * (3 * 2 + 2)            # per-epoch validation + the final test evaluation of every fold
+        finally:
+            pa.uninstall()
+    finally:
+        sys.path.remove(REF)
+
+
+def test_strict_device_is_the_default_and_extras_are_opt_in(monkeypatch):
+    """VERDICT r4 housekeeping: (a) without PTR_STRICT_DEVICE=0 a CPU tensor in a FusedLinear is an error, not torch's F.linear; (b) install()
+    leaves the rankers SURVEY.md 2 marks out of scope (DASALC, MDPRank) alone unless asked."""
+    import torch
+    import ptranking_amd as pa
+    from ptranking_amd import _lib, linear
+    lin = linear.FusedLinear(4, 3)
+    monkeypatch.delenv("PTR_STRICT_DEVICE", raising=False)
+    with pytest.raises(_lib.NativeLibraryError):
+        lin(torch.zeros(2, 4))
+    monkeypatch.setenv("PTR_STRICT_DEVICE", "0")
+    assert lin(torch.zeros(2, 4)).shape == (2, 3)
+    assert "MDPRank" not in pa.RANKER_NAMES and "DASALC" not in pa.RANKER_NAMES and set(pa.EXTRA_RANKER_NAMES) == {"DASALC", "MDPRank"}
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    try:
+        installed = pa.install(extras=True)
+        try:
+            assert set(installed) == set(pa.RANKER_NAMES) | set(pa.EXTRA_RANKER_NAMES)
         finally:
             pa.uninstall()
     finally:

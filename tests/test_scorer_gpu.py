@@ -315,3 +315,31 @@ def test_two_pass_backward_equals_the_layer_wise_kernels(F, NL, R, p, monkeypatc
         grads[tail] = g.double().cpu()
     scale = max(1.0, float(grads["0"].abs().max()))
     assert float((grads["1"] - grads["0"]).abs().max()) <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("kind", ["Adam", "Adagrad", "RMS"])
+def test_opt_step_loss_equals_the_separate_step_and_sum(kind):
+    """ABI v4 `ptr_opt_step_loss`: the optimiser step + loss-slot sum launch of the data-parallel direct step gives the bits of the separate
+    ptr_adam_step / ptr_adagrad_step / ptr_rmsprop_step and ptr_sum_f32 calls (it runs the arithmetic of ptr_mlp_backward_step's reduction tail)."""
+    import ctypes as C
+    from ptranking_amd import _lib
+    from ptranking_amd.scorer import FLAT_OPTIMIZERS
+    torch.manual_seed(5)
+    n, nq = 34001, 1000
+    p0 = torch.randn(n, device="cuda"); g = torch.randn(n, device="cuda"); lq = torch.rand(nq, device="cuda")
+    pa_, pb_ = torch.nn.Parameter(p0.clone()), torch.nn.Parameter(p0.clone())
+    kw = dict(lr=1e-2, weight_decay=1e-3)
+    oa, ob = FLAT_OPTIMIZERS[kind]([pa_], **kw), FLAT_OPTIMIZERS[kind]([pb_], **kw)
+    st = _lib.current_stream(p0.device)
+    for it in range(3):
+        pa_.grad = g * (it + 1); pb_.grad = g * (it + 1)
+        oa.step()
+        want = torch.empty(1, device="cuda")
+        _lib.call("ptr_sum_f32", _lib.ptr(lq), nq, C.c_float(1.0), _lib.ptr(want), st)
+        k, lr, h1, h2, eps, wd, step, s1, s2 = ob.fused_step_args(pb_)
+        got = torch.empty(1, device="cuda")
+        _lib.call("ptr_opt_step_loss", _lib.ptr(pb_), _lib.ptr(pb_.grad), C.c_int64(n), k, C.c_float(lr), C.c_float(h1), C.c_float(h2), C.c_float(eps),
+                  C.c_float(wd), step, _lib.ptr(s1), _lib.ptr(s2), _lib.ptr(lq), nq, _lib.ptr(got), st)
+        assert torch.equal(pa_.detach(), pb_.detach()), (kind, it)
+        assert torch.equal(got, want)
+        assert torch.equal(pb_.grad, g * (it + 1))                  # the gradient is read, not rewritten
