@@ -149,8 +149,10 @@ int ptr_sum_f32(const float *x, int n, float scale, float *out, void *stream);
  * `params` / `grad` are ONE flat fp32 buffer in PyTorch's own order and layouts:
  *   W1[100][F] b1[100] | W2[100][100] b2[100] | ... (NL hidden layers) | w_out[100] b_out[1]      (ptr_mlp_num_params floats)
  * X is [R][F] row-major (R = B*L documents), preds [R].  train != 0: dropout p_drop from the counter-based generator
- * seeded by `seed`, and the post-dropout activations needed by backward are written to acts [NL][R][PTR_MLP_ACT_LD]
- * (rows padded to 112 floats = 7 aligned 64-byte sectors).
+ * seeded by `seed`, and the post-dropout activations needed by backward are written to `acts`: ptr_mlp_acts_floats(R, NL) floats,
+ * opaque to the caller (ABI v4: TILE-MAJOR [NL][ceil(R / 16)][7][16][16] — every block of 16 rows x 16 of the PTR_MLP_ACT_LD = 112
+ * padded features is one contiguous KB, the unit a forward store instruction writes and a backward LDS-DMA piece reads; element
+ * (layer, row, col) at layer * ceil16(R) * 112 + (row / 16) * 1792 + (col / 16) * 256 + (row % 16) * 16 + col % 16).
  * ptr_mlp_backward: dpreds [R] -> grad (every entry overwritten); ws (ptr_mlp_backward_ws_floats) and dz (ptr_mlp_backward_dz_floats
  * floats: [NL][R][PTR_MLP_ACT_LD] for the layer-wise kernels, 0 => may be NULL when the single-pass fused backward serves the
  * configuration — NL = 3, F in {132, 136, 140}) are caller-provided scratch; p_drop / seed must be the forward call's.
@@ -158,6 +160,7 @@ int ptr_sum_f32(const float *x, int n, float scale, float *out, void *stream);
 size_t ptr_mlp_num_params(int F, int NL);
 size_t ptr_mlp_backward_ws_floats(int F, int NL);
 size_t ptr_mlp_backward_dz_floats(int R, int F, int NL);
+size_t ptr_mlp_acts_floats(int R, int NL);                       /* ABI v4: NL * ceil16(R) * 112 */
 int ptr_mlp_forward(const float *X, const float *params, int R, int F, int NL, int train, float p_drop, uint64_t seed,
                     float *preds, float *acts, void *stream);
 int ptr_mlp_backward(const float *X, const float *params, const float *acts, const float *dpreds, int R, int F, int NL,

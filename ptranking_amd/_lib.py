@@ -39,6 +39,7 @@ SIGNATURES = {
     "ptr_mlp_num_params": [_i, _i],
     "ptr_mlp_backward_ws_floats": [_i, _i],
     "ptr_mlp_backward_dz_floats": [_i, _i, _i],
+    "ptr_mlp_acts_floats": [_i, _i],
     "ptr_mlp_forward": [_vp, _vp, _i, _i, _i, _i, _f, _u64, _vp, _vp, _vp],
     "ptr_mlp_backward": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _vp, _vp, _vp, _vp],
     "ptr_mlp_backward_step": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _i, _vp, _vp, _vp, _i, _vp, _vp],
@@ -69,7 +70,7 @@ SIGNATURES = {
     "ptr_letor_load": [C.c_char_p, _i, _f, C.c_int64, C.c_int32, C.c_int64, _vp, _i, _vp, _vp, _vp],
 }
 _RESTYPES = {"ptr_last_error": C.c_char_p, "ptr_mlp_num_params": C.c_size_t, "ptr_mlp_backward_ws_floats": C.c_size_t,
-             "ptr_mlp_backward_dz_floats": C.c_size_t, "ptr_mlp_x6_ws_bytes": C.c_size_t, "ptr_linear_backward_weight_ws_floats": C.c_size_t, "ptr_bn_ws_floats": C.c_size_t,
+             "ptr_mlp_backward_dz_floats": C.c_size_t, "ptr_mlp_acts_floats": C.c_size_t, "ptr_mlp_x6_ws_bytes": C.c_size_t, "ptr_linear_backward_weight_ws_floats": C.c_size_t, "ptr_bn_ws_floats": C.c_size_t,
              "ptr_layernorm_backward_ws_floats": C.c_size_t}
 OPTIONAL = set()
 

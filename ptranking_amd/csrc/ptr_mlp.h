@@ -13,8 +13,19 @@ constexpr int kH = 100;          // hidden width, hard-wired in the reference (p
 constexpr int kHP = 112;         // padded to 7 MFMA tiles of 16
 constexpr int kMT = 7;
 constexpr int kMaxLayers = 8;
-constexpr int kAL = 112;         // leading dimension of the stored activations / dZ: rows are 448 B = 7 aligned 64-B sectors,
-                                 // one per (row, 16-feature tile); features 100..111 are padding
+constexpr int kAL = 112;         // floats per row of the stored activations / leading dimension of the dZ scratch; features 100..111 are padding
+// r5: the stored activations are TILE-MAJOR: [layer][row tile of 16][feature tile of 16 (7 of them)][row in tile][feature in tile] — every
+// (16 rows x 16 features) block is ONE contiguous KB, the unit a forward store instruction writes (lane (j, g) = row j, features 4g..4g+3 of
+// the tile: 64 lanes x 16 B back to back) and an LDS-DMA piece of the backward reads.  Row-major rows (448 B) made every store instruction
+// touch sixteen 64-byte pieces in sixteen different rows (bf16x6 training forward 375 -> 349 us at 524 288 x 136, scratch/r5_call1.sh).
+// A layer holds ceil(R / 16) whole row tiles: rows past R of the last tile are written (finite values) and never contribute (their
+// dLoss/dscore is 0).  The dZ scratch of the layer-wise backward stays row-major [R][112].
+constexpr int kActTile = 16 * kAL;                                   // floats of one row tile (7 KB)
+__host__ __device__ inline int act_row_tiles(int R) { return (R + 15) >> 4; }
+__host__ __device__ inline size_t act_layer_floats(int R) { return (size_t)act_row_tiles(R) * kActTile; }
+__host__ __device__ inline size_t act_off(int row, int col) {       // float offset of (row, col) inside a layer
+    return (size_t)(row >> 4) * kActTile + (size_t)(((col >> 4) << 8) + ((row & 15) << 4) + (col & 15));
+}
 
 // flat parameter layout:  W1[100][F] b1[100] | W2[100][100] b2[100] | ... | w_out[100] b_out[1]
 __host__ __device__ inline size_t off_W(int l, int F) { return l == 0 ? 0 : (size_t)kH * F + kH + (size_t)(l - 1) * (kH * kH + kH); }

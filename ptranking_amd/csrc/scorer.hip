@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(NTHR)
 mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs a, float *__restrict__ preds,
                float *__restrict__ acts) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int F = a.F, NL = a.NL, R = a.R, ld1 = ld_w1(F);
+    const int F = a.F, NL = a.NL, R = a.R, ld1 = ld_w1(F), R16 = act_row_tiles(a.R) * 16;
     float *W1s = smem;
     float *Wh = W1s + (W1G == 0 ? (size_t)kHP * ld1 : (W1G == 2 ? (size_t)2 * kHP * kSlabLd : 0));
     float *Bs = Wh + (size_t)(NL - 1) * kHP * kH;
@@ -504,14 +504,14 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
                     // (28 stores issued back to back at the layer transition stall the wave on the store path)
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) {
-                        if (row[rt] < R) {
+                        if (row[rt] < R16) {            // whole row tiles (tile-major `acts`, ptr_mlp.h): rows past R hold finite values nobody uses
 #if defined(PTR_FWD_L2STORE)     // experiment: same store instructions, L2-resident target
-                            float *arow = acts + ((size_t)(l - 1) * R + (row[rt] & 4095)) * kAL;
+                            float *arow = acts + (size_t)(l - 1) * act_layer_floats(R) + act_off(row[rt] & 4095, 0);
 #else
-                            float *arow = acts + ((size_t)(l - 1) * R + row[rt]) * kAL;
+                            float *arow = acts + (size_t)(l - 1) * act_layer_floats(R) + act_off(row[rt], 0);
 #endif
 #if !defined(PTR_FWD_NOSTORE)
-                            *reinterpret_cast<f32x4 *>(arow + 16 * S + 4 * g) = S < kLast ? hin[S][rt] : tail_store(hin[S][rt][0], 1.0f);
+                            *reinterpret_cast<f32x4 *>(arow + 256 * S + 4 * g) = S < kLast ? hin[S][rt] : tail_store(hin[S][rt][0], 1.0f);
 #else
                             if (hin[S][rt][0] == 123.456f) acts[0] = 1.0f;
 #endif
@@ -538,16 +538,16 @@ mlp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ P, MlpArgs
 #pragma unroll
                 for (int c = 0; c < (mt == kMT - 1 ? 1 : 4); ++c) { h[c] = fmaxf(h[c], 0.0f); sc[rt] = fmaf(h[c], w4[c], sc[rt]); }
                 if constexpr (TRAIN) {
-                    if (row[rt] < R) {
+                    if (row[rt] < R16) {
 #if defined(PTR_FWD_L2STORE)
-                        float *arow = acts + ((size_t)(NL - 1) * R + (row[rt] & 4095)) * kAL;
+                        float *arow = acts + (size_t)(NL - 1) * act_layer_floats(R) + act_off(row[rt] & 4095, 0);
 #else
-                        float *arow = acts + ((size_t)(NL - 1) * R + row[rt]) * kAL;
+                        float *arow = acts + (size_t)(NL - 1) * act_layer_floats(R) + act_off(row[rt], 0);
 #endif
 #if defined(PTR_FWD_NOSTORE)
                         if (h[0] == 123.456f) acts[1] = 1.0f;
 #else
-                        *reinterpret_cast<f32x4 *>(arow + 16 * mt + 4 * g) = mt < kMT - 1 ? h : tail_store(h[0], 0.0f);
+                        *reinterpret_cast<f32x4 *>(arow + 256 * mt + 4 * g) = mt < kMT - 1 ? h : tail_store(h[0], 0.0f);
 #endif
                     }
                 }
@@ -610,7 +610,7 @@ mlp_bwd_dz_kernel(const float *__restrict__ P, const float *__restrict__ acts, c
             dspf[rt] = dpreds[rc];
 #pragma unroll
             for (int mt = 0; mt < kMT; ++mt)
-                hpf[mt][rt] = *reinterpret_cast<const f32x4 *>(acts + ((size_t)(NL - 1) * R + rc) * kAL + 16 * mt + 4 * g);
+                hpf[mt][rt] = *reinterpret_cast<const f32x4 *>(acts + (size_t)(NL - 1) * act_layer_floats(R) + act_off(rc, 16 * mt + 4 * g));
         }
     };
     const int tile_first = blockIdx.x * wpb + wave, tile_step = gridDim.x * wpb;
@@ -660,7 +660,7 @@ mlp_bwd_dz_kernel(const float *__restrict__ P, const float *__restrict__ acts, c
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
                     const bool ok = row[rt] < R;
-                    const size_t o = ((size_t)(l - 1) * R + row[rt]) * kAL + 16 * mt + 4 * g;
+                    const size_t o = (size_t)(l - 1) * act_layer_floats(R) + act_off(row[rt], 16 * mt + 4 * g);       // (`acts` is tile-major; dz row-major)
                     gate[mt][rt] = *reinterpret_cast<const f32x4 *>(acts + (ok ? o : 0));
                 }
             f32x4 acc[kMT][RT];
@@ -767,12 +767,13 @@ mlp_bwd_dw_kernel(const float *__restrict__ A, int lda, const float *__restrict_
             const bool rok = !guard || r < r_end;
             const int rc = rok ? r : r_end - 1;
             const float *dzr = dZ + (size_t)rc * kAL;
-            const float *ar = A + (size_t)rc * lda;
+            // A = X (row-major, lda) for the first layer, the stored activations (tile-major, ptr_mlp.h act_off) for the others
+            const float *ar = SITE0 ? A + (size_t)rc * lda : A + act_off(rc, 0);
 #pragma unroll
             for (int mt = 0; mt < kMT; ++mt) pa[u][mt] = dzr[fa[mt]] * ((rok & fa_ok[mt]) ? 1.0f : 0.0f);
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
-                float v = ar[kb[t]];
+                float v = SITE0 ? ar[kb[t]] : ar[((kb[t] >> 4) << 8) + (kb[t] & 15)];
                 bool keep = rok & kb_ok[t];
                 if constexpr (SITE0) keep = keep & drop_keep1(a.seed_lo, a.seed_hi, 0, rc, kb[t], thr);   // thr == 0 keeps all
                 pb[u][t] = v * (keep ? scale : 0.0f);
@@ -889,7 +890,8 @@ mlp_bwd_dw_lds_kernel(const float *__restrict__ A, int lda, const float *__restr
         for (int s_ = 0; s_ < SA; ++s_) {
             const int r = r0 + a_row[s_];
             const int rc = r < r_end ? r : r_end - 1;
-            ra[s_] = *reinterpret_cast<const f32x4 *>(A + (size_t)rc * lda + (a_ok[s_] ? a_col[s_] : 0));
+            const int cc = a_ok[s_] ? a_col[s_] : 0;
+            ra[s_] = *reinterpret_cast<const f32x4 *>(SITE0 ? A + (size_t)rc * lda + cc : A + act_off(rc, cc));      // X row-major / activations tile-major
         }
 #pragma unroll
         for (int s_ = 0; s_ < SZ; ++s_) {
@@ -1131,6 +1133,7 @@ extern "C" size_t ptr_mlp_backward_ws_floats(int F, int NL) {
 
 // floats of dZ scratch ptr_mlp_backward needs for (R, F, NL): 0 when the single-pass fused backward serves the configuration
 // (X / acts assumed 16-byte aligned, as every torch allocation is)
+extern "C" size_t ptr_mlp_acts_floats(int R, int NL) { return R > 0 && NL > 0 ? (size_t)NL * ptr::act_layer_floats(R) : 0; }
 extern "C" size_t ptr_mlp_backward_dz_floats(int R, int F, int NL) {
     return ptr::bwd_fused_supported(F, NL, nullptr, nullptr) ? 0 : (size_t)NL * (size_t)R * ptr::kAL;
 }
@@ -1294,7 +1297,7 @@ int ptr::mlp_backward_impl(const char *who, const float *X, const float *params,
     // 2. dW per layer (row contraction), every block writes its partial into ws[block][flat parameter layout]
     for (int l = 0; l < (tail ? 1 : NL); ++l) {
         const int K = l == 0 ? F : kH;
-        const float *A = l == 0 ? X : acts + (size_t)(l - 1) * R * kAL;
+        const float *A = l == 0 ? X : acts + (size_t)(l - 1) * act_layer_floats(R);      // (tile-major: the !SITE0 kernels address it with act_off)
         const int lda = l == 0 ? F : kAL;
         const float *dZ = dz + (size_t)l * R * kAL;
         const int ntk = (K + 15) / 16;

@@ -7,8 +7,10 @@
 // HBM traffic per document (F = 136, NL = 3): read 4F (X) + NL*448 (activations) + 4 (dpreds) = 1.9 KB; the only writes are
 // one partial gradient per workgroup (256 x 136 KB).  The layer-wise path (scorer.hip) moves 5.8 KB per document.
 //
-// Structure.  A persistent 8-wave workgroup per CU walks slabs of 32 documents.  Per slab everything lives in LDS as plain
-// [row][feature] images (row stride 112 floats = 16 mod 32 banks, X: 16*NT1 (+16)):
+// Structure.  A persistent 8-wave workgroup per CU walks slabs of 32 documents.  Per slab everything lives in LDS: the activation / dZ
+// images TILE-MAJOR like the stored activations (ptr_mlp.h act_off: [row tile of 16][feature tile of 16][row][feature], so a slab image is a
+// straight 14 KB copy of global memory and lane (feature j, row g) of an MFMA operand read still hits 32 distinct banks), the X image as
+// plain [row][feature] (row stride 16*NT1 (+16) = 16 mod 32 banks):
 //     A_l   the stored activations, landed by LDS-DMA (global_load_lds_dwordx4) one slab ahead, no registers involved
 //     XS    the input features with the input dropout recomputed (global -> registers one slab ahead -> hash -> LDS)
 //     Z_l   dZ of the hidden layers, produced in place (top layer) or by the chain phases
@@ -279,16 +281,17 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
 
     // this wave's share of the activation DMA (chunks of 64 lanes x 16 B)
     auto issue_dma = [&](int slab, int buf, int lane_o) {
-        // a slab image is CONTIGUOUS in global memory (row stride = image stride = 448 B): float offset row0*112 + chunk*256 + lane*4,
-        // clamped to the last float4 of the layer for the tail slab (rows >= R only need finite values: their dLoss/dscore is 0)
-        const int off0 = slab * kSlabF + 4 * lane_o;
-        const int last = R * kAL - 4;
+        // a slab image is CONTIGUOUS in global memory: two row tiles of 7 KB each (tile-major, ptr_mlp.h), chunk ch < 7 = feature tile ch of the
+        // first, ch >= 7 of the second; a tail slab whose second row tile does not exist re-reads the last one (rows >= R only need finite
+        // values: their dLoss/dscore is 0) — all scalar arithmetic
+        const int nrt = act_row_tiles(R);
 #pragma unroll
         for (int q = 0; q < (NL * 14 + kBW - 1) / kBW; ++q) {
             const int k = W + kBW * q;                     // scalar
             if (k < NL * 14) {
                 const int layer = k / 14, ch = k - 14 * layer;
-                const float *src = acts + (size_t)layer * R * kAL + min(off0 + ch * 256, last);
+                const int rt = min(2 * slab + (ch >= 7 ? 1 : 0), nrt - 1);
+                const float *src = acts + (size_t)layer * act_layer_floats(R) + (size_t)rt * kActTile + (ch >= 7 ? ch - 7 : ch) * 256 + 4 * lane_o;
                 const uint32_t dst = bufA_addr + (uint32_t)(((buf * NL + layer) * kSlabF + ch * 256) * 4);
                 glds16(src, __builtin_amdgcn_readfirstlane(dst));
             }
@@ -359,7 +362,7 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
         for (int h = 0; h < 4; ++h) {                      // all reads first: the in-place update must not serialise the four rows
             const int r = rs + 9 * h;
             const bool ok = rs < 9 && r < kSR;
-            pa[h] = ok ? img + r * kAL + 4 * f4 : junk_row + 4 * f4;
+            pa[h] = ok ? img + (r >> 4) * kActTile + (f4 >> 2) * 256 + (r & 15) * 16 + (f4 & 3) * 4 : junk_row + 4 * f4;
             h4[h] = *reinterpret_cast<const f32x4 *>(pa[h]);
             const float dsr = dsb[buf * kSR + (ok ? r : 0)];
             ds[h] = ok ? dsr : 0.0f;
@@ -396,9 +399,9 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
             uint32_t zb[NL], ab[NL], zb6[NL], ab6[NL];
 #pragma unroll
             for (int l = 0; l < NL; ++l) {
-                zb[l] = lds_byte_addr(l == NL - 1 ? cur + (NL - 1) * kSlabF : Zb + l * kSlabF) + (uint32_t)((g * kAL + j) * 4);
+                zb[l] = lds_byte_addr(l == NL - 1 ? cur + (NL - 1) * kSlabF : Zb + l * kSlabF) + (uint32_t)((g * 16 + j) * 4);
                 ab[l] = l == 0 ? lds_byte_addr(XS) + (uint32_t)((g * LDX + j) * 4)
-                               : lds_byte_addr(cur + (l - 1) * kSlabF) + (uint32_t)((g * kAL + j) * 4);
+                               : lds_byte_addr(cur + (l - 1) * kSlabF) + (uint32_t)((g * 16 + j) * 4);
                 zb6[l] = zb[l] - (uint32_t)((j - (j & 3)) * 4);       // out-feature tile 6 as 4x4 blocks: lane j reads feature 96 + (j & 3)
                 ab6[l] = ab[l] - (uint32_t)((j - (j & 3)) * 4);       // in-feature tile 6 of a hidden layer likewise
                 asm volatile("" : "+v"(zb[l]), "+v"(ab[l]), "+v"(zb6[l]), "+v"(ab6[l]));
@@ -408,12 +411,14 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
                 static_for<CNT>([&](auto k_) {
                     constexpr int t = kTM<NL, NT1>.lst[WV][PH][k_];
                     constexpr int l = kTM<NL, NT1>.tl[t], n = kTM<NL, NT1>.tn[t], m = kTM<NL, NT1>.tm[t];
+                    // image rows 4 ks + g of a tile-major image: row tile ks >> 2, row (4 (ks & 3) + g) in it — the lane part g * 16 + j sits in the base
+                    const int kso = (ks >> 2) * kActTile + (ks & 3) * 64;
                     if constexpr (kTM<NL, NT1>.first_a(WV, PH, k_))
-                        av[set][l][m] = *reinterpret_cast<lds_f *>((uintptr_t)((m == kMT - 1 ? zb6[l] : zb[l]) + (uint32_t)((4 * ks * kAL + 16 * m) * 4)));
+                        av[set][l][m] = *reinterpret_cast<lds_f *>((uintptr_t)((m == kMT - 1 ? zb6[l] : zb[l]) + (uint32_t)((kso + 256 * m) * 4)));
                     if constexpr (kTM<NL, NT1>.first_b(WV, PH, k_))
-                        bv[set][l][n] = *reinterpret_cast<lds_f *>((uintptr_t)(ab[l] + (uint32_t)((4 * ks * (l == 0 ? LDX : kAL) + 16 * n) * 4)));
+                        bv[set][l][n] = *reinterpret_cast<lds_f *>((uintptr_t)(ab[l] + (uint32_t)((l == 0 ? 4 * ks * LDX + 16 * n : kso + 256 * n) * 4)));
                     if constexpr (kTM<NL, NT1>.first_nstrip(WV, PH, k_))
-                        bv6[set][l] = *reinterpret_cast<lds_f *>((uintptr_t)(ab6[l] + (uint32_t)((4 * ks * kAL + 16 * 6) * 4)));
+                        bv6[set][l] = *reinterpret_cast<lds_f *>((uintptr_t)(ab6[l] + (uint32_t)((kso + 256 * 6) * 4)));
                 });
             };
             auto mma = [&](auto set_) {
@@ -494,12 +499,12 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
                 // independent MFMA chains in flight (dependent-accumulator latency 40 cycles vs 32 issue)
 #pragma unroll
                 for (int rt = 0; rt < kSR / 16; ++rt) {
-                    const int row = 16 * rt + j;
+                    const int rbase = rt * kActTile + j * 16;         // document j of row tile rt: feature tile S at + 256 S (tile-major images)
                     f32x4 b[6];
 #pragma unroll
-                    for (int S = 0; S < 6; ++S) b[S] = *reinterpret_cast<const f32x4 *>(src + row * kAL + 16 * S + 4 * g);
-                    const float bt = src[row * kAL + 96 + g];
-                    const f32x4 gt = *reinterpret_cast<const f32x4 *>(gate + row * kAL + 16 * W + 4 * g);
+                    for (int S = 0; S < 6; ++S) b[S] = *reinterpret_cast<const f32x4 *>(src + rbase + 256 * S + 4 * g);
+                    const float bt = src[rbase + 256 * 6 + g];
+                    const f32x4 gt = *reinterpret_cast<const f32x4 *>(gate + rbase + 256 * W + 4 * g);
                     f32x4 ac0 = f32x4{0.f, 0.f, 0.f, 0.f}, ac1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int S = 0; S < 6; ++S) {
@@ -512,7 +517,7 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
                     f32x4 d;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) d[e] = (ac0[e] + ac1[e]) * (gt[e] > 0.0f ? inv_keep : 0.0f);
-                    *reinterpret_cast<f32x4 *>(dst + row * kAL + 16 * W + 4 * g) = d;
+                    *reinterpret_cast<f32x4 *>(dst + rbase + 256 * W + 4 * g) = d;
                     if constexpr (c < CH - 1) dbc[c] += d;            // db_{l-1}: column sum of the dZ image just produced (rows >= R are 0)
                 }
             } else {
@@ -540,7 +545,7 @@ __device__ __forceinline__ void bwd_body(const float *__restrict__ X, const floa
                 const int idx = tid_o + 256 * u;
                 const int r = idx / (kAL / 4), c4 = idx - r * (kAL / 4);
                 if (idx < kSR * (kAL / 4) && row0 + r < R)
-                    *reinterpret_cast<f32x4 *>(dz0 + (size_t)(row0 + r) * kAL + 4 * c4) = *reinterpret_cast<const f32x4 *>(Zb + r * kAL + 4 * c4);
+                    *reinterpret_cast<f32x4 *>(dz0 + (size_t)(row0 + r) * kAL + 4 * c4) = *reinterpret_cast<const f32x4 *>(Zb + act_off(r, 4 * c4));   // dz0 is row-major
             }
         }
         BWD_STAMP(1 + 2 * CH);

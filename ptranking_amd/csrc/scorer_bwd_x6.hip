@@ -229,7 +229,7 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
     float dsv[2];
     const b6_rsrc xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0, (int)((uint32_t)R * (uint32_t)(F * 4)), 0x00020000);
     const b6_rsrc dsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dpreds), 0, (int)((uint32_t)R * 4u), 0x00020000);
-    const b6_srd asrd = b6_make_srd(acts, (uint32_t)NL * (uint32_t)R * (kAL * 4));       // host: NL * R * 448 and R * F * 4 < 4 GB
+    const b6_srd asrd = b6_make_srd(acts, (uint32_t)NL * (uint32_t)(act_layer_floats(R) * 4));       // host: NL * ceil16(R) * 448 and R * F * 4 < 4 GB
     uint32_t jx = (uint32_t)j * (uint32_t)(F * 4) + (uint32_t)g * 16, j4 = (uint32_t)j * 4, l16 = (uint32_t)lane * 16;
     asm volatile("" : "+v"(jx), "+v"(j4), "+v"(l16));
     auto load_x = [&](int slab) __attribute__((always_inline)) {
@@ -267,14 +267,14 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
     // the next slab's stored activations by DMA into the staging area, its dLoss/dscore into registers
     auto prefetch = [&](int slab) __attribute__((always_inline)) {
         const int row0 = slab * kB6S;
-        // a slab image is contiguous in a layer (row stride = 448 B): 14 pieces of 1 KB per layer, 42 in all (pieces past the end of a layer's
-        // rows read the next layer / zeros: those documents carry dLoss/dscore = 0)
+        // a slab image is contiguous in a layer (two tile-major row tiles of 7 KB): 14 pieces of 1 KB per layer, 42 in all (a row tile past the
+        // end of a layer reads the next layer's first tile / zeros: those documents carry dLoss/dscore = 0)
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
             const int k = W + 8 * q;                                 // scalar
             if (k < 3 * 14) {
                 const int layer = k / 14, ch = k - 14 * layer;
-                b6_bdma16(asrd, l16, (uint32_t)layer * (uint32_t)R * (kAL * 4) + (uint32_t)row0 * (kAL * 4) + (uint32_t)ch * 1024,
+                b6_bdma16(asrd, l16, (uint32_t)layer * (uint32_t)(act_layer_floats(R) * 4) + (uint32_t)row0 * (kAL * 4) + (uint32_t)ch * 1024,
                           __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(kB6_ST + layer * kB6STG + ch * 1024)));
             }
         }
@@ -303,7 +303,8 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
             const f32x4 wo4 = *reinterpret_cast<lds_f32x4_b *>((uintptr_t)(b6_opaque(lds0 + (uint32_t)(kB6_WO + 64 * W)) + (uint32_t)(16 * g)));
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                const uint32_t so = b6_opaque(lds0 + (uint32_t)(kB6_ST + 64 * W)) + 2 * wr_z + (uint32_t)(16 * dt * kAL * 4);     // j * 448 + 16 g
+                // the staging area is a straight copy of two tile-major row tiles (ptr_mlp.h): feature tile W of row tile dt at dt * 7168 + W * 1024, lane (j, g) at j * 64 + 16 g
+                const uint32_t so = b6_opaque(lds0 + (uint32_t)(kB6_ST + 1024 * W)) + (uint32_t)(j * 64 + 16 * g) + (uint32_t)(dt * kActTile * 4);
                 const f32x4 a1 = *reinterpret_cast<lds_f32x4_b *>((uintptr_t)so);
                 const f32x4 a2 = *reinterpret_cast<lds_f32x4_b *>((uintptr_t)(so + kB6STG));
                 const f32x4 a3 = *reinterpret_cast<lds_f32x4_b *>((uintptr_t)(so + 2 * kB6STG));
@@ -461,7 +462,7 @@ static int bwd_x6_mode() {
 bool bwd_x6_supported(int R, int F, int NL, const void *X, const void *acts) {
     if (bwd_x6_mode() == 0) return false;
     const int NT1 = (F + 15) / 16;
-    if ((uint64_t)NL * (uint64_t)R * (kAL * 4) >= 0xFFFFF000ull || (uint64_t)R * (uint64_t)F * 4 >= 0xFFFFF000ull) return false;     // buffer resources: < 4 GB
+    if ((uint64_t)NL * (uint64_t)act_layer_floats(R) * 4 >= 0xFFFFF000ull || (uint64_t)R * (uint64_t)F * 4 >= 0xFFFFF000ull) return false;     // buffer resources: < 4 GB
     return NL == 3 && NT1 == 9 && F % 4 == 0 && F < 16 * NT1 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 && (reinterpret_cast<uintptr_t>(acts) & 15) == 0;
 }
 int launch_bwd_x6(const float *X, const float *params, const float *acts, const float *dpreds, const MlpArgs &a, float *ws, hipStream_t st,

@@ -116,13 +116,15 @@ __device__ __forceinline__ f32x4 x6_load16(x6_rsrc srd, uint32_t voff, uint32_t 
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)voff, (int)soff, 0));
 }
 __device__ __forceinline__ void x6_store4(x6_rsrc srd, uint32_t off, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), srd, (int)off, 0, 0); }
-constexpr uint32_t kX6Oob = 0xFFFFF000u;       // an offset no buffer of ours reaches
+constexpr uint32_t kX6Oob = 0xFFFFC000u;       // an offset no buffer of ours reaches — NOR the offset plus the largest immediate added to it
+                                               // (6 x 1 KB feature tiles of a row tile: 0xFFFFF000 + 4096 wrapped to offset 0 and wrote row 0, r5)
+constexpr uint64_t kX6BufLimit = 0xFFFFC000ull;
 
 #define X6_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16((A).v, (B).v, (C), 0, 0, 0)
 
 // =================================================================================================== forward
 // LDS: ring kX6Ring x slice | biases NL x [112] | w_out [112] | b_out + pad
-// STORE: write the post-dropout layer inputs acts [NL][R][112] (the layout scorer.hip documents; column 100 of the first NL - 1 = 1.0)
+// STORE: write the post-dropout layer inputs `acts` (tile-major, ptr_mlp.h: [NL][ceil(R/16)][7][16][16]; column 100 of the first NL - 1 = 1.0)
 //
 // Schedule of one slice step of a wave (84 MFMAs: 7 out-feature tiles x 2 document tiles x 6 plane products), one region per tile:
 //     read A(t1) | MFMA t0 + work 0 | read A(t2) | MFMA t1 + work 1 | read A(t3) | MFMA t2 + work 2 | SYNC | ... | read A(next slice, t0) | MFMA t6 + work 6
@@ -136,22 +138,7 @@ constexpr uint32_t kX6Oob = 0xFFFFF000u;       // an offset no buffer of ours re
 // next layer's B fragments) of the tile that has just finished.  Registers: nothing may spill — a scratch reload waits with vmcnt for
 // everything older, i.e. for the DMA pieces and X loads in flight (r4 trace: 9 K instead of 3.4 K cycles per step around the spills).
 #define X6_SB() __builtin_amdgcn_sched_barrier(0)
-#ifdef PTR_X6_TILEMAJOR
-#define X6_TSTRIDE 1024
-#ifdef PTR_X6_TM_HALF6
-#define X6_TBLOCK 6656u          /* tile 6 = 16 rows x 32 B (features 96..103) */
-#else
-#define X6_TBLOCK 7168u
-#endif
-#else
-#define X6_TSTRIDE 64
-#endif
-#if defined(PTR_X6_TILEMAJOR) && defined(PTR_X6_TM_HALF6)
-// tile 6 of a 16-row block: lanes g < 2 write 16 B at j * 32 + g * 16, the others nothing
-#define X6_T6FIX(o, mt) ((mt) == kMT - 1 ? ((g < 2 && (o) != kX6Oob) ? (o) - (uint32_t)lane * 16u + (uint32_t)(j * 32 + g * 16) : kX6Oob) : (o))
-#else
-#define X6_T6FIX(o, mt) (o)
-#endif
+#define X6_TSTRIDE 1024           /* bytes between the feature tiles of a row tile of the stored activations (tile-major, ptr_mlp.h) */
 // interleave hint for the region in front of it: NM x (1 MFMA, then NV VALU)
 #define X6_MIX(NM, NV)                                                                                     \
     do {                                                                                                   \
@@ -260,7 +247,7 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
     uint32_t wo_delta = (uint32_t)NL * (kHP * 4);                // Wo = Bs + NL * 112 floats: a scalar added at the (seven) uses instead of a second register
     asm volatile("" : "+s"(wo_delta));
     auto lds4 = [](uint32_t base, int byte_off) __attribute__((always_inline)) { return *reinterpret_cast<lds_f32x4 *>((uintptr_t)(base + (uint32_t)byte_off)); };
-    const uint32_t layer_bytes = (uint32_t)R * (kAL * 4);                       // host: NL * R * 448 < 2^32 - 4096
+    const uint32_t nrt = (uint32_t)act_row_tiles(R), layer_bytes = nrt * (uint32_t)(kActTile * 4);   // host: NL * layer_bytes < 2^32 - 4096
     const x6_rsrc xsrd = x6_srd(const_cast<float *>(X), (uint32_t)R * (uint32_t)(F * 4));     // host: R * F * 4 < 2^32 - 4096
     const x6_rsrc psrd = x6_srd(preds, (uint32_t)R * 4u);
     const x6_rsrc asrd = x6_srd(acts, STORE ? (uint32_t)NL * layer_bytes : 0u);
@@ -330,11 +317,16 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
     // Per-lane constants, one register each; everything that depends on the tile is a SCALAR added per use (s_mul / s_add on the scalar
     // unit, one v_add or an soffset operand on the vector side) — per-tile VGPR copies of rows, offsets and keys cost a dozen registers
     // this kernel does not have:
-    //   jX / jA   byte offset of the lane's 16 (32) bytes inside row j of X / of `acts`
+    //   jX / l16  byte offset of the lane's 32 bytes inside row j of X / of its 16 bytes inside a (16 rows x 16 features) block of `acts`
+    //             (row j at 64 j, its features 4 g .. + 3 at + 16 g: the block is one contiguous KB per store instruction either way)
     //   jH / jK   dropout key parts  j * kDropRowMul + g * kDropFgMul + seed_lo (hidden sites, fg = 4 mt + g) / with 2 g (X site, fg = 8 s + 2 g + h)
-    uint32_t jX = (uint32_t)j * (uint32_t)(F * 4) + (uint32_t)g * 32, jA = (uint32_t)j * (kAL * 4) + (uint32_t)g * 16;
+#ifdef PTR_X6_LANE_LINEAR   // timing experiment (wrong block layout): lane l at byte 16 l of its (16 rows x 16 features) block
+    uint32_t jX = (uint32_t)j * (uint32_t)(F * 4) + (uint32_t)g * 32, l16 = (uint32_t)lane * 16;
+#else
+    uint32_t jX = (uint32_t)j * (uint32_t)(F * 4) + (uint32_t)g * 32, l16 = (uint32_t)(j * 64 + g * 16);   // row j, features 4 g .. + 3 of the block
+#endif
     uint32_t jH = (uint32_t)j * kDropRowMul + (uint32_t)g * kDropFgMul + a.seed_lo, jK = jH + (uint32_t)g * kDropFgMul;
-    asm volatile("" : "+v"(jX), "+v"(jA), "+v"(jH), "+v"(jK));
+    asm volatile("" : "+v"(jX), "+v"(l16), "+v"(jH), "+v"(jK));
     // quarter q = (dt, h) of slice s of the 32 documents from row t32 on: the float4 a lane contributes to the B fragment.  X is read through
     // a buffer resource: rows past R and columns past F get an out-of-range offset (zeros)
     auto load_xq = [&](f32x4 (&rw)[DT][2], int t32, int s, int q) __attribute__((always_inline)) {
@@ -399,12 +391,13 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
         const int tile = tile_of(it), tile_next = tile_of(it + 1);
         const int t32 = tile * RPT, t32n = tile_next * RPT;        // first row of this / the next tile
         auto store_off = [&](int layer, int dt) __attribute__((always_inline)) {       // opaque: `+ 64 mt` stays an immediate instead of seven hoisted select operands
+            // tile-major: this wave's 16-row tile is 7 contiguous KB, a store instruction = lane * 16 + 1024 * feature tile.  Whole tiles are
+            // written (rows past R of the last tile hold finite values nobody uses); tiles past the last one get an out-of-range offset
+            const uint32_t rt = (uint32_t)(t32 + 16 * dt) >> 4;
 #ifdef PTR_X6_L2STORE      // ablation: the same store instructions, aimed at an L2-resident part of the buffer
-            uint32_t o = j < R - t32 - 16 * dt ? jA + ((uint32_t)((t32 + 16 * dt) & 2047) * (kAL * 4)) : kX6Oob;
-#elif defined(PTR_X6_TILEMAJOR)   // timing experiment: every store instruction writes ONE contiguous KB (tile-major [R/16][7][16 rows][16 features])
-            uint32_t o = j < R - t32 - 16 * dt ? (uint32_t)lane * 16u + ((uint32_t)((t32 + 16 * dt) >> 4) * X6_TBLOCK + (uint32_t)layer * layer_bytes) : kX6Oob;
+            uint32_t o = rt < nrt ? l16 + ((rt & 127u) * (uint32_t)(kActTile * 4)) : kX6Oob;
 #else
-            uint32_t o = j < R - t32 - 16 * dt ? jA + ((uint32_t)(t32 + 16 * dt) * (kAL * 4) + (uint32_t)layer * layer_bytes) : kX6Oob;
+            uint32_t o = rt < nrt ? l16 + (rt * (uint32_t)(kActTile * 4) + (uint32_t)layer * layer_bytes) : kX6Oob;
 #endif
             asm volatile("" : "+v"(o));
             return o;
@@ -426,7 +419,7 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
                     f32x4 o = h;
                     if (mt == kMT - 1 && g == 1) o[0] = 1.0f;              // the ones column (100) of the fused backward
 #ifndef PTR_X6_NOSTORE
-                    x6_store16(asrd, X6_T6FIX(store_off(site - 1, dt), mt) + X6_TSTRIDE * mt, o);
+                    x6_store16(asrd, store_off(site - 1, dt) + X6_TSTRIDE * mt, o);
 #endif
                 }
                 split_pack4(h, bp[mt >> 1][dt], 2 * (mt & 1));
@@ -458,7 +451,7 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
                 for (int c = 0; c < 4; ++c) { h[c] = relu1(h[c]); sc[dt] = fmaf(h[c], w4[c], sc[dt]); }
                 if constexpr (STORE) {
 #ifndef PTR_X6_NOSTORE
-                    x6_store16(asrd, X6_T6FIX(store_off(NL - 1, dt), mt) + X6_TSTRIDE * mt, h);
+                    x6_store16(asrd, store_off(NL - 1, dt) + X6_TSTRIDE * mt, h);
 #endif
                 }
             }
@@ -562,12 +555,12 @@ extern "C" int ptr_mlp_forward_x6(const float *X, const float *params, int R, in
         set_error("%s: X, acts and wimg must be 16-byte aligned", who); return PTR_ERR_INVALID_ARG;
     }
     if (R == 0) return 0;
-    if ((uint64_t)R * (uint64_t)F * 4 >= 0xFFFFF000ull) {
+    if ((uint64_t)R * (uint64_t)F * 4 >= kX6BufLimit) {
         set_error("%s: R * F * 4 bytes of X exceed the 4 GB a buffer resource addresses (R=%d, F=%d): split the batch", who, R, F);
         return PTR_ERR_UNSUPPORTED;
     }
-    if (train && (uint64_t)NL * (uint64_t)R * (kAL * 4) >= 0xFFFFF000ull) {
-        set_error("%s: NL * R * 448 bytes of activations exceed the 4 GB a buffer resource addresses (R=%d): split the batch", who, R);
+    if (train && (uint64_t)NL * (uint64_t)act_layer_floats(R) * 4 >= kX6BufLimit) {
+        set_error("%s: NL * ceil16(R) * 448 bytes of activations exceed the 4 GB a buffer resource addresses (R=%d): split the batch", who, R);
         return PTR_ERR_UNSUPPORTED;
     }
     MlpArgs a{R, F, NL, train ? p_drop : 0.0f, (uint32_t)seed, (uint32_t)(seed >> 32)};

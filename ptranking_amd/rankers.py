@@ -18,7 +18,7 @@ from . import dp
 from . import functional as F_
 from .host import DeviceEvaluator, DeviceTrainLoop, PointScorerRanker, is_multilabel
 from .listsf import FusedListScorerMixin
-from .scorer import FlatAdagrad, FlatAdam, FlatRMSprop, FusedPointScorer, FusedScorerMixin, mlp_forward
+from .scorer import FlatAdagrad, FlatAdam, FlatRMSprop, FusedPointScorer, FusedScorerMixin, alloc_acts, mlp_forward
 
 RANKER_NAMES = ("RankNet", "LambdaRank", "LambdaLoss", "ApproxNDCG", "ListNet", "ListMLE", "STListNet", "RankCosine", "RankMSE", "SoftRank")
 # SURVEY.md 2 marks these OUT OF SCOPE (the reference's driver cannot reach them): kept as classes for whoever asks for them by name
@@ -89,7 +89,7 @@ class FusedStepMixin:
             if len(cache) >= 4:                      # a few length buckets at most: do not pin scratch for every shape ever seen
                 cache.pop(next(iter(cache)))
             ndz = _lib.query("ptr_mlp_backward_dz_floats", R, Fd, NL)
-            buf = dict(preds=torch.empty((B, L), device=dev), acts=torch.empty((NL, R, 112), device=dev),
+            buf = dict(preds=torch.empty((B, L), device=dev), acts=alloc_acts(R, NL, dev),
                        loss_q=torch.empty(max(B, 1), device=dev), dpreds=torch.empty((B, L), device=dev),
                        ws=torch.empty(_lib.query("ptr_mlp_backward_ws_floats", Fd, NL), device=dev),
                        dz=torch.empty(ndz, device=dev) if ndz else None)

@@ -19,7 +19,22 @@ from . import _lib
 from . import dp
 
 HIDDEN = 100   # ptranking/base/point_ranker.py:30
-ACT_LD = 112   # PTR_MLP_ACT_LD: leading dimension of the stored activations / dZ scratch
+ACT_LD = 112   # PTR_MLP_ACT_LD: padded features per row of the stored activations / leading dimension of the dZ scratch
+
+
+def acts_floats(R, NL):
+    """Floats of the stored-activation buffer of an R-row, NL-layer training forward: NL * ceil16(R) * 112 (tile-major, include/ptranking_amd.h)."""
+    return NL * ((R + 15) // 16) * 16 * ACT_LD
+
+
+def alloc_acts(R, NL, device):
+    return torch.empty(acts_floats(R, NL), device=device, dtype=torch.float32)
+
+
+def acts_rowmajor(acts, R, NL):
+    """[NL, R, 112] row-major copy of a tile-major activation buffer (tests / debugging)."""
+    T = (R + 15) // 16
+    return acts[:NL * T * 16 * ACT_LD].view(NL, T, 7, 16, 16).permute(0, 1, 3, 2, 4).reshape(NL, T * 16, ACT_LD)[:, :R]
 
 
 _STACK_AF = {'R', 'LR', 'E', 'SE', 'CE', 'GE', 'S', 'T'}      # the working entries of get_AF (utils.py:100-143) minus the random RReLU
@@ -62,7 +77,7 @@ def x6_mode():
     return os.environ.get("PTR_MLP_X6", "1")
 
 
-X6_BUFFER_LIMIT = 0xFFFFF000      # bytes a buffer resource of ptr_mlp_forward_x6 addresses (scorer_x6.hip: X and the stored activations)
+X6_BUFFER_LIMIT = 0xFFFFC000      # bytes a buffer resource of ptr_mlp_forward_x6 addresses (scorer_x6.hip: X and the stored activations)
 
 
 def x6_serves(X2d, R, F, NL, train):
@@ -72,7 +87,7 @@ def x6_serves(X2d, R, F, NL, train):
         return False
     if R * F * 4 >= X6_BUFFER_LIMIT:
         return False
-    if train and NL * R * ACT_LD * 4 >= X6_BUFFER_LIMIT:
+    if train and acts_floats(R, NL) * 4 >= X6_BUFFER_LIMIT:
         return False
     return True
 
@@ -113,7 +128,7 @@ class _ScorerFn(torch.autograd.Function):
         dev = X2d.device
         preds = torch.empty(R, device=dev, dtype=torch.float32)
         train = bool(store or p > 0.0)
-        acts = torch.empty((NL, R, ACT_LD), device=dev, dtype=torch.float32) if train else None
+        acts = alloc_acts(R, NL, dev) if train else None
         with torch.cuda.device(dev):
             mlp_forward(X2d, flat, R, F, NL, train, p, seed, preds, acts, dev)
         if store:

@@ -2,12 +2,13 @@
 import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ptranking_amd import _lib
+from ptranking_amd import scorer as _scorer
 from ptranking_amd.scorer import FusedPointScorer, x6_workspace
 NL, F, R = 3, int(os.environ.get("F", 136)), int(os.environ.get("R", 524288))
 torch.manual_seed(0)
 fused = FusedPointScorer(F, num_layers=NL, dropout=0.1).cuda()
 Xs = [torch.randn(R, F, device="cuda") for _ in range(4)]
-preds = torch.empty(R, device="cuda"); acts = torch.empty(NL, R, 112, device="cuda")
+preds = torch.empty(R, device="cuda"); acts = _scorer.alloc_acts(R, NL, "cuda")
 ws = x6_workspace(Xs[0].device, F, NL)
 st = _lib.current_stream(Xs[0].device)
 out = []

@@ -4,6 +4,8 @@ with identical weights and — in training mode — the identical dropout masks 
 import pytest
 import torch
 
+from ptranking_amd import scorer as _scorer
+
 pytestmark = pytest.mark.gpu
 
 
@@ -297,7 +299,7 @@ def test_two_pass_backward_equals_the_layer_wise_kernels(F, NL, R, p, monkeypatc
     torch.manual_seed(F + R)
     fused = FusedPointScorer(F, num_layers=NL, dropout=p).cuda()
     X = torch.randn(R, F, device="cuda"); w = torch.randn(R, device="cuda")
-    preds = torch.empty(R, device="cuda"); acts = torch.empty(NL, R, 112, device="cuda")
+    preds = torch.empty(R, device="cuda"); acts = _scorer.alloc_acts(R, NL, "cuda")
     st = _lib.current_stream(X.device)
     seed = 77 + R
     _lib.call("ptr_mlp_forward", _lib.ptr(X), _lib.ptr(fused.flat.data), R, F, NL, 1, C.c_float(p), C.c_uint64(seed), _lib.ptr(preds), _lib.ptr(acts), st)

@@ -7,6 +7,8 @@ import ctypes as C
 import pytest
 import torch
 
+from ptranking_amd import scorer as _scorer
+
 pytestmark = pytest.mark.gpu
 
 
@@ -42,7 +44,7 @@ def _forward(fused, X, NL, train, seed, x6):
     from ptranking_amd.scorer import x6_workspace
     R, F = X.shape
     preds = torch.empty(R, device="cuda")
-    acts = torch.full((NL, R, 112), float("nan"), device="cuda") if train else None
+    acts = torch.full((_scorer.acts_floats(R, NL),), float("nan"), device="cuda") if train else None
     st = _lib.current_stream(X.device)
     if x6:
         ws = x6_workspace(X.device, F, NL)
@@ -74,7 +76,8 @@ def test_x6_forward_matches_float64_modules(F, NL, R, train):
     err = float((preds.double().cpu() - exp).abs().max())
     assert err <= 2e-5 * scale, (err, scale)
     if train:
-        assert not torch.isnan(acts).any(), "every activation row / padding column must be written"
+        assert not torch.isnan(acts).any(), "every activation row (of whole 16-row tiles) / padding column must be written"
+        acts = _scorer.acts_rowmajor(acts, R, NL)                   # the buffer is tile-major (include/ptranking_amd.h)
         for l in range(NL):
             e = float((acts[l, :, :100].double().cpu() - eacts[l]).abs().max())
             assert e <= 2e-5 * max(1.0, float(eacts[l].abs().max())), (l, e)
@@ -82,6 +85,7 @@ def test_x6_forward_matches_float64_modules(F, NL, R, train):
             assert torch.all(acts[l, :, 100] == ones) and torch.all(acts[l, :, 101:] == 0.0)
         if F % 4 == 0 and not (F == 140 and NL == 5):               # where the fp32-MFMA forward serves the shape too: same gates
             _, acts_old = _forward(fused, X, NL, True, seed, x6=False)
+            acts_old = _scorer.acts_rowmajor(acts_old, R, NL)
             flips = sum(int(((acts[l, :, :100] > 0) != (acts_old[l, :, :100] > 0)).sum()) for l in range(NL))
             assert flips <= max(4, R * 100 * NL // 1_000_000), flips   # only pre-activations at rounding distance of the ReLU kink may differ
 
@@ -176,7 +180,7 @@ def test_x6_backward_matches_float64_modules_and_the_fp32_kernel(F, R, p, monkey
     w = torch.randn(R, device="cuda")
     seed = 99 + R
     preds = torch.empty(R, device="cuda")
-    acts = torch.empty(NL, R, 112, device="cuda")
+    acts = _scorer.alloc_acts(R, NL, "cuda")
     st = _lib.current_stream(X.device)
     _lib.call("ptr_mlp_forward", _lib.ptr(X), _lib.ptr(fused.flat.data), R, F, NL, 1, C.c_float(p), C.c_uint64(seed), _lib.ptr(preds), _lib.ptr(acts), st)
     ws = torch.empty(_lib.query("ptr_mlp_backward_ws_floats", F, NL), device="cuda")
@@ -223,7 +227,7 @@ def test_x6_backward_is_bit_stable_and_opt_in(monkeypatch):
     F, NL, R = 136, 3, 32768 + 11
     fused = FusedPointScorer(F, num_layers=NL, dropout=0.1).cuda()
     X = torch.randn(R, F, device="cuda"); w = torch.randn(R, device="cuda")
-    preds = torch.empty(R, device="cuda"); acts = torch.empty(NL, R, 112, device="cuda")
+    preds = torch.empty(R, device="cuda"); acts = _scorer.alloc_acts(R, NL, "cuda")
     st = _lib.current_stream(X.device)
     _lib.call("ptr_mlp_forward", _lib.ptr(X), _lib.ptr(fused.flat.data), R, F, NL, 1, C.c_float(0.1), C.c_uint64(5), _lib.ptr(preds), _lib.ptr(acts), st)
     ws = torch.empty(_lib.query("ptr_mlp_backward_ws_floats", F, NL), device="cuda")
@@ -261,7 +265,7 @@ def test_x6_wide_dw_matches_float64_modules_and_the_fp32_kernel(F, NL, R, p, mon
     w = torch.randn(R, device="cuda")
     seed = 4242 + R
     preds = torch.empty(R, device="cuda")
-    acts = torch.empty(NL, R, 112, device="cuda")
+    acts = _scorer.alloc_acts(R, NL, "cuda")
     st = _lib.current_stream(X.device)
     _lib.call("ptr_mlp_forward", _lib.ptr(X), _lib.ptr(fused.flat.data), R, F, NL, 1, C.c_float(p), C.c_uint64(seed), _lib.ptr(preds), _lib.ptr(acts), st)
     ws = torch.empty(_lib.query("ptr_mlp_backward_ws_floats", F, NL), device="cuda")
