@@ -9,6 +9,7 @@
 //     different grades contributes exactly one term, seen from its winner);
 //   * clamp(min=1e-8) before and after the power, log2 (not ln), score differences clamped to +-1e8, NaN -> 0.
 #include "ptr_device.h"
+#include "ptr_dropout.h"          // f32x4
 
 namespace ptr {
 
@@ -209,6 +210,124 @@ lambdaloss_kernel(const float *__restrict__ preds, const float *__restrict__ lab
     }
 }
 
+// r5: NDCG_Loss2 / Loss2++ with a SMALL cut-off (kk = min(k, n) <= 11: the default k = 5 of BASELINE config 5) on presorted labels.  Only
+// the kk best-scored documents enter the loss (lambdaloss.py:127-128: both predicted ranks < k), so no sort: kk rounds of a wavefront
+// arg-max (score descending, document index ascending on ties — the order count_ranks gives) pick them, their kk (kk - 1) / 2 pairs are
+// evaluated ONE PAIR PER LANE with the arithmetic of lambdaloss_kernel's pair body, and the gradient row is zeros plus kk patched
+// entries.  One wavefront per query, everything in registers, float4 loads / stores; the IDCG is the only full-length pass.
+template <int V>
+__global__ void __launch_bounds__(kBlock)
+lambdaloss_topk_kernel(const float *__restrict__ preds, const float *__restrict__ labels, const int32_t *__restrict__ lens, int B, int L,
+                       int k, float sigma, float mu, int loss_type, float *__restrict__ loss_q, float *__restrict__ grad) {
+    constexpr int E = 4 * V;
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (q >= B) return;                                            // waves are independent
+    const int n = query_len(lens, q, L), L4 = L >> 2;
+    const f32x4 *ps = reinterpret_cast<const f32x4 *>(preds + (size_t)q * L), *py = reinterpret_cast<const f32x4 *>(labels + (size_t)q * L);
+    float s[E], y[E];
+    float part = 0.0f;
+#pragma unroll
+    for (int m = 0; m < V; ++m) {
+        const int c = lane + 64 * m;
+        const f32x4 a = ps[c < L4 ? c : 0], b = py[c < L4 ? c : 0];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = 4 * c + e;
+            const bool in = i < n;
+            s[4 * m + e] = in ? a[e] : -INFINITY;
+            y[4 * m + e] = in ? b[e] : 0.0f;
+            part += in ? (__builtin_amdgcn_exp2f(b[e]) - 1.0f) * inv_log2_pos(i) : 0.0f;   // IDCG of the (presorted = ideal) label order,
+            // adhoc_metric.py:205-217 (2^l - 1 on v_exp_f32: exact for the integer grades, 1 ulp otherwise)
+        }
+    }
+    const float idcg = wave_sum_dpp(part);
+    const int kk = k < n ? (k < 0 ? 0 : k) : n;
+    // ---- the kk best documents, in rank order: record r lives in lane r
+    float rs = 0.0f, ry = 0.0f;
+    int ri = -1;
+    for (int r = 0; r < kk; ++r) {
+        float best = -INFINITY, blab = 0.0f;
+        int bidx = 0x7fffffff;
+#pragma unroll
+        for (int m = 0; m < V; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = 4 * (lane + 64 * m) + e;
+                const bool live = i < n && s[4 * m + e] == s[4 * m + e];           // NaN scores never win (the reference sorts them last)
+                const bool better = live && (bidx == 0x7fffffff || s[4 * m + e] > best);
+                best = better ? s[4 * m + e] : best; blab = better ? y[4 * m + e] : blab; bidx = better ? i : bidx;
+            }
+        const float gmax = wave_max_dpp(bidx == 0x7fffffff ? -INFINITY : best);   // DPP ladders: no LDS crossbar round trips in the selection
+        const int cand = wave_min_i32_dpp((bidx != 0x7fffffff && best == gmax) ? bidx : 0x7fffffff);
+        if (cand == 0x7fffffff) break;                                              // fewer than kk rankable documents (all NaN)
+        const uint64_t own = __builtin_amdgcn_ballot_w64(bidx == cand);
+        const int wl = (int)__builtin_ctzll(own);
+        const float wlab = __shfl(blab, wl, 64);
+        if (lane == r) { rs = gmax; ry = wlab; ri = cand; }
+#pragma unroll
+        for (int m = 0; m < V; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * (lane + 64 * m) + e == cand) s[4 * m + e] = __builtin_nanf("");   // taken: never live again
+    }
+    // ---- pairs (a < b < kk), one per lane; arithmetic of lambdaloss_kernel's pair body
+    const float eps = 1e-8f, inv_ln2 = 1.4426950408889634f, log2_eps = -26.575424759098897f;
+    const float rG = ri >= 0 ? (__builtin_amdgcn_exp2f(ry) - 1.0f) / idcg : 0.0f;          // lambdaloss.py:106
+    const float rinv = 1.0f / (1.0f / log2f((float)lane + 2.0f));                          // inv[rank], rank = lane (lambdaloss.py:41,49,94)
+    const int npairs = kk * (kk - 1) / 2;
+    int a = 0, rem = lane;
+    for (int it = 0; it < 11; ++it) { const int row = kk - 1 - a; if (rem >= row && row > 0) { rem -= row; ++a; } }
+    const bool has = lane < npairs;
+    const int b = has ? a + 1 + rem : 0;
+    const int aa = has ? a : 0;
+    const float sa = __shfl(rs, aa, 64), sb = __shfl(rs, b, 64), ya = __shfl(ry, aa, 64), yb = __shfl(ry, b, 64);
+    const float Ga = __shfl(rG, aa, 64), Gb = __shfl(rG, b, 64), ia = __shfl(rinv, aa, 64), ib = __shfl(rinv, b, 64);
+    const int dist = b - aa;
+    const float id0 = __shfl(rinv, dist > 0 ? dist - 1 : 0, 64), id1 = __shfl(rinv, dist, 64);
+    float lacc = 0.0f, g_a = 0.0f;
+    const bool a_wins = ya > yb, b_wins = yb > ya;                                        // lambdaloss.py:127-128
+    if (has && (a_wins || b_wins)) {
+        const float delta = fabsf(id0 - id1);
+        const float absG = fabsf(Ga - Gb);
+        float w = delta * absG;                                                            // NDCG_Loss2, :44
+        if (loss_type == PTR_LAMBDALOSS_NDCG_LOSS2PP) w = (fabsf(ia - ib) + mu * delta) * absG;   // :57
+        float df = a_wins ? sa - sb : sb - sa;
+        df = fminf(fmaxf(df, -1e8f), 1e8f);
+        if (df != df) df = 0.0f;                                                           // :115-116
+        const float x = sigma * df;
+        const float p0 = 1.0f / (1.0f + expf(-x));
+        const float lp = p0 >= eps ? -log1pf(expf(-x)) * inv_ln2 : log2_eps;
+        const float z = w * lp;
+        const bool wp_ok = z >= log2_eps;
+        lacc = -(wp_ok ? z : log2_eps);                                                    // :118-119,132
+        float g = 0.0f;
+        if (p0 >= eps && wp_ok) g = -(w * sigma * (1.0f - p0)) * inv_ln2;
+        g_a = a_wins ? g : -g;                                                             // d loss / d s_a; s_b gets the negative
+    }
+    const float loss = wave_sum_dpp(lacc);
+    // ---- gradient row: zeros + the kk records' entries
+    f32x4 o[V];
+#pragma unroll
+    for (int m = 0; m < V; ++m) o[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < kk; ++r) {
+        const float gr = wave_sum_dpp((has && aa == r ? g_a : 0.0f) - (has && b == r ? g_a : 0.0f));
+        const int idx = __shfl(ri, r, 64);
+#pragma unroll
+        for (int m = 0; m < V; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * (lane + 64 * m) + e == idx) o[m][e] = gr;
+    }
+    f32x4 *go = reinterpret_cast<f32x4 *>(grad + (size_t)q * L);
+#pragma unroll
+    for (int m = 0; m < V; ++m) {
+        const int c = lane + 64 * m;
+        if (c < L4) go[c] = o[m];
+    }
+    if (lane == 0) loss_q[q] = loss;
+}
+
 }  // namespace ptr
 
 extern "C" int ptr_lambdaloss_fwd_bwd(const float *preds, const float *labels, const int32_t *lens, int B, int L, int k,
@@ -223,7 +342,17 @@ extern "C" int ptr_lambdaloss_fwd_bwd(const float *preds, const float *labels, c
         return PTR_ERR_INVALID_ARG;
     }
     hipStream_t st = as_stream(stream);
-    if (B > 0) {
+    static const bool topk_off = [] { const char *e = getenv("PTR_LAMBDALOSS_TOPK"); return e && atoi(e) == 0; }();
+    const bool topk = !topk_off && presort && k <= 11 && loss_type != PTR_LAMBDALOSS_NDCG_LOSS1 && L % 4 == 0 && L <= 1024 &&
+                      ((reinterpret_cast<uintptr_t>(preds) | reinterpret_cast<uintptr_t>(labels) | reinterpret_cast<uintptr_t>(grad)) & 15) == 0;
+    if (B > 0 && topk) {
+        // small cut-off on presorted labels: wavefront arg-max selection instead of a sort, one pair per lane (lambdaloss_topk_kernel)
+        auto go = [&](auto kern) -> int {
+            hipLaunchKernelGGL(kern, dim3((B + 3) / 4), dim3(kBlock), 0, st, preds, labels, lens, B, L, k, sigma, mu, loss_type, loss_q, grad);
+            return check_hip(hipGetLastError(), who);
+        };
+        if (int rc = L <= 256 ? go(lambdaloss_topk_kernel<1>) : (L <= 512 ? go(lambdaloss_topk_kernel<2>) : go(lambdaloss_topk_kernel<4>))) return rc;
+    } else if (B > 0) {
         // one wavefront per query up to 256 documents (ranks from a register bitonic sort, one accumulator row), four beyond
         int rc = dispatch_wave256_tiling(L, [&]<int G, int DPT>() -> int {
             constexpr int QPB = kBlock / G, NW = G / kWave;

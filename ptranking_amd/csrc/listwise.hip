@@ -496,6 +496,13 @@ __device__ __forceinline__ uint32_t mix64(uint64_t x) {      // splitmix64 final
     return (uint32_t)(x >> 16);
 }
 
+// r5: the random field of a document from 32-bit arithmetic — one lowbias32 finaliser per document on a per-query key (the splitmix64
+// finaliser above costs two 64-bit multiplies per document: six quarter-rate 32-bit multiplies; the shuffle kernel was issue-bound on them)
+__device__ __forceinline__ uint32_t tie_query_key(uint64_t seed, uint32_t q) {
+    return lowbias32((uint32_t)seed ^ lowbias32((uint32_t)(seed >> 32) + q * 0x9E3779B1u));
+}
+__device__ __forceinline__ uint32_t tie_hash(uint32_t qkey, uint32_t i) { return lowbias32(qkey + i * 0x85EBCA77u); }
+
 // perm = argsort by (label descending, random key ascending, index ascending): a uniformly random order inside every
 // group of equal labels — the distribution arg_shuffle_ties draws from (sampling_utils.py:13-28).
 // Integer grades in [0, 63] (MultiLabel) take the fast path: label and an 18-bit random field are packed into ONE float key
@@ -517,28 +524,34 @@ shuffle_ties_kernel(const float *__restrict__ labels, const int32_t *__restrict_
     float y[DPT], key[DPT];
     uint32_t r[DPT];
     bool small_int = true;
+    const uint32_t qkey = tie_query_key(seed, (uint32_t)q);
 #pragma unroll
     for (int m = 0; m < DPT; ++m) {
         const int i = t + m * G;
         const bool in = i < n;
         y[m] = in ? labels[(size_t)q * L + i] : 0.0f;
-        r[m] = mix64(seed ^ ((uint64_t)q * 0x100000001B3ull + (uint64_t)i) * 0xD6E8FEB86659FD93ull);
+        r[m] = tie_hash(qkey, (uint32_t)i);
         small_int &= !in || (y[m] >= 0.0f && y[m] < 64.0f && y[m] == floorf(y[m]));
         key[m] = in ? y[m] * 262144.0f + (float)(262143u - (r[m] >> 14)) : -INFINITY;
     }
-    // one decision per workgroup keeps the barriers below uniform
-    int *all_small = reinterpret_cast<int *>(smem + (size_t)QPB * 3 * Lp);   // carved from the dynamic region (no static LDS in
-    if (tid == 0) *all_small = 1;                                            // front of it: keeps the float4 tiles 16-byte aligned)
-    __syncthreads();
-    if (!small_int) *all_small = 0;
-    __syncthreads();
-    const bool fast = *all_small != 0;
+    bool fast;
+    if constexpr (G == kWave) {
+        fast = __all(small_int);                  // one wavefront per query: the waves of a block are independent, no workgroup barrier anywhere
+    } else {
+        // one decision per workgroup keeps the barriers below uniform
+        int *all_small = reinterpret_cast<int *>(smem + (size_t)QPB * 3 * Lp);   // carved from the dynamic region (no static LDS in
+        if (tid == 0) *all_small = 1;                                            // front of it: keeps the float4 tiles 16-byte aligned)
+        __syncthreads();
+        if (!small_int) *all_small = 0;
+        __syncthreads();
+        fast = *all_small != 0;
+    }
 #pragma unroll
     for (int m = 0; m < DPT; ++m) {
         const int i = t + m * G;
         if (i < Lp) { keys[i] = fast ? key[m] : (i < n ? y[m] : -INFINITY); rnd[i] = r[m]; }
     }
-    __syncthreads();
+    if constexpr (G == kWave) wave_lds_sync(); else __syncthreads();
     int rk[DPT];
     if (fast) {
         // integer keys below 2^24; field collisions (equal keys) recount exactly inside either form
@@ -568,7 +581,7 @@ shuffle_ties_kernel(const float *__restrict__ labels, const int32_t *__restrict_
         const int i = t + m * G;
         if (i < n) out[rk[m]] = i;
     }
-    __syncthreads();
+    if constexpr (G == kWave) wave_lds_sync(); else __syncthreads();
     if (valid) {
 #pragma unroll
         for (int m = 0; m < DPT; ++m) {

@@ -36,7 +36,7 @@ sort_desc_kernel(const float *__restrict__ preds, const int32_t *__restrict__ le
         own[m] = i < n ? preds[(size_t)q * L + i] : -INFINITY;
         if (i < Lp) keys[i] = own[m];
     }
-    __syncthreads();
+    if constexpr (G == kWave) wave_lds_sync(); else __syncthreads();               // one wavefront per query: no workgroup barrier (r5)
     if constexpr (G == kWave) count_ranks_wave<DPT>(keys, sv, n, Lp, t, own, rk);   // leaves sv = keys in descending order
     else count_ranks_fast<G, DPT>(keys, si_, n, t, own, rk);      // si_ doubles as the permutation-check scratch before it is filled
     if constexpr (G == kWave) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
@@ -46,7 +46,7 @@ sort_desc_kernel(const float *__restrict__ preds, const int32_t *__restrict__ le
         const int i = t + m * G;
         if (i < n) { sv[rk[m]] = own[m]; si_[rk[m]] = i; }
     }
-    __syncthreads();
+    if constexpr (G == kWave) wave_lds_sync(); else __syncthreads();
     if (valid) {
 #pragma unroll
         for (int m = 0; m < DPT; ++m) {
@@ -88,7 +88,9 @@ batch_max_kernel(const float *__restrict__ labels, const int32_t *__restrict__ l
 // 2^l - 1 on the transcendental pipe alone (v_exp_f32: exact for the integer grades, 1 ulp otherwise; labels are far from its denormal range)
 __device__ __forceinline__ float gain_fast(float label) { return __builtin_amdgcn_exp2f(label) - 1.0f; }
 // LDS per group (floats): S_id[Lp] | Y_id[Lp] | Y_sys[Lp]
-template <int G, int DPT>
+// WHICH: compile-time set of requested metrics (bit 0 nDCG, 1 nERR, 2 AP, 3 P) for the sets the Evaluator asks for (one metric, or all
+// four); -1 = decided at run time from the output pointers.  The walk's nine prefix scans shrink to the ones the set needs (r5).
+template <int G, int DPT, int WHICH>
 __global__ void __launch_bounds__(kBlock)
 metrics_kernel(const float *__restrict__ preds, const float *__restrict__ labels, const int32_t *__restrict__ lens, int B, int L,
                int Lp, Cutoffs ck, int presort, int linear_gain, float max_label_host, const float *__restrict__ max_label_dev,
@@ -117,7 +119,7 @@ metrics_kernel(const float *__restrict__ preds, const float *__restrict__ labels
         const int i = t + m * G;
         if (i < Lp) S_id[i] = si[m];
     }
-    __syncthreads();
+    if constexpr (G == kWave) wave_lds_sync(); else __syncthreads();       // one wavefront per query: its LDS region is its own
     int rk[DPT];
     // ranks by packed fma-clamp counting (one VALU slot per compare; ties / overflow fall back to the exact compares) — the O(L^2) count
     // is what the kernel's time is made of: 0.54 -> 0.2 ms for 65 536 x 256.  Y_id (not staged yet) is the permutation-check scratch.
@@ -128,7 +130,7 @@ metrics_kernel(const float *__restrict__ preds, const float *__restrict__ labels
         const int i = t + m * G;
         if (i < n) Y_sys[rk[m]] = li[m];                    // torch.gather(labels, idx), ranker.py:52
     }
-    __syncthreads();
+    if constexpr (G == kWave) wave_lds_sync(); else __syncthreads();
     if constexpr (G == kWave) {
         // only the ideal LABELS are walked below, and equal labels are interchangeable: a value-only sort, no tie handling
         (void)ipos;
@@ -149,7 +151,7 @@ metrics_kernel(const float *__restrict__ preds, const float *__restrict__ labels
 #pragma unroll
             for (int r = 0; r < DPT; ++r) { if (t * DPT + r < Lp) Y_id[t * DPT + r] = t * DPT + r < n ? v[r] : 0.0f; }
         }
-        __syncthreads();
+        wave_lds_sync();
     } else {
         stage_ideal_order<G, DPT>(S_id, Y_id, n, Lp, t, presort != 0, si, li, ipos);   // ends with a barrier
     }
@@ -159,10 +161,12 @@ metrics_kernel(const float *__restrict__ preds, const float *__restrict__ labels
         const int lane = t;
         const float max_label = max_label_dev ? ordered_to_float(reinterpret_cast<const int *>(max_label_dev)[0]) : max_label_host;
         const float rpow_max = 1.0f / exp2f(max_label);      // adhoc_metric.py:133 (2^max_label: the reciprocal of a power of two is exact)
-        float *r_ndcg = o_ndcg ? o_ndcg + (size_t)q * ck.nk : nullptr;
-        float *r_nerr = o_nerr ? o_nerr + (size_t)q * ck.nk : nullptr;
-        float *r_ap = o_ap ? o_ap + (size_t)q * ck.nk : nullptr;
-        float *r_p = o_p ? o_p + (size_t)q * ck.nk : nullptr;
+        const bool w_ndcg = WHICH < 0 ? o_ndcg != nullptr : (WHICH & 1) != 0, w_nerr = WHICH < 0 ? o_nerr != nullptr : (WHICH & 2) != 0;
+        const bool w_ap = WHICH < 0 ? o_ap != nullptr : (WHICH & 4) != 0, w_p = WHICH < 0 ? o_p != nullptr : (WHICH & 8) != 0;
+        float *r_ndcg = w_ndcg ? o_ndcg + (size_t)q * ck.nk : nullptr;
+        float *r_nerr = w_nerr ? o_nerr + (size_t)q * ck.nk : nullptr;
+        float *r_ap = w_ap ? o_ap + (size_t)q * ck.nk : nullptr;
+        float *r_p = w_p ? o_p + (size_t)q * ck.nk : nullptr;
         int used = 0;
         for (int c = 0; c < ck.nk; ++c) used += (ck.k[c] >= 1 && ck.k[c] <= n) ? 1 : 0;
         if (lane < ck.nk && lane >= used) {                  // zero padding goes last (adhoc_metric.py:255-258)
@@ -182,23 +186,32 @@ metrics_kernel(const float *__restrict__ preds, const float *__restrict__ labels
             const float rdisc = __builtin_amdgcn_rcpf(__builtin_amdgcn_logf((float)r + 2.0f));   // 1 / log2(rank + 2): v_log_f32, v_rcp_f32 (1 ulp each)
             // DCG gain: 2^l - 1 for graded labels, the raw label for LABEL_TYPE.Permutation (adhoc_metric.py:207-212,225-230)
             const float gs = in ? (linear_gain ? ys : gain_fast(ys)) : 0.0f, gi = in ? (linear_gain ? yi : gain_fast(yi)) : 0.0f;
-            const float sdcg = wave_incl_sum(in ? gs * rdisc : 0.0f, lane) + c_sdcg;     // adhoc_metric.py:233-234
-            const float idcg = wave_incl_sum(in ? gi * rdisc : 0.0f, lane) + c_idcg;
+            float sdcg = 0.0f, idcg = 1.0f;
+            if (w_ndcg) {
+                sdcg = wave_incl_sum(in ? gs * rdisc : 0.0f, lane) + c_sdcg;     // adhoc_metric.py:233-234
+                idcg = wave_incl_sum(in ? gi * rdisc : 0.0f, lane) + c_idcg;
+            }
             const float rel = in ? fminf(fmaxf(ys, 0.0f), 1.0f) : 0.0f;                // binary relevance (:106)
-            const float cumrel = wave_incl_sum(rel, lane) + c_rel;
+            const float cumrel = (w_ap || w_p) ? wave_incl_sum(rel, lane) + c_rel : 0.0f;
             const float rr = __builtin_amdgcn_rcpf((float)r + 1.0f);
             const float pr = cumrel / ((float)r + 1.0f);                 // rank-wise precision (:111): the reference's correctly rounded division — a
                                                                          // perfect prefix gives P@k = AP = 1.0 exactly, not 0.99999994; rr (1 ulp) stays
                                                                          // for the nERR cascade below
-            const float cumprec = wave_incl_sum(pr * rel, lane) + c_prec;               // (:112)
-            const float cumideal = wave_incl_sum(yi, lane) + c_ideal;                   // GRADED ideal labels (:114)
-            const float ssat = gs * rpow_max, isat = gi * rpow_max;                       // (:133)
-            // cascade: product of (1 - sat) over EARLIER ranks (:135-143) = exclusive prefix product
-            const float s_incl = wave_incl_prod(in ? 1.0f - ssat : 1.0f, lane), i_incl = wave_incl_prod(in ? 1.0f - isat : 1.0f, lane);
-            float s_excl = __shfl_up(s_incl, 1, 64), i_excl = __shfl_up(i_incl, 1, 64);
-            if (lane == 0) { s_excl = 1.0f; i_excl = 1.0f; }
-            const float serr = wave_incl_sum(in ? rr * ssat * (s_excl * c_sun) : 0.0f, lane) + c_serr;
-            const float ierr = wave_incl_sum(in ? rr * isat * (i_excl * c_iun) : 0.0f, lane) + c_ierr;
+            float cumprec = 0.0f, cumideal = 1.0f;
+            if (w_ap) {
+                cumprec = wave_incl_sum(pr * rel, lane) + c_prec;               // (:112)
+                cumideal = wave_incl_sum(yi, lane) + c_ideal;                   // GRADED ideal labels (:114)
+            }
+            float serr = 0.0f, ierr = 1.0f, s_incl = 1.0f, i_incl = 1.0f;
+            if (w_nerr) {
+                const float ssat = gs * rpow_max, isat = gi * rpow_max;                       // (:133)
+                // cascade: product of (1 - sat) over EARLIER ranks (:135-143) = exclusive prefix product
+                s_incl = wave_incl_prod(in ? 1.0f - ssat : 1.0f, lane); i_incl = wave_incl_prod(in ? 1.0f - isat : 1.0f, lane);
+                float s_excl = __shfl_up(s_incl, 1, 64), i_excl = __shfl_up(i_incl, 1, 64);
+                if (lane == 0) { s_excl = 1.0f; i_excl = 1.0f; }
+                serr = wave_incl_sum(in ? rr * ssat * (s_excl * c_sun) : 0.0f, lane) + c_serr;
+                ierr = wave_incl_sum(in ? rr * isat * (i_excl * c_iun) : 0.0f, lane) + c_ierr;
+            }
             if (in) {
                 int slot = 0;
                 for (int c = 0; c < ck.nk; ++c) {
@@ -270,14 +283,25 @@ extern "C" int ptr_metrics_at_ks(const float *preds, const float *labels, const 
         if (int rc = check_hip(hipGetLastError(), who)) return rc;
         ml_dev = max_label_ws;
     }
+    const int which = (ndcg ? 1 : 0) | (nerr ? 2 : 0) | (ap ? 4 : 0) | (prec ? 8 : 0);
     return dispatch_wave_tiling(L, [&]<int G, int DPT>() -> int {
         constexpr int QPB = kBlock / G;
         const int Lp = G == kWave ? kWave * DPT : round_up(L, 4);
-        auto kern = metrics_kernel<G, DPT>;
-        const size_t lds = (size_t)QPB * 3 * Lp * sizeof(float);
-        if (int e = allow_lds(kern, lds)) return e;
-        hipLaunchKernelGGL(kern, dim3((B + QPB - 1) / QPB), dim3(kBlock), lds, st, preds, labels, lens, B, L, Lp, ck, presort, label_type == PTR_LABEL_PERMUTATION ? 1 : 0, max_label,
-                           ml_dev, ndcg, nerr, ap, prec);
-        return check_hip(hipGetLastError(), who);
+        auto go = [&](auto kern) -> int {
+            const size_t lds = (size_t)QPB * 3 * Lp * sizeof(float);
+            if (int e = allow_lds(kern, lds)) return e;
+            hipLaunchKernelGGL(kern, dim3((B + QPB - 1) / QPB), dim3(kBlock), lds, st, preds, labels, lens, B, L, Lp, ck, presort, label_type == PTR_LABEL_PERMUTATION ? 1 : 0, max_label,
+                               ml_dev, ndcg, nerr, ap, prec);
+            return check_hip(hipGetLastError(), who);
+        };
+        // the Evaluator's calls: one metric (ndcg_at_k(s), nerr_at_k, ap_at_k, p_at_k) or all four (adhoc_performance_at_ks)
+        switch (which) {
+            case 1: return go(metrics_kernel<G, DPT, 1>);
+            case 2: return go(metrics_kernel<G, DPT, 2>);
+            case 4: return go(metrics_kernel<G, DPT, 4>);
+            case 8: return go(metrics_kernel<G, DPT, 8>);
+            case 15: return go(metrics_kernel<G, DPT, 15>);
+            default: return go(metrics_kernel<G, DPT, -1>);
+        }
     });
 }

@@ -333,6 +333,32 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 #undef PTR_DPP_ADD
+// Wavefront max / integer min out of the VALU alone, same DPP ladder (lanes a control does not write keep the identity); every lane receives
+// the result (v_readlane of lane 63).
+#define PTR_DPP_STEP(v, ident, ctrl, rows) __builtin_amdgcn_update_dpp((ident), (v), (ctrl), (rows), 0xF, false)
+__device__ __forceinline__ float wave_max_dpp(float x) {
+    const int ninf = __builtin_bit_cast(int, -INFINITY);
+    int v = __builtin_bit_cast(int, x);
+    auto mx = [](int a, int b) { return __builtin_bit_cast(int, fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b))); };
+    v = mx(v, PTR_DPP_STEP(v, ninf, 0xB1, 0xF));
+    v = mx(v, PTR_DPP_STEP(v, ninf, 0x4E, 0xF));
+    v = mx(v, PTR_DPP_STEP(v, ninf, 0x141, 0xF));
+    v = mx(v, PTR_DPP_STEP(v, ninf, 0x140, 0xF));
+    v = mx(v, PTR_DPP_STEP(v, ninf, 0x142, 0xA));
+    v = mx(v, PTR_DPP_STEP(v, ninf, 0x143, 0xC));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 63));
+}
+__device__ __forceinline__ int wave_min_i32_dpp(int v) {
+    const int big = 0x7fffffff;
+    v = min(v, PTR_DPP_STEP(v, big, 0xB1, 0xF));
+    v = min(v, PTR_DPP_STEP(v, big, 0x4E, 0xF));
+    v = min(v, PTR_DPP_STEP(v, big, 0x141, 0xF));
+    v = min(v, PTR_DPP_STEP(v, big, 0x140, 0xF));
+    v = min(v, PTR_DPP_STEP(v, big, 0x142, 0xA));
+    v = min(v, PTR_DPP_STEP(v, big, 0x143, 0xC));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+#undef PTR_DPP_STEP
 __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
     f32x2 d;
     asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));

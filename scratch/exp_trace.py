@@ -9,7 +9,7 @@ R = 4096 * 128
 X = torch.randn(R, F, device="cuda"); dp = torch.randn(R, device="cuda")
 NP = _lib.query("ptr_mlp_num_params", F, NL)
 P = torch.randn(NP, device="cuda") * 0.1
-preds = torch.empty(R, device="cuda"); acts = torch.empty((NL, R, 112), device="cuda")
+preds = torch.empty(R, device="cuda"); acts = torch.empty(NL * ((R + 15) // 16) * 16 * 112, device="cuda")
 ws = torch.zeros(_lib.query("ptr_mlp_backward_ws_floats", F, NL), device="cuda"); grad = torch.empty(NP, device="cuda")
 st = _lib.current_stream(X.device)
 _lib.call("ptr_mlp_forward", _lib.ptr(X), _lib.ptr(P), R, F, NL, 1, C.c_float(0.1), C.c_uint64(5), _lib.ptr(preds), _lib.ptr(acts), st)

@@ -262,6 +262,29 @@ def test_oracle_lambdaloss_approx(F, B, L, use_lens):
             G.assert_close(grad, g, f"approxndcg couple={couple} grad")
 
 
+@pytest.mark.parametrize("B,L", [(37, 8), (64, 64), (33, 128), (40, 256), (9, 512), (5, 1024)])
+@pytest.mark.parametrize("use_lens", [False, True])
+def test_lambdaloss_small_cutoff_kernel(F, B, L, use_lens):
+    """r5 `lambdaloss_topk_kernel` (presorted labels, k <= 11, L % 4 == 0): wavefront arg-max selection + one pair per lane, against the C
+    oracle for every cut-off 1..11, both loss types and tied scores among the best documents (index tie-break)."""
+    from oracle import c_oracle as CO
+    preds, labels, ln = synth(4000 + L, B, L, lens=use_lens, presort=True)
+    preds[::3, : min(L, 6)] = np.float32(0.25)                       # ties among the best-scored documents of every third query
+    preds[1::3, 0] = np.float32(9.0)
+    lens_t = None if ln is None else dev(ln)
+    for lt, code in (("NDCG_Loss2", 1), ("NDCG_Loss2++", 2)):
+        for k in (1, 2, 3, 5, 8, 11):
+            loss, grad = loss_and_grad(F.lambdaloss_loss, preds, dev(labels), k=k, sigma=1.0, mu=5.0, loss_type=lt, presort=True, lens=lens_t)
+            lq, g = CO.lambdaloss(preds, labels, k, 1.0, 5.0, code, True, lens=ln)
+            G.assert_close(loss, lq.astype(np.float64).sum(), f"lambdaloss top-k {lt} k={k}")
+            G.assert_close(grad, g, f"lambdaloss top-k {lt} k={k} grad")
+    # sigma != 1 and the saturated / clamped branches through the same kernel
+    loss, grad = loss_and_grad(F.lambdaloss_loss, preds * 30.0, dev(labels), k=5, sigma=2.5, mu=5.0, loss_type="NDCG_Loss2", presort=True, lens=lens_t)
+    lq, g = CO.lambdaloss((preds * 30.0).astype(np.float32), labels, 5, 2.5, 5.0, 1, True, lens=ln)
+    G.assert_close(loss, lq.astype(np.float64).sum(), "lambdaloss top-k saturated")
+    G.assert_close(grad, g, "lambdaloss top-k saturated grad")
+
+
 # (L = 64 / 128 / 256 / 512 / 700: the register kernels' lane groupings G = 16 / 32 / 64 and 1 / 2 / 4 float4 per lane; 3, 30 (L % 4 != 0)
 # and 4096 take the LDS kernels; `scale` = 10 / 12 spreads the scores past the range of 24 behind which ListMLE switches to its libm form; far beyond that the reference
 # itself returns log(0) = -inf)
