@@ -12,7 +12,7 @@ Rank 0 prints ONE JSON line (contract in the task statement).  `value` is measur
 queries per GPU (1024 is the survey's headline batch) measured the same way with fewer steps.  Extra objects:
   roofline      the dominant kernel of the step by time (the fused single-pass scorer backward, fp32 MFMA): algorithmic flops per
                 launch / its average launch duration measured with HIP events on the launch stream during the timed region (every 4th step), vs
-                the 157.3 TFLOP/s fp32 MFMA peak; `traffic` = PMC HBM bytes (profiles/r04_pmc_traffic.json, trusted only when its kernel-source hash matches the built sources), `algorithmic_bytes_*`
+                the 157.3 TFLOP/s fp32 MFMA peak; `traffic` = PMC HBM bytes (profiles/r05_pmc_traffic.json, trusted only when its kernel-source hash matches the built sources), `algorithmic_bytes_*`
                 = SURVEY 8(d)'s definition (features + scores), `design_bytes_*` = what the design additionally moves (stored
                 activations, partial gradients)
   kernels       the other kernels of the step: scorer forward (MFMA roofline), the north-star LambdaRank loss kernel against the
@@ -219,7 +219,7 @@ def metric_path(ranker, B, L, F, device, rank, ks=(1, 3, 5, 10, 20, 50), cpu_sec
                          "sample": f"{done} queries in {cel:.1f} s: torch-CPU scorer forward + sort + gather + nDCG@ks + AP@10 on batches of 64 queries"}}
 
 
-PMC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r05_pmc_traffic.json")
 
 
 def kernel_source_hash():

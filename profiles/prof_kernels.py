@@ -8,7 +8,7 @@
 
 `run` launches each entry point ITERS times at B queries (default 65 536; inputs far larger than the 256 MB Infinity Cache) on the MSLR label
 mix.  `summarise` joins the rocprofv3 kernel averages with the ALGORITHMIC bytes of SURVEY.md 8(d) — 12L+4 per query for the fused loss
-kernels (16L+4 for ListMLE with its int32 permutation), 8L+4*len(ks) for the metric kernel, 16L for the sort (4L in, 4L values + 8L int64
+kernels (16L+4 for ListMLE with its int64 permutation), 8L+4*len(ks) for the metric kernel, 16L for the sort (4L in, 4L values + 8L int64
 indices out), 12L for the tie shuffle (4L labels in, 8L int64 order out) — and prints achieved GB/s against the 8 TB/s HBM peak.
 """
 import json
