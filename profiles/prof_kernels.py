@@ -26,7 +26,7 @@ CASES = [
     ("lambdarank L=256", "lambdarank_ring_kernel<4>", 256, lambda L: 12 * L + 4),
     ("listnet L=256", "listnet_vec_kernel", 256, lambda L: 12 * L + 4),
     ("listmle L=256", "listmle_vec_kernel", 256, lambda L: 16 * L + 4),
-    ("lambdaloss L=256 k=5", "lambdaloss_kernel", 256, lambda L: 12 * L + 4),
+    ("lambdaloss L=256 k=5", "lambdaloss_", 256, lambda L: 12 * L + 4),
     ("approxndcg L=512", "approxndcg", 512, lambda L: 12 * L + 4),
     ("metrics L=256", "metrics_kernel", 256, lambda L: 8 * L + 4 * len(KS) * 4),
     ("sort_desc L=256", "sort_desc_kernel", 256, lambda L: 16 * L),
