@@ -85,6 +85,21 @@ __device__ __forceinline__ void b6_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 // A scalar the compiler cannot fold: image bases go through this INSIDE the slab loop, or hipcc precomputes one address register per (image,
 // plane, tile) combination — the images lie past the 64 KB ds offset range — hoists the dozens of them out of the loop and spills them
 __device__ __forceinline__ uint32_t b6_opaque(uint32_t x) { asm volatile("" : "+s"(x)); return x; }
+#ifndef PTR_B6_DMA_CHAIN_ONLY
+#define PTR_B6_DMA_CHAIN_ONLY 1
+#endif
+#ifndef PTR_B6_PREFETCH_LATE
+#define PTR_B6_PREFETCH_LATE 1        /* 1: the next-next slab's DMA is issued at the end of the chain-3 phase instead of right behind B4 */
+#endif
+#ifndef PTR_B6_PIPE_W7
+#define PTR_B6_PIPE_W7 1
+#endif
+#ifndef PTR_B6_PIPE_C2
+#define PTR_B6_PIPE_C2 0
+#endif
+#ifndef PTR_B6_STAGE_ORDER
+#define PTR_B6_STAGE_ORDER 0
+#endif
 #define B6_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16((A).v, (B).v, (C), 0, 0, 0)
 
 template <int NT1>
@@ -271,7 +286,11 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
         // end of a layer reads the next layer's first tile / zeros: those documents carry dLoss/dscore = 0)
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
+#if PTR_B6_DMA_CHAIN_ONLY
+            const int k = chain ? W + 7 * q : 3 * 14;                // scalar; wave 7 (the longest MFMA stream of the chain phases) issues none
+#else
             const int k = W + 8 * q;                                 // scalar
+#endif
             if (k < 3 * 14) {
                 const int layer = k / 14, ch = k - 14 * layer;
                 b6_bdma16(asrd, l16, (uint32_t)layer * (uint32_t)(act_layer_floats(R) * 4) + (uint32_t)row0 * (kAL * 4) + (uint32_t)ch * 1024,
@@ -282,23 +301,14 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
         for (int dt = 0; dt < 2; ++dt)                               // rows past R: out of range, 0 — exactly the gradient they must contribute
             dsv[dt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dsrd, (int)j4, (int)((uint32_t)(row0 + 16 * dt) * 4u), 0));
     };
-    const int slab0 = blockIdx.x;
-    prefetch(slab0 < nslabs ? slab0 : nslabs - 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                       // zero fill + first staging visible to every wave
-
-#ifdef PTR_B6_TRACE       // experiment builds: shader-clock stamps of workgroup 0 behind its partial gradient (ws is sized for 2 partials per CU)
-    unsigned long long *trace = reinterpret_cast<unsigned long long *>(ws + (size_t)gridDim.x * np_stride) + W * 256;
-    int nstamp = 0;
-#define B6_STAMP() do { if (blockIdx.x == 0 && lane == 0 && nstamp < 256) trace[nstamp++] = clock64(); } while (0)
-#else
-#define B6_STAMP() do { } while (0)
-#endif
-    for (int slab = slab0; slab < nslabs; slab += gridDim.x) {
-        B6_STAMP();
-        const int row0 = slab * kB6S;
-        uint32_t m2 = 0u, m1 = 0u;                     // gate bits (activation > 0) of this lane's 2 x 4 elements of layers 2 / 1
-        // ---- staging pass: dZ3, the plane images of A2 / A1 / X
+    // r5: the slab loop is software-pipelined.  The staging pass of slab s + 1 (fp32 staging area -> dZ3 and the plane images of A2 / A1)
+    // runs INSIDE the dW_1 phase of slab s: it writes the dZ buffer, A2 and A1, which the dW_1 phase (dZ1 x X) does not read — the two dZ
+    // buffers swap roles every slab (`zi` = the buffer holding this slab's dZ3, then dZ1; `zo` = dZ2, then the NEXT slab's dZ3).  Waves w and
+    // w + 4 share a SIMD: waves 0..3 stage first and multiply second, waves 4..7 the other way round, so a SIMD's matrix pipe and vector
+    // ALU are busy at the same time.  Three barriers per slab (was four, with an all-VALU staging phase of 3.8 K cycles of 21.4 K).
+    uint32_t m2 = 0u, m1 = 0u;                         // gate bits (activation > 0) of this lane's 2 x 4 elements of layers 2 / 1, per slab
+    auto staging = [&](uint32_t zdst) __attribute__((always_inline)) {        // zdst: LDS offset (from lds0) of the dZ buffer that receives dZ3
+        m2 = 0u; m1 = 0u;
         if (chain) {
             const f32x4 wo4 = *reinterpret_cast<lds_f32x4_b *>((uintptr_t)(b6_opaque(lds0 + (uint32_t)(kB6_WO + 64 * W)) + (uint32_t)(16 * g)));
 #pragma unroll
@@ -319,23 +329,38 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
                 }
                 if (W == 0 && g == 0) abo += ds;
                 const uint32_t wo = wr_z + b6_opaque(lds0 + (uint32_t)(32 * W)) + (uint32_t)(16 * dt * kB6ZRS);
-                b6_write4(wo + kB6_ZA, kB6ZPL, z3);
-                b6_write4(wo + kB6_A2, kB6ZPL, a2);       // (ZA .. A2 lie within the 64 KB the ds offset field reaches from `wo`)
+                b6_write4(wo + b6_opaque(zdst), kB6ZPL, z3);
+                b6_write4(wo + kB6_A2, kB6ZPL, a2);
                 b6_write4(wo + kB6_A1, kB6ZPL, a1);
             }
         }
+    };
+    const int slab0 = blockIdx.x;
+    prefetch(slab0 < nslabs ? slab0 : nslabs - 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                       // zero fill + first staging visible to every wave
+
+#ifdef PTR_B6_TRACE       // experiment builds: shader-clock stamps of workgroup 0 behind its partial gradient (ws is sized for 2 partials per CU)
+    unsigned long long *trace = reinterpret_cast<unsigned long long *>(ws + (size_t)gridDim.x * np_stride) + W * 256;
+    int nstamp = 0;
+#define B6_STAMP() do { if (blockIdx.x == 0 && lane == 0 && nstamp < 256) trace[nstamp++] = clock64(); } while (0)
+#else
+#define B6_STAMP() do { } while (0)
+#endif
+    uint32_t zi = kB6_ZA, zo = kB6_ZB;
+    staging(zi);                                                     // slab 0
+    b6_barrier();                                                    // images complete, staging area consumed
+    {
+        const int nxt = slab0 + (int)gridDim.x;
+        prefetch(nxt < nslabs ? nxt : nslabs - 1);                  // (past the last slab: a redundant copy nobody stages — its dLoss/dscore is never used)
+    }
+    for (int slab = slab0; slab < nslabs; slab += gridDim.x) {
         B6_STAMP();
-        b6_barrier();                                                // B1: images complete, staging consumed
-        B6_STAMP();
-        {
-            const int nxt = slab + (int)gridDim.x;
-            prefetch(nxt < nslabs ? nxt : nslabs - 1);
-        }
         // ---- chain 3 (dZ3 -> dZ2) + dW_3, chain 2 (dZ2 -> dZ1) + dW_2
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             if (c == 1) load_x(slab);                               // behind B2: live through this phase only (registers), staged in front of B3
-            const uint32_t zin = b6_opaque(lds0 + (c == 0 ? kB6_ZA : kB6_ZB)), zout = b6_opaque(lds0 + (c == 0 ? kB6_ZB : kB6_ZA) + (uint32_t)(32 * W));
+            const uint32_t zin = b6_opaque(lds0 + (c == 0 ? zi : zo)), zout = b6_opaque(lds0 + (c == 0 ? zo : zi) + (uint32_t)(32 * W));
             const uint32_t aim = b6_opaque(lds0 + (c == 0 ? kB6_A2 : kB6_A1));
             if (chain) {
                 f32x4 cc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -344,7 +369,7 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
                     for (int p = 0; p < 3; ++p)
                         b[p].q = *reinterpret_cast<lds_u32x4_b *>((uintptr_t)(zin + rd_b + (uint32_t)(p * kB6ZPL + 16 * (u & 1) * kB6ZRS + 64 * (u >> 1))));
                 };
-                if (c == 0) {                        // chain 3 has the registers for a fragment in flight beside the one being multiplied
+                if (c == 0 || PTR_B6_PIPE_C2) {      // chain 3 has the registers for a fragment in flight beside the one being multiplied
                     BFrag b[2][3];
                     read_b(b[0], 0);
 #pragma unroll
@@ -382,32 +407,70 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
                 }
                 // dW of the layer whose dZ is the chain's INPUT: row w, in-tiles 0..4 of the activations below it
                 if (c == 0) dw_row(std::integral_constant<int, 5>{}, std::true_type{}, 0, zin, W, aim + tr_z, kB6ZPL, kB6ZRS, 0);
-                else dw_row(std::integral_constant<int, 5>{}, std::false_type{}, 5, zin, W, aim + tr_z, kB6ZPL, kB6ZRS, 0);
+                else dw_row(std::integral_constant<int, 5>{}, std::bool_constant<PTR_B6_PIPE_C2 != 0>{}, 5, zin, W, aim + tr_z, kB6ZPL, kB6ZRS, 0);
             } else {
 #pragma unroll
                 for (int mo = 0; mo < 7; ++mo)       // wave 7: in-tiles 5, 6 of every row
-                    dw_row(std::integral_constant<int, 2>{}, std::false_type{}, 14 * c + 2 * mo, zin, mo, aim + tr_z, kB6ZPL, kB6ZRS, 5);
+                    dw_row(std::integral_constant<int, 2>{}, std::bool_constant<PTR_B6_PIPE_W7 != 0>{}, 14 * c + 2 * mo, zin, mo, aim + tr_z, kB6ZPL, kB6ZRS, 5);
             }
-            if (c == 1) stage_x(slab);                               // the XI image, complete at B3
+#if PTR_B6_PREFETCH_LATE
+            if (c == 0 && slab != slab0) {                           // the staging area was consumed before the last B4: the NEXT slab's activations
+                const int nxt = slab + (int)gridDim.x;               // (the prologue issued slab0's successor itself)
+                prefetch(nxt < nslabs ? nxt : nslabs - 1);
+            }
+#endif
+            if (c == 1) {
+                stage_x(slab);                                       // the XI image, complete at B3
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the NEXT slab's staging area has landed (issued two phases ago)
+            }
             B6_STAMP();
             b6_barrier();                                            // B2 / B3
             B6_STAMP();
         }
-        // ---- dW_1: dZ1 (in ZA) x the X image
+        // ---- dW_1: dZ1 (in `zi`) x the X image  ||  the staging pass of the next slab (-> `zo`, A2, A1: nobody reads them in this phase)
         {
-            const uint32_t za = b6_opaque(lds0 + kB6_ZA), xi = b6_opaque(lds0 + kB6_XI) + tr_x;
-            if (chain) {
-                dw_row(std::integral_constant<int, 8>{}, std::true_type{}, 10, za, W, xi, kB6XPL, kB6XRS, 0);
-            } else {
+            const bool more = slab + (int)gridDim.x < nslabs;       // wave-uniform
+            const uint32_t za = b6_opaque(lds0 + zi), xi = b6_opaque(lds0 + kB6_XI) + tr_x;
+            auto dw1 = [&]() __attribute__((always_inline)) {
+                if (chain) {
+                    dw_row(std::integral_constant<int, 8>{}, std::true_type{}, 10, za, W, xi, kB6XPL, kB6XRS, 0);
+                } else {
 #pragma unroll
-                for (int mo = 0; mo < 7; ++mo) dw_row(std::integral_constant<int, 1>{}, std::false_type{}, 28 + mo, za, mo, xi, kB6XPL, kB6XRS, 8);
+                    for (int mo = 0; mo < 7; ++mo) dw_row(std::integral_constant<int, 1>{}, std::false_type{}, 28 + mo, za, mo, xi, kB6XPL, kB6XRS, 8);
+                }
+            };
+#if PTR_B6_STAGE_ORDER == 0
+            if (more) staging(zo);
+            __builtin_amdgcn_sched_barrier(0);
+            dw1();
+#elif PTR_B6_STAGE_ORDER == 1
+            dw1();
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) staging(zo);
+#else
+            if (W < 4) {
+                if (more) staging(zo);
+                __builtin_amdgcn_sched_barrier(0);
+                dw1();
+            } else {
+                dw1();
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) staging(zo);
             }
+#endif
         }
         B6_STAMP();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the next slab's staging has landed
+        b6_barrier();                                                // B4: dZ1 / X consumed, next slab's images complete, staging area free
         B6_STAMP();
-        b6_barrier();                                                // B4
+#if !PTR_B6_PREFETCH_LATE
+        {
+            const int nxt = slab + 2 * (int)gridDim.x;
+            prefetch(nxt < nslabs ? nxt : nslabs - 1);
+        }
+#endif
+        const uint32_t tz = zi; zi = zo; zo = tz;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the run-ahead DMA must not outlive the workgroup's LDS allocation
 
     // ---- this workgroup's partial gradient, flat parameter layout (every element written exactly once)
     float *out = ws + (size_t)blockIdx.x * np_stride;

@@ -9,7 +9,7 @@ for F, R in ((136, 2085), (136, 32), (132, 777), (140, 4096 + 5), (136, 131072),
     torch.manual_seed(R)
     fused = FusedPointScorer(F, num_layers=NL, dropout=0.1).cuda()
     X = torch.randn(R, F, device="cuda"); dp = torch.randn(R, device="cuda")
-    preds = torch.empty(R, device="cuda"); acts = torch.empty(NL, R, 112, device="cuda")
+    preds = torch.empty(R, device="cuda"); acts = torch.empty(NL * ((R + 15) // 16) * 16 * 112, device="cuda")
     st = _lib.current_stream(X.device)
     _lib.call("ptr_mlp_forward", _lib.ptr(X), _lib.ptr(fused.flat.data), R, F, NL, 1, C.c_float(0.1), C.c_uint64(77), _lib.ptr(preds), _lib.ptr(acts), st)
     ws = torch.empty(_lib.query("ptr_mlp_backward_ws_floats", F, NL), device="cuda")

@@ -9,7 +9,7 @@ NL, F, R = 3, 136, 524288
 torch.manual_seed(0)
 fused = FusedPointScorer(F, num_layers=NL, dropout=0.1).cuda()
 X = torch.randn(R, F, device="cuda"); dp = torch.randn(R, device="cuda")
-preds = torch.empty(R, device="cuda"); acts = torch.empty(NL, R, 112, device="cuda")
+preds = torch.empty(R, device="cuda"); acts = torch.empty(NL * ((R + 15) // 16) * 16 * 112, device="cuda")
 st = _lib.current_stream(X.device)
 os.environ["PTR_MLP_X6"] = "0"
 _lib.call("ptr_mlp_forward", _lib.ptr(X), _lib.ptr(fused.flat.data), R, F, NL, 1, C.c_float(0.1), C.c_uint64(77), _lib.ptr(preds), _lib.ptr(acts), st)
@@ -20,10 +20,11 @@ for _ in range(2):
 torch.cuda.synchronize()
 NP = _lib.query("ptr_mlp_num_params", F, NL)
 tr = ws[256 * NP:256 * NP + 8 * 512].cpu().numpy().view(np.uint64).reshape(8, 256).astype(np.int64)
-names = ["staging", "B1 wait", "chain3+dW3", "B2 wait", "chain2+dW2+X", "B3 wait", "dW1", "DMA wait", "B4 wait"]
+names = ["chain3+dW3", "B2 wait", "chain2+dW2+X", "B3 wait", "dW1+staging(next)", "B4 wait", "prefetch issue"]
+NS = len(names)
 for w in (0, 3, 4, 7):
     t = tr[w]
-    n = int((t > 0).sum()) // 9
-    d = np.diff(t[:9 * n + 1] if t[9 * n] > 0 else t[:9 * n]).reshape(-1, 9)[1:6] if n > 6 else None
+    n = int((t > 0).sum()) // NS
+    d = np.diff(t[:NS * n + 1] if t[NS * n] > 0 else t[:NS * n]).reshape(-1, NS)[1:6] if n > 6 else None
     if d is None: print("wave", w, "too few stamps", n); continue
     print(f"wave {w}: per slab (mean of slabs 1..5): " + ", ".join(f"{nm} {int(v)}" for nm, v in zip(names, d.mean(axis=0))) + f" | total {int(d.sum(axis=1).mean())}")

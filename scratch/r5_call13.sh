@@ -1,0 +1,5 @@
+#!/bin/bash
+cd /root/repo
+python scratch/dbg_bwd_x6.py 2>&1 | grep -v amdgpu | tail -3
+for v in b6c2 b6base b6early; do echo $v; PTR_LIB=$PWD/ptranking_amd/libptranking_amd.$v.so python scratch/dbg_bwd_x6.py 2>&1 | grep -v amdgpu | tail -1; done
+timeout 600 python -m pytest tests/test_x6_gpu.py -q -m gpu -x -k "bwd or backward" 2>&1 | tail -2
