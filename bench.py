@@ -537,7 +537,7 @@ def main():
             return float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else None
 
         R = B * L
-        NL = 3
+        NL = NL_ = 3
         timed_steps = (args.steps + EVENT_EVERY - 1) // EVENT_EVERY       # steps of the timed region that carried event brackets
         fwd_flop = 2.0 * (100 * F + (NL - 1) * 100 * 100 + 100) * R          # algorithmic: 2*(100F + 2*100*100 + 100) per document
         bwd_flop = 2.0 * (100 * F + (NL - 1) * 100 * 100) * R + 2.0 * (NL - 1) * 100 * 100 * R + 2.0 * 100 * R   # dW + dZ chain + top
@@ -627,10 +627,17 @@ def main():
         if t_bwd and args.scorer == "pointsf":
             tf = bwd_flop / (t_bwd * 1e-3) / 1e12
             fused = (NL == 3 and 129 <= F <= 143 and F % 4 == 0)
-            roofline = {"kernel": ("mlp_bwd_fused_kernel<3,9> (single-pass scorer backward: dZ chain + all weight gradients, fp32 MFMA 16x16x4) "
+            bwd_x6 = fused and os.environ.get("PTR_BWD_X6", "1") != "0"       # r5: the bf16x6 single-pass backward is the default where it serves the shape
+            bwd_peak = BF16X6_PEAK_TFLOPS if bwd_x6 else MFMA_F32_PEAK_TFLOPS
+            roofline = {"kernel": ("mlp_bwd_x6_kernel<9> (single-pass scorer backward: dZ chain + all weight gradients, every fp32 product as six "
+                                   "v_mfma_f32_16x16x32_bf16 products with fp32 accumulation; bf16 plane images in LDS, software-pipelined slabs) "
+                                   "+ reduce_partials_kernel" if bwd_x6 else
+                                   "mlp_bwd_fused_kernel<3,9> (single-pass scorer backward: dZ chain + all weight gradients, fp32 MFMA 16x16x4) "
                                    "+ reduce_partials_kernel" if fused else "mlp_bwd_dz + 3 x mlp_bwd_dw + reduce_partials (layer-wise backward)"),
-                        "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
-                        "traffic": pmc_bytes("ptr::mlp_bwd_fused_kernel"), "avg_launch_ms": t_bwd, "algorithmic_flop_per_launch": bwd_flop,
+                        "formulation": "bf16x6 (fp32 results)" if bwd_x6 else "fp32 MFMA",
+                        "bound": "mfma", "achieved": tf, "peak": bwd_peak, "unit": "TFLOP/s (effective fp32)" if bwd_x6 else "TFLOP/s", "frac": tf / bwd_peak,
+                        "frac_of_fp32_mfma_peak": tf / MFMA_F32_PEAK_TFLOPS,
+                        "traffic": pmc_bytes("ptr::mlp_bwd_x6_kernel" if bwd_x6 else "ptr::mlp_bwd_fused_kernel"), "avg_launch_ms": t_bwd, "algorithmic_flop_per_launch": bwd_flop,
                         "algorithmic_bytes_per_launch": R * (4 * F + 4),
                         "design_bytes_per_launch": NL * R * 448 + 256 * 4 * (100 * F + 100 + (NL - 1) * 10100 + 101),
                         "entry_point": "ptr_mlp_backward_step" if bwd_fused_step else "ptr_mlp_backward",
@@ -680,7 +687,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "formulation": {"scorer_forward": "bf16x6: fp32 operands split exactly into three bf16 pieces, six bf16 MFMA products per fp32 product, fp32 "
                                               "accumulation (error vs float64 <= the fp32-MFMA path, tests/test_x6_gpu.py)" if fwd_x6 else "fp32 MFMA",
-                            "scorer_backward": "fp32 MFMA", "loss": "fp32 VALU"},
+                            "scorer_backward": ("bf16x6 (the forward's arithmetic; error vs float64 within the fp32-MFMA backward's, tests/test_x6_gpu.py)"
+                                                if (args.scorer == "pointsf" and NL_ == 3 and 129 <= F <= 143 and F % 4 == 0 and os.environ.get("PTR_BWD_X6", "1") != "0")
+                                                else "fp32 MFMA"), "loss": "fp32 VALU"},
             "config": {"workload": (f"{args.loss} train step (pointsf 3x100 ReLU scorer, dropout 0.1, Adam), " if args.scorer == "pointsf" else
                                     f"{args.loss} train step (the reference's DEFAULT pointsf: 5 x [Linear 100 -> BatchNorm(affine) -> GELU] + "
                                     f"Linear -> BatchNorm -> Sigmoid, dropout 0.1, Adam), " if args.scorer == "pointsf_default" else

@@ -97,6 +97,9 @@ __device__ __forceinline__ uint32_t b6_opaque(uint32_t x) { asm volatile("" : "+
 #ifndef PTR_B6_PIPE_C2
 #define PTR_B6_PIPE_C2 0
 #endif
+#ifndef PTR_B6_PRIO
+#define PTR_B6_PRIO 0
+#endif
 #ifndef PTR_B6_STAGE_ORDER
 #define PTR_B6_STAGE_ORDER 0
 #endif
@@ -307,12 +310,12 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
     // w + 4 share a SIMD: waves 0..3 stage first and multiply second, waves 4..7 the other way round, so a SIMD's matrix pipe and vector
     // ALU are busy at the same time.  Three barriers per slab (was four, with an all-VALU staging phase of 3.8 K cycles of 21.4 K).
     uint32_t m2 = 0u, m1 = 0u;                         // gate bits (activation > 0) of this lane's 2 x 4 elements of layers 2 / 1, per slab
-    auto staging = [&](uint32_t zdst) __attribute__((always_inline)) {        // zdst: LDS offset (from lds0) of the dZ buffer that receives dZ3
-        m2 = 0u; m1 = 0u;
+    auto staging = [&](uint32_t zdst, int dt0 = 0, int dt1 = 2) __attribute__((always_inline)) {        // zdst: LDS offset (from lds0) of the dZ buffer that receives dZ3; document tiles dt0 .. dt1 - 1
+        if (dt0 == 0) { m2 = 0u; m1 = 0u; }
         if (chain) {
             const f32x4 wo4 = *reinterpret_cast<lds_f32x4_b *>((uintptr_t)(b6_opaque(lds0 + (uint32_t)(kB6_WO + 64 * W)) + (uint32_t)(16 * g)));
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
+            for (int dt = dt0; dt < dt1; ++dt) {
                 // the staging area is a straight copy of two tile-major row tiles (ptr_mlp.h): feature tile W of row tile dt at dt * 7168 + W * 1024, lane (j, g) at j * 64 + 16 g
                 const uint32_t so = b6_opaque(lds0 + (uint32_t)(kB6_ST + 1024 * W)) + (uint32_t)(j * 64 + 16 * g) + (uint32_t)(dt * kActTile * 4);
                 const f32x4 a1 = *reinterpret_cast<lds_f32x4_b *>((uintptr_t)so);
@@ -346,6 +349,9 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
 #define B6_STAMP() do { if (blockIdx.x == 0 && lane == 0 && nstamp < 256) trace[nstamp++] = clock64(); } while (0)
 #else
 #define B6_STAMP() do { } while (0)
+#endif
+#if PTR_B6_PRIO
+    if (W >= 4) __builtin_amdgcn_s_setprio(1);      // waves w and w + 4 share a SIMD and the older one wins every arbitration: static priority for the younger half
 #endif
     uint32_t zi = kB6_ZA, zo = kB6_ZB;
     staging(zi);                                                     // slab 0
@@ -439,7 +445,17 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
                     for (int mo = 0; mo < 7; ++mo) dw_row(std::integral_constant<int, 1>{}, std::false_type{}, 28 + mo, za, mo, xi, kB6XPL, kB6XRS, 8);
                 }
             };
-#if PTR_B6_STAGE_ORDER == 0
+#if PTR_B6_STAGE_ORDER == 3
+            // the two halves of the staging pass between the two halves of the dW_1 row: the MFMAs of four tiles drain while the vector ALU splits
+            if (chain) {
+                if (more) staging(zo, 0, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                dw_row(std::integral_constant<int, 4>{}, std::true_type{}, 10, za, W, xi, kB6XPL, kB6XRS, 0);
+                if (more) staging(zo, 1, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                dw_row(std::integral_constant<int, 4>{}, std::true_type{}, 14, za, W, xi, kB6XPL, kB6XRS, 4);
+            } else dw1();
+#elif PTR_B6_STAGE_ORDER == 0
             if (more) staging(zo);
             __builtin_amdgcn_sched_barrier(0);
             dw1();
@@ -515,12 +531,12 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
     }
 }
 
-// PTR_BWD_X6 (read per call): "1" selects this kernel wherever it serves the shape.  It is OPT-IN: r4 measured it at parity with the fp32-MFMA
-// fused backward (610 vs 600 us at 524 288 x 136; both spend ~21 K cycles per 32-document slab, of which the MFMAs are 6.6 K here and 16 K
-// there: the four barrier-separated phases, the staging pass and the LDS traffic set the time, not the matrix pipe) — see DESIGN.md 3.2.
+// PTR_BWD_X6 (read per call): "0" selects the fp32-MFMA fused backward (scorer_bwd.hip) instead.  r5: this kernel is the DEFAULT wherever it
+// serves the shape — software-pipelined (the next slab's staging pass inside the dW_1 phase, DMA issued by the chain waves at the end of the
+// chain-3 phase) it takes 462 us at 524 288 x 136 against 587-603 us (r4: 610 vs 600, opt-in).
 static int bwd_x6_mode() {
     const char *e = getenv("PTR_BWD_X6");
-    return e ? atoi(e) : 0;
+    return e ? atoi(e) : 1;
 }
 bool bwd_x6_supported(int R, int F, int NL, const void *X, const void *acts) {
     if (bwd_x6_mode() == 0) return false;
