@@ -100,6 +100,9 @@ __device__ __forceinline__ uint32_t b6_opaque(uint32_t x) { asm volatile("" : "+
 #ifndef PTR_B6_PRIO
 #define PTR_B6_PRIO 0
 #endif
+#ifndef PTR_B6_X_PHASE
+#define PTR_B6_X_PHASE 1              /* chain phase (0 / 1) in which X is loaded and turned into its plane image */
+#endif
 #ifndef PTR_B6_STAGE_ORDER
 #define PTR_B6_STAGE_ORDER 0
 #endif
@@ -365,7 +368,7 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
         // ---- chain 3 (dZ3 -> dZ2) + dW_3, chain 2 (dZ2 -> dZ1) + dW_2
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            if (c == 1) load_x(slab);                               // behind B2: live through this phase only (registers), staged in front of B3
+            if (c == PTR_B6_X_PHASE) load_x(slab);                  // live through this phase only (registers), staged in front of its barrier
             const uint32_t zin = b6_opaque(lds0 + (c == 0 ? zi : zo)), zout = b6_opaque(lds0 + (c == 0 ? zo : zi) + (uint32_t)(32 * W));
             const uint32_t aim = b6_opaque(lds0 + (c == 0 ? kB6_A2 : kB6_A1));
             if (chain) {
@@ -375,7 +378,7 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
                     for (int p = 0; p < 3; ++p)
                         b[p].q = *reinterpret_cast<lds_u32x4_b *>((uintptr_t)(zin + rd_b + (uint32_t)(p * kB6ZPL + 16 * (u & 1) * kB6ZRS + 64 * (u >> 1))));
                 };
-                if (c == 0 || PTR_B6_PIPE_C2) {      // chain 3 has the registers for a fragment in flight beside the one being multiplied
+                if (c != PTR_B6_X_PHASE || PTR_B6_PIPE_C2) {      // the chain phase without X in flight has the registers for a fragment in flight beside the one being multiplied
                     BFrag b[2][3];
                     read_b(b[0], 0);
 #pragma unroll
@@ -412,23 +415,23 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
                     b6_write4(zout + wr_z + (uint32_t)(16 * dt * kB6ZRS), kB6ZPL, dz);
                 }
                 // dW of the layer whose dZ is the chain's INPUT: row w, in-tiles 0..4 of the activations below it
-                if (c == 0) dw_row(std::integral_constant<int, 5>{}, std::true_type{}, 0, zin, W, aim + tr_z, kB6ZPL, kB6ZRS, 0);
-                else dw_row(std::integral_constant<int, 5>{}, std::bool_constant<PTR_B6_PIPE_C2 != 0>{}, 5, zin, W, aim + tr_z, kB6ZPL, kB6ZRS, 0);
+                if (c == 0) dw_row(std::integral_constant<int, 5>{}, std::bool_constant<PTR_B6_X_PHASE != 0 || PTR_B6_PIPE_C2 != 0>{}, 0, zin, W, aim + tr_z, kB6ZPL, kB6ZRS, 0);
+                else dw_row(std::integral_constant<int, 5>{}, std::bool_constant<PTR_B6_X_PHASE != 1 || PTR_B6_PIPE_C2 != 0>{}, 5, zin, W, aim + tr_z, kB6ZPL, kB6ZRS, 0);
             } else {
 #pragma unroll
                 for (int mo = 0; mo < 7; ++mo)       // wave 7: in-tiles 5, 6 of every row
                     dw_row(std::integral_constant<int, 2>{}, std::bool_constant<PTR_B6_PIPE_W7 != 0>{}, 14 * c + 2 * mo, zin, mo, aim + tr_z, kB6ZPL, kB6ZRS, 5);
             }
+            if (c == PTR_B6_X_PHASE) stage_x(slab);                  // the XI image (read by dW_1 only: free since the last B4)
+            // (the DMA goes BEHIND the X staging: hipcc's waitcnt for the X registers does not count the asm DMA, a wait placed behind it would
+            // wait for the whole prefetch)
 #if PTR_B6_PREFETCH_LATE
             if (c == 0 && slab != slab0) {                           // the staging area was consumed before the last B4: the NEXT slab's activations
                 const int nxt = slab + (int)gridDim.x;               // (the prologue issued slab0's successor itself)
                 prefetch(nxt < nslabs ? nxt : nslabs - 1);
             }
 #endif
-            if (c == 1) {
-                stage_x(slab);                                       // the XI image, complete at B3
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the NEXT slab's staging area has landed (issued two phases ago)
-            }
+            if (c == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the NEXT slab's staging area has landed (issued a phase ago)
             B6_STAMP();
             b6_barrier();                                            // B2 / B3
             B6_STAMP();
@@ -445,7 +448,18 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
                     for (int mo = 0; mo < 7; ++mo) dw_row(std::integral_constant<int, 1>{}, std::false_type{}, 28 + mo, za, mo, xi, kB6XPL, kB6XRS, 8);
                 }
             };
-#if PTR_B6_STAGE_ORDER == 3
+#if PTR_B6_STAGE_ORDER == 4
+            // complementary halves of a SIMD without a second copy of either body (two copies under a wave-id branch spilled 115 registers):
+            // a two-trip loop that runs the staging pass in the first trip for waves 0..3 and in the second for waves 4..7 — waves w and
+            // w + 4 share a SIMD, so its vector ALU splits one wave's next slab while its matrix pipe multiplies the other's dW_1
+            const bool stage_first = W < 4;
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h) {
+                if ((h == 0) == stage_first) { if (more) staging(zo); }
+                else dw1();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#elif PTR_B6_STAGE_ORDER == 3
             // the two halves of the staging pass between the two halves of the dW_1 row: the MFMAs of four tiles drain while the vector ALU splits
             if (chain) {
                 if (more) staging(zo, 0, 1);

@@ -120,3 +120,27 @@ def test_self_launch_refuses_more_ranks_than_gpus():
                          capture_output=True, text=True, timeout=300, cwd=root)
     assert out.returncode != 0 and out.stdout.strip() == ""
     assert "one rank per GPU is required" in out.stderr
+
+
+def test_committed_kernel_profiles_hold_no_fraction_above_one():
+    """a roofline fraction above 1 means the "peak" was not a bound.  Every `frac` / `frac_of_hbm_peak` in the committed
+    round-5 stand-alone kernel profile and bench lines is a fraction."""
+    import glob
+
+    def fracs(o, path=""):
+        if isinstance(o, dict):
+            for k, v in o.items():
+                if k in ("frac", "frac_of_hbm_peak") and isinstance(v, (int, float)):
+                    yield path + "/" + k, v
+                else:
+                    yield from fracs(v, path + "/" + k)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_kernels_B65536.json")) + glob.glob(os.path.join(ROOT, "profiles", "r05_bench_*.json")))
+    assert files, "the round-5 profiles are committed"
+    for f in files:
+        text = open(f).read().strip()
+        try:
+            d = json.loads(text)                                   # an indented summary file
+        except ValueError:
+            d = json.loads(text.splitlines()[-1])                  # a bench line (ONE line of JSON, possibly behind noise)
+        bad = [(k, v) for k, v in fracs(d) if not (0.0 <= v <= 1.0)]
+        assert not bad, (os.path.basename(f), bad)
