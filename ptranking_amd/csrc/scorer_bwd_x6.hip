@@ -103,6 +103,9 @@ __device__ __forceinline__ uint32_t b6_opaque(uint32_t x) { asm volatile("" : "+
 #ifndef PTR_B6_X_PHASE
 #define PTR_B6_X_PHASE 1              /* chain phase (0 / 1) in which X is loaded and turned into its plane image */
 #endif
+#ifndef PTR_B6_SWZ
+#define PTR_B6_SWZ 1
+#endif
 #ifndef PTR_B6_STAGE_ORDER
 #define PTR_B6_STAGE_ORDER 0
 #endif
@@ -177,11 +180,24 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
     float awo[4] = {0.0f, 0.0f, 0.0f, 0.0f}, abo = 0.0f;
 
     // per-lane addresses
+    // r5: the 8-byte chunks of a row's 32-byte feature-tile groups are XOR-swizzled by a row bit (chunk g of row r sits at g ^ 2 ((r >> 2) & 1)): a plane-image
+    // store (ds_write_b64: 16 consecutive lanes = the 16 rows of one chunk column, 224-byte stride = 4 distinct bank pairs) is 2-way instead of 4-way
+    // conflicted (SQ counters, r5: 45 % of this kernel's LDS cycles were conflict cycles), and every reader follows with a per-lane constant: the chain's
+    // ds_read_b128 takes the other 16-byte half on the swizzled rows (still conflict-free), a transpose read permutes its four chunks per lane group.
+#if PTR_B6_SWZ
+    const uint32_t swz = (uint32_t)((j >> 2) & 1);
+    const uint32_t wr_z = (uint32_t)(j * kB6ZRS) + 8u * ((uint32_t)g ^ (2u * swz));        // + 16 dt rows, + 32 tile bytes: this lane's 8 bytes of a 112-column image row
+    const uint32_t wr_x = (uint32_t)(j * kB6XRS) + 8u * ((uint32_t)g ^ (2u * swz));
+    const uint32_t rd_b = (uint32_t)(j * kB6ZRS + 32 * (g >> 1)) + 16u * (((uint32_t)g & 1u) ^ swz);       // chain B fragment: document j, 8 features from 32 s + 8 g
+    const uint32_t tr_z = (uint32_t)((4 * g + (j >> 2)) * kB6ZRS) + 8u * (((uint32_t)j & 3u) ^ (2u * ((uint32_t)g & 1u)));     // transpose-read chunk of a 112-column image (row 4 g + (j >> 2): its swizzle bit is g & 1)
+    const uint32_t tr_x = (uint32_t)((4 * g + (j >> 2)) * kB6XRS) + 8u * (((uint32_t)j & 3u) ^ (2u * ((uint32_t)g & 1u)));
+#else
     const uint32_t wr_z = (uint32_t)(j * kB6ZRS + 8 * g);            // + 16 dt rows, + 32 tile bytes: this lane's 8 bytes of a 112-column image row
     const uint32_t wr_x = (uint32_t)(j * kB6XRS + 8 * g);
     const uint32_t rd_b = (uint32_t)(j * kB6ZRS + 16 * g);           // chain B fragment: document j, 8 features from 32 s + 8 g
     const uint32_t tr_z = (uint32_t)((4 * g + (j >> 2)) * kB6ZRS + 8 * (j & 3));     // transpose-read chunk of a 112-column image
     const uint32_t tr_x = (uint32_t)((4 * g + (j >> 2)) * kB6XRS + 8 * (j & 3));
+#endif
 
     // the slab's fragment of tile t (16 features x 32 documents) of an image, k slot (G, e): e < 4 document 4 G + e, e >= 4 document 16 + 4 G + e - 4
     auto read_tr = [&](BFrag (&f)[3], uint32_t img_lane, int plane_bytes, int row_bytes, int t) __attribute__((always_inline)) {
