@@ -64,6 +64,10 @@ bool bwd_x6_supported(int R, int F, int NL, const void *X, const void *acts);
 int launch_bwd_x6(const float *X, const float *params, const float *acts, const float *dpreds, const MlpArgs &a, float *ws, hipStream_t st,
                   const char *who);
 
+bool bwd_x6_tail_supported(int R, int NL, const void *acts);
+int launch_bwd_x6_tail(const float *params, const float *acts, const float *dpreds, const MlpArgs &a, float *ws, float *dz0, hipStream_t st,
+                       const char *who);
+
 // ---- bf16x6 row contraction dW of the first layer for wide inputs (scorer_dw_x6.hip); interface of mlp_bwd_dw_lds_kernel
 bool dw_x6_supported(int R, int K, int lda, const void *A);
 int launch_dw_x6(const float *A, int lda, const float *dZ, int K, int nt_base, const MlpArgs &a, float *ws, size_t np_stride, size_t w_off, size_t b_off,

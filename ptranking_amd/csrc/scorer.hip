@@ -1284,7 +1284,9 @@ int ptr::mlp_backward_impl(const char *who, const float *X, const float *params,
     // behind them from the tail kernel's.
     const bool tail = R > 0 && bwd_tail_supported(NL, acts);
     if (tail) {
-        if (int e = launch_bwd_tail(params, acts, dpreds, a, ws, dz, st, who)) return e;
+        // r5: on the bf16 instructions for three hidden layers (the pipelined kernel's TAIL form, scorer_bwd_x6.hip); fp32-MFMA otherwise / PTR_BWD_X6=0
+        if (int e = bwd_x6_tail_supported(R, NL, acts) ? launch_bwd_x6_tail(params, acts, dpreds, a, ws, dz, st, who)
+                                                       : launch_bwd_tail(params, acts, dpreds, a, ws, dz, st, who)) return e;
     } else {
         const size_t lds = dz_lds_floats(NL) * sizeof(float);
         auto go = [&](auto kern) -> int {

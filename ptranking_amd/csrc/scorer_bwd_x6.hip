@@ -114,8 +114,12 @@ __device__ __forceinline__ uint32_t b6_opaque(uint32_t x) { asm volatile("" : "+
 template <int NT1>
 __global__ void __launch_bounds__(512, 2)
 mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, const float *__restrict__ acts, const float *__restrict__ dpreds,
-                  MlpArgs a, float *__restrict__ ws, size_t np_stride) {
-    static_assert(NT1 == 9, "the X image is laid out for nine in-feature tiles");
+                  MlpArgs a, float *__restrict__ ws, size_t np_stride, float *__restrict__ dz0) {
+    static_assert(NT1 == 9 || NT1 == 0, "the X image is laid out for nine in-feature tiles; NT1 = 0 is the TAIL form");
+    // NT1 == 0: the TAIL form for every other input width (r5; the fp32-MFMA kernel's TAIL form, scorer_bwd.hip, on the bf16 instructions): no X
+    // image, no dW_1 tiles — the chain's last result dZ_1 goes to HBM as fp32 (dz0 [R][112], row-major) for the first-layer dW kernel, which also takes
+    // db_1 off its column sums; what is left of the third phase is the next slab's staging pass.
+    constexpr bool TAIL = NT1 == 0;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_b6[];
     constexpr int NL = 3;
     const int F = a.F, R = a.R;
@@ -264,7 +268,8 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
     f32x4 xr[2][2];                        // X of the CURRENT slab, [tile slot][doc tile]: chain wave: slot 0 = tile w; wave 7: tiles 7, 8 — loaded
                                            // behind B1, turned into the XI image in front of B3 (it is only read by the dW_1 phase)
     float dsv[2];
-    const b6_rsrc xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0, (int)((uint32_t)R * (uint32_t)(F * 4)), 0x00020000);
+    const b6_rsrc xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0, TAIL ? 0 : (int)((uint32_t)R * (uint32_t)(F * 4)), 0x00020000);
+    const b6_rsrc zsrd = __builtin_amdgcn_make_buffer_rsrc(dz0, 0, TAIL ? (int)((uint32_t)R * (uint32_t)(kAL * 4)) : 0, 0x00020000);      // host: R * 448 < 4 GB
     const b6_rsrc dsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dpreds), 0, (int)((uint32_t)R * 4u), 0x00020000);
     const b6_srd asrd = b6_make_srd(acts, (uint32_t)NL * (uint32_t)(act_layer_floats(R) * 4));       // host: NL * ceil16(R) * 448 and R * F * 4 < 4 GB
     uint32_t jx = (uint32_t)j * (uint32_t)(F * 4) + (uint32_t)g * 16, j4 = (uint32_t)j * 4, l16 = (uint32_t)lane * 16;
@@ -384,7 +389,7 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
         // ---- chain 3 (dZ3 -> dZ2) + dW_3, chain 2 (dZ2 -> dZ1) + dW_2
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            if (c == PTR_B6_X_PHASE) load_x(slab);                  // live through this phase only (registers), staged in front of its barrier
+            if constexpr (!TAIL) { if (c == PTR_B6_X_PHASE) load_x(slab); }      // live through this phase only (registers), staged in front of its barrier
             const uint32_t zin = b6_opaque(lds0 + (c == 0 ? zi : zo)), zout = b6_opaque(lds0 + (c == 0 ? zo : zi) + (uint32_t)(32 * W));
             const uint32_t aim = b6_opaque(lds0 + (c == 0 ? kB6_A2 : kB6_A1));
             if (chain) {
@@ -428,7 +433,12 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
                     f32x4 dz;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dz[r] = (m >> (4 * dt + r)) & 1u ? cc[dt][r] * scale : 0.0f;
-                    b6_write4(zout + wr_z + (uint32_t)(16 * dt * kB6ZRS), kB6ZPL, dz);
+                    if (TAIL && c == 1) {        // dZ_1 leaves the chip: row (slab, dt, j), features 16 W + 4 g .. + 3 (rows past R: out of range, dropped)
+                        const uint32_t row = (uint32_t)(slab * kB6S + 16 * dt + j);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dz), zsrd, (int)(row < (uint32_t)R ? row * (kAL * 4) + (uint32_t)(64 * W + 16 * g) : 0xFFFFF000u), 0, 0);
+                    } else {
+                        b6_write4(zout + wr_z + (uint32_t)(16 * dt * kB6ZRS), kB6ZPL, dz);
+                    }
                 }
                 // dW of the layer whose dZ is the chain's INPUT: row w, in-tiles 0..4 of the activations below it
                 if (c == 0) dw_row(std::integral_constant<int, 5>{}, std::bool_constant<PTR_B6_X_PHASE != 0 || PTR_B6_PIPE_C2 != 0>{}, 0, zin, W, aim + tr_z, kB6ZPL, kB6ZRS, 0);
@@ -438,7 +448,7 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
                 for (int mo = 0; mo < 7; ++mo)       // wave 7: in-tiles 5, 6 of every row
                     dw_row(std::integral_constant<int, 2>{}, std::bool_constant<PTR_B6_PIPE_W7 != 0>{}, 14 * c + 2 * mo, zin, mo, aim + tr_z, kB6ZPL, kB6ZRS, 5);
             }
-            if (c == PTR_B6_X_PHASE) stage_x(slab);                  // the XI image (read by dW_1 only: free since the last B4)
+            if constexpr (!TAIL) { if (c == PTR_B6_X_PHASE) stage_x(slab); }     // the XI image (read by dW_1 only: free since the last B4)
             // (the DMA goes BEHIND the X staging: hipcc's waitcnt for the X registers does not count the asm DMA, a wait placed behind it would
             // wait for the whole prefetch)
 #if PTR_B6_PREFETCH_LATE
@@ -455,6 +465,9 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
         // ---- dW_1: dZ1 (in `zi`) x the X image  ||  the staging pass of the next slab (-> `zo`, A2, A1: nobody reads them in this phase)
         {
             const bool more = slab + (int)gridDim.x < nslabs;       // wave-uniform
+            if constexpr (TAIL) {
+                if (more) staging(zo);
+            } else {
             const uint32_t za = b6_opaque(lds0 + zi), xi = b6_opaque(lds0 + kB6_XI) + tr_x;
             auto dw1 = [&]() __attribute__((always_inline)) {
                 if (chain) {
@@ -505,6 +518,7 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
             }
 #endif
         }
+            }
         B6_STAMP();
         b6_barrier();                                                // B4: dZ1 / X consumed, next slab's images complete, staging area free
         B6_STAMP();
@@ -535,8 +549,10 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
     if (chain) {
 #pragma unroll
         for (int n = 0; n < 5; ++n) { store_tile(st[n], 2, W, n); store_tile(st[5 + n], 1, W, n); }
+        if constexpr (!TAIL) {
 #pragma unroll
-        for (int n = 0; n < 8; ++n) store_tile(st[10 + n], 0, W, n);
+            for (int n = 0; n < 8; ++n) store_tile(st[10 + n], 0, W, n);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float v = awo[r];
@@ -556,7 +572,7 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
         for (int mo = 0; mo < 7; ++mo) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) { store_tile(st[2 * mo + q], 2, mo, 5 + q); store_tile(st[14 + 2 * mo + q], 1, mo, 5 + q); }
-            store_tile(st[28 + mo], 0, mo, 8);
+            if constexpr (!TAIL) store_tile(st[28 + mo], 0, mo, 8);
         }
     }
 }
@@ -580,7 +596,25 @@ int launch_bwd_x6(const float *X, const float *params, const float *acts, const 
     const size_t NP = n_params(a.NL, a.F);
     auto kern = mlp_bwd_x6_kernel<9>;
     if (int e = allow_lds(kern, kB6Lds)) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), kB6Lds, st, X, params, acts, dpreds, a, ws, NP);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), kB6Lds, st, X, params, acts, dpreds, a, ws, NP, (float *)nullptr);
+    return check_hip(hipGetLastError(), who);
+}
+
+// The TAIL form (every input width, three hidden layers): dZ chain + the hidden layers' gradients + d w_out / d b_out in one pass over the stored
+// activations on the bf16 instructions, dZ of the first layer written to dz0 [R][112] for the first-layer dW kernel.  Same grid and partial layout as
+// the fp32-MFMA tail kernel (launch_bwd_tail, scorer_bwd.hip), which PTR_BWD_X6=0 keeps.
+bool bwd_x6_tail_supported(int R, int NL, const void *acts) {
+    if (bwd_x6_mode() == 0) return false;
+    if ((uint64_t)NL * (uint64_t)act_layer_floats(R) * 4 >= 0xFFFFF000ull || (uint64_t)R * (kAL * 4) >= 0xFFFFF000ull) return false;      // buffer resources: < 4 GB
+    return NL == 3 && (reinterpret_cast<uintptr_t>(acts) & 15) == 0;
+}
+int launch_bwd_x6_tail(const float *params, const float *acts, const float *dpreds, const MlpArgs &a, float *ws, float *dz0, hipStream_t st,
+                       const char *who) {
+    const int grid = bwd_fused_grid(a.R);
+    const size_t NP = n_params(a.NL, a.F);
+    auto kern = mlp_bwd_x6_kernel<0>;
+    if (int e = allow_lds(kern, kB6Lds)) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), kB6Lds, st, (const float *)nullptr, params, acts, dpreds, a, ws, NP, dz0);
     return check_hip(hipGetLastError(), who);
 }
 
