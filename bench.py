@@ -458,7 +458,7 @@ def main():
     extras = {}
     if world == 1 and args.scorer == "pointsf" and (args.extras == "on" or (args.extras == "auto" and headline and B >= 1024)):
         # (i) the padded variant: the same step on lists of MSLR-like lengths padded to L, through `lens` (what PaddedQueryBatches feeds)
-        el, _, _, _ = measure(ranker, B, args.sweep_steps, args.warmup, 1, padded=True)
+        el, _, _, _ = measure(ranker, B, args.sweep_steps, args.warmup, 1, padded=True)      # (same kernels as the headline: no separate guard)
         extras["padded"] = {"value": B * args.sweep_steps / el, "unit": "queries/s", "ms_per_step": 1e3 * el / args.sweep_steps,
                             "mean_len": measure.mean_len, "padded_len": L, "documents_per_s": B * measure.mean_len * args.sweep_steps / el,
                             "steps": args.sweep_steps,
@@ -466,7 +466,10 @@ def main():
                                     "runs on all padded rows, the loss kernel skips padded documents"}
         # (ii) the metric path: Evaluator.ndcg_at_ks + ap_at_k (ptranking/base/ranker.py:67-95,130-160) over a synthetic loader, device-resident
         # (predict -> metrics kernel, nothing leaves the GPU but [len(ks)] numbers) vs the port's CPU loop (predict -> sort -> gather -> metric)
-        extras["metric_path"] = metric_path(ranker, B, L, F, device, rank)
+        try:
+            extras["metric_path"] = metric_path(ranker, B, L, F, device, rank)
+        except Exception as e:                     # an extra must never take the contract's line down with it
+            extras["metric_path"] = {"error": f"{type(e).__name__}: {e}"}
         # (iii) BASELINE.json configs 1, 3, 4, 5: one short window each (10 steps) so that the driver's record carries them
         cfgs = [("C1_ranknet_L32", "RankNet", "pointsf", 32, 136, 4096), ("C3_listnet_L256", "ListNet", "pointsf", 256, 136, 4096),
                 ("C3_listmle_L256", "ListMLE", "pointsf", 256, 136, 4096), ("C4_approxndcg_L512_F700", "ApproxNDCG", "pointsf", 512, 700, 1024),
@@ -476,11 +479,15 @@ def main():
         for tag, loss_c, scorer_c, Lc, Fc, Bc in cfgs:
             Bc = min(Bc, B)
             torch.cuda.empty_cache()
-            rc = build_ranker(loss_c, scorer_c, F=Fc)
-            el, _, _, _ = measure(rc, Bc, 10, 2, 1, L=Lc, F=Fc, nbatches=2, prewarm_steps=6)
-            extras["configs"][tag] = {"value": Bc * 10 / el, "unit": "queries/s", "ms_per_step": 1e3 * el / 10, "steps": 10, "loss": loss_c,
-                                      "scorer": scorer_c, "list_len": Lc, "features": Fc, "queries_per_step": Bc}
-            del rc
+            try:
+                rc = build_ranker(loss_c, scorer_c, F=Fc)
+                el, _, _, _ = measure(rc, Bc, 10, 2, 1, L=Lc, F=Fc, nbatches=2, prewarm_steps=6)
+                extras["configs"][tag] = {"value": Bc * 10 / el, "unit": "queries/s", "ms_per_step": 1e3 * el / 10, "steps": 10, "loss": loss_c,
+                                          "scorer": scorer_c, "list_len": Lc, "features": Fc, "queries_per_step": Bc}
+                del rc
+            except Exception as e:
+                gc.enable()
+                extras["configs"][tag] = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
 
     # the loss kernel alone, at the headline list length and at the north-star's stated one (BASELINE.json: list_len=256), same
