@@ -215,117 +215,197 @@ lambdaloss_kernel(const float *__restrict__ preds, const float *__restrict__ lab
 // arg-max (score descending, document index ascending on ties — the order count_ranks gives) pick them, their kk (kk - 1) / 2 pairs are
 // evaluated ONE PAIR PER LANE with the arithmetic of lambdaloss_kernel's pair body, and the gradient row is zeros plus kk patched
 // entries.  One wavefront per query, everything in registers, float4 loads / stores; the IDCG is the only full-length pass.
+//
+// Persistent wavefronts (a grid-stride walk over the queries): what depends on the lane alone — the discount of its positions, the
+// double-inverted discount inv[lane], the (a, b) pair of the lane and that pair's position weights — is computed once per wavefront
+// (the pair table again only when kk changes, i.e. for lists shorter than k).  Up to 256 documents (V = 1) each lane keeps its four
+// documents ordered, so a selection round is one DPP max ladder, a ballot and a pop in the winning lane (the lowest lane among equal
+// heads holds the lowest index); the pair body runs on the transcendental pipe while every pair of the query has |sigma ds| <= 80 (the
+// RankNet kernel's policy: pairwise.hip), the library functions otherwise.
 template <int V>
 __global__ void __launch_bounds__(kBlock)
 lambdaloss_topk_kernel(const float *__restrict__ preds, const float *__restrict__ labels, const int32_t *__restrict__ lens, int B, int L,
                        int k, float sigma, float mu, int loss_type, float *__restrict__ loss_q, float *__restrict__ grad) {
     constexpr int E = 4 * V;
+    constexpr int kDead = 0x7fffffff;
     const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
-    if (q >= B) return;                                            // waves are independent
-    const int n = query_len(lens, q, L), L4 = L >> 2;
-    const f32x4 *ps = reinterpret_cast<const f32x4 *>(preds + (size_t)q * L), *py = reinterpret_cast<const f32x4 *>(labels + (size_t)q * L);
-    float s[E], y[E];
-    float part = 0.0f;
+    const int wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6));
+    const int nwaves = gridDim.x * (kBlock / kWave), L4 = L >> 2;
+    const float eps = 1e-8f, inv_ln2 = 1.4426950408889634f, log2_eps = -26.575424759098897f;
+    float disc[E];
 #pragma unroll
-    for (int m = 0; m < V; ++m) {
-        const int c = lane + 64 * m;
-        const f32x4 a = ps[c < L4 ? c : 0], b = py[c < L4 ? c : 0];
+    for (int m = 0; m < V; ++m)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int i = 4 * c + e;
-            const bool in = i < n;
-            s[4 * m + e] = in ? a[e] : -INFINITY;
-            y[4 * m + e] = in ? b[e] : 0.0f;
-            part += in ? (__builtin_amdgcn_exp2f(b[e]) - 1.0f) * inv_log2_pos(i) : 0.0f;   // IDCG of the (presorted = ideal) label order,
-            // adhoc_metric.py:205-217 (2^l - 1 on v_exp_f32: exact for the integer grades, 1 ulp otherwise)
-        }
-    }
-    const float idcg = wave_sum_dpp(part);
-    const int kk = k < n ? (k < 0 ? 0 : k) : n;
-    // ---- the kk best documents, in rank order: record r lives in lane r
-    float rs = 0.0f, ry = 0.0f;
-    int ri = -1;
-    for (int r = 0; r < kk; ++r) {
-        float best = -INFINITY, blab = 0.0f;
-        int bidx = 0x7fffffff;
+        for (int e = 0; e < 4; ++e) disc[4 * m + e] = inv_log2_pos(4 * (lane + 64 * m) + e);
+    const float rinv = 1.0f / (1.0f / log2f((float)lane + 2.0f));                          // inv[rank], rank = lane (lambdaloss.py:41,49,94)
+    int kk_tab = -1, aa = 0, b = 0;                                                        // the lane's pair (aa < b < kk) for kk == kk_tab
+    bool has = false;
+    float delta = 0.0f, dpos = 0.0f;
+    for (int q = wave0; q < B; q += nwaves) {                                              // waves are independent
+        const int n = query_len(lens, q, L);
+        const f32x4 *ps = reinterpret_cast<const f32x4 *>(preds + (size_t)q * L), *py = reinterpret_cast<const f32x4 *>(labels + (size_t)q * L);
+        float s[E], y[E];
+        float part = 0.0f;
 #pragma unroll
-        for (int m = 0; m < V; ++m)
+        for (int m = 0; m < V; ++m) {
+            const int c = lane + 64 * m;
+            const f32x4 a4 = ps[c < L4 ? c : 0], b4 = py[c < L4 ? c : 0];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int i = 4 * (lane + 64 * m) + e;
-                const bool live = i < n && s[4 * m + e] == s[4 * m + e];           // NaN scores never win (the reference sorts them last)
-                const bool better = live && (bidx == 0x7fffffff || s[4 * m + e] > best);
-                best = better ? s[4 * m + e] : best; blab = better ? y[4 * m + e] : blab; bidx = better ? i : bidx;
+                const int i = 4 * c + e;
+                const bool in = i < n;
+                s[4 * m + e] = in ? a4[e] : -INFINITY;
+                y[4 * m + e] = in ? b4[e] : 0.0f;
+                part += in ? (__builtin_amdgcn_exp2f(b4[e]) - 1.0f) * disc[4 * m + e] : 0.0f;   // IDCG of the (presorted = ideal) label order,
+                // adhoc_metric.py:205-217 (2^l - 1 on v_exp_f32: exact for the integer grades, 1 ulp otherwise)
             }
-        const float gmax = wave_max_dpp(bidx == 0x7fffffff ? -INFINITY : best);   // DPP ladders: no LDS crossbar round trips in the selection
-        const int cand = wave_min_i32_dpp((bidx != 0x7fffffff && best == gmax) ? bidx : 0x7fffffff);
-        if (cand == 0x7fffffff) break;                                              // fewer than kk rankable documents (all NaN)
-        const uint64_t own = __builtin_amdgcn_ballot_w64(bidx == cand);
-        const int wl = (int)__builtin_ctzll(own);
-        const float wlab = __shfl(blab, wl, 64);
-        if (lane == r) { rs = gmax; ry = wlab; ri = cand; }
+        }
+        const float idcg = wave_sum_dpp(part);
+        const int kk = k < n ? (k < 0 ? 0 : k) : n;
+        if (kk != kk_tab) {                                                                // uniform: kk depends on the query alone
+            kk_tab = kk;
+            const int npairs = kk * (kk - 1) / 2;
+            int a = 0, rem = lane;
+            for (int it = 0; it < 11; ++it) { const int row = kk - 1 - a; if (rem >= row && row > 0) { rem -= row; ++a; } }
+            has = lane < npairs;
+            b = has ? a + 1 + rem : 0;
+            aa = has ? a : 0;
+            const float ia = __shfl(rinv, aa, 64), ib = __shfl(rinv, b, 64);
+            const int dist = b - aa;
+            const float id0 = __shfl(rinv, dist > 0 ? dist - 1 : 0, 64), id1 = __shfl(rinv, dist, 64);
+            delta = fabsf(id0 - id1);                                                      // :44
+            dpos = fabsf(ia - ib);                                                         // :57
+        }
+        // ---- the kk best documents, in rank order: record r lives in lane r
+        float rs = 0.0f, ry = 0.0f;
+        int ri = -1;
+        if constexpr (V == 1) {
+            float hs[4], hy[4];
+            int hi[4];
 #pragma unroll
-        for (int m = 0; m < V; ++m)
+            for (int e = 0; e < 4; ++e) {
+                const int i = 4 * lane + e;
+                const bool live = i < n && s[e] == s[e];                                   // NaN scores never win (the reference sorts them last)
+                hs[e] = live ? s[e] : -INFINITY; hy[e] = y[e]; hi[e] = live ? i : kDead;
+            }
+            auto cx = [&](int u, int w) {                                                  // position u keeps the better (score desc, index asc)
+                const bool sw = hs[w] > hs[u] || (hs[w] == hs[u] && hi[w] < hi[u]);
+                const float s0 = sw ? hs[w] : hs[u], s1 = sw ? hs[u] : hs[w], y0 = sw ? hy[w] : hy[u], y1 = sw ? hy[u] : hy[w];
+                const int i0 = sw ? hi[w] : hi[u], i1 = sw ? hi[u] : hi[w];
+                hs[u] = s0; hs[w] = s1; hy[u] = y0; hy[w] = y1; hi[u] = i0; hi[w] = i1;
+            };
+            cx(0, 1); cx(2, 3); cx(0, 2); cx(1, 3); cx(1, 2);
+            for (int r = 0; r < kk; ++r) {
+                const float gmax = wave_max_dpp(hs[0]);                                    // DPP ladder: no LDS crossbar round trips in the selection
+                const uint64_t own = __builtin_amdgcn_ballot_w64(hi[0] != kDead && hs[0] == gmax);
+                if (own == 0) break;                                                       // fewer than kk rankable documents (all NaN)
+                const int wl = (int)__builtin_ctzll(own);                                  // the lowest lane holds the lowest index
+                const float wy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hy[0]), wl));
+                const int wi = __builtin_amdgcn_readlane(hi[0], wl);
+                if (lane == r) { rs = gmax; ry = wy; ri = wi; }
+                if (lane == wl) {
+                    hs[0] = hs[1]; hy[0] = hy[1]; hi[0] = hi[1];
+                    hs[1] = hs[2]; hy[1] = hy[2]; hi[1] = hi[2];
+                    hs[2] = hs[3]; hy[2] = hy[3]; hi[2] = hi[3];
+                    hs[3] = -INFINITY; hi[3] = kDead;
+                }
+            }
+        } else {
+            for (int r = 0; r < kk; ++r) {
+                float best = -INFINITY, blab = 0.0f;
+                int bidx = kDead;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (4 * (lane + 64 * m) + e == cand) s[4 * m + e] = __builtin_nanf("");   // taken: never live again
-    }
-    // ---- pairs (a < b < kk), one per lane; arithmetic of lambdaloss_kernel's pair body
-    const float eps = 1e-8f, inv_ln2 = 1.4426950408889634f, log2_eps = -26.575424759098897f;
-    const float rG = ri >= 0 ? (__builtin_amdgcn_exp2f(ry) - 1.0f) / idcg : 0.0f;          // lambdaloss.py:106
-    const float rinv = 1.0f / (1.0f / log2f((float)lane + 2.0f));                          // inv[rank], rank = lane (lambdaloss.py:41,49,94)
-    const int npairs = kk * (kk - 1) / 2;
-    int a = 0, rem = lane;
-    for (int it = 0; it < 11; ++it) { const int row = kk - 1 - a; if (rem >= row && row > 0) { rem -= row; ++a; } }
-    const bool has = lane < npairs;
-    const int b = has ? a + 1 + rem : 0;
-    const int aa = has ? a : 0;
-    const float sa = __shfl(rs, aa, 64), sb = __shfl(rs, b, 64), ya = __shfl(ry, aa, 64), yb = __shfl(ry, b, 64);
-    const float Ga = __shfl(rG, aa, 64), Gb = __shfl(rG, b, 64), ia = __shfl(rinv, aa, 64), ib = __shfl(rinv, b, 64);
-    const int dist = b - aa;
-    const float id0 = __shfl(rinv, dist > 0 ? dist - 1 : 0, 64), id1 = __shfl(rinv, dist, 64);
-    float lacc = 0.0f, g_a = 0.0f;
-    const bool a_wins = ya > yb, b_wins = yb > ya;                                        // lambdaloss.py:127-128
-    if (has && (a_wins || b_wins)) {
-        const float delta = fabsf(id0 - id1);
+                for (int m = 0; m < V; ++m)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = 4 * (lane + 64 * m) + e;
+                        const bool live = i < n && s[4 * m + e] == s[4 * m + e];
+                        const bool better = live && (bidx == kDead || s[4 * m + e] > best);
+                        best = better ? s[4 * m + e] : best; blab = better ? y[4 * m + e] : blab; bidx = better ? i : bidx;
+                    }
+                const float gmax = wave_max_dpp(bidx == kDead ? -INFINITY : best);
+                const int cand = wave_min_i32_dpp((bidx != kDead && best == gmax) ? bidx : kDead);
+                if (cand == kDead) break;
+                const uint64_t own = __builtin_amdgcn_ballot_w64(bidx == cand);
+                const int wl = (int)__builtin_ctzll(own);
+                const float wlab = __shfl(blab, wl, 64);
+                if (lane == r) { rs = gmax; ry = wlab; ri = cand; }
+#pragma unroll
+                for (int m = 0; m < V; ++m)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (4 * (lane + 64 * m) + e == cand) s[4 * m + e] = __builtin_nanf("");   // taken: never live again
+            }
+        }
+        // ---- pairs (a < b < kk), one per lane; arithmetic of lambdaloss_kernel's pair body
+        const float rG = ri >= 0 ? (__builtin_amdgcn_exp2f(ry) - 1.0f) / idcg : 0.0f;      // lambdaloss.py:106
+        const float sa = __shfl(rs, aa, 64), sb = __shfl(rs, b, 64), ya = __shfl(ry, aa, 64), yb = __shfl(ry, b, 64);
+        const float Ga = __shfl(rG, aa, 64), Gb = __shfl(rG, b, 64);
+        float lacc = 0.0f, g_a = 0.0f;
+        const bool a_wins = ya > yb, b_wins = yb > ya;                                     // lambdaloss.py:127-128
+        const bool act = has && (a_wins || b_wins);
         const float absG = fabsf(Ga - Gb);
         float w = delta * absG;                                                            // NDCG_Loss2, :44
-        if (loss_type == PTR_LAMBDALOSS_NDCG_LOSS2PP) w = (fabsf(ia - ib) + mu * delta) * absG;   // :57
+        if (loss_type == PTR_LAMBDALOSS_NDCG_LOSS2PP) w = (dpos + mu * delta) * absG;      // :57
         float df = a_wins ? sa - sb : sb - sa;
         df = fminf(fmaxf(df, -1e8f), 1e8f);
         if (df != df) df = 0.0f;                                                           // :115-116
         const float x = sigma * df;
-        const float p0 = 1.0f / (1.0f + expf(-x));
-        const float lp = p0 >= eps ? -log1pf(expf(-x)) * inv_ln2 : log2_eps;
-        const float z = w * lp;
-        const bool wp_ok = z >= log2_eps;
-        lacc = -(wp_ok ? z : log2_eps);                                                    // :118-119,132
-        float g = 0.0f;
-        if (p0 >= eps && wp_ok) g = -(w * sigma * (1.0f - p0)) * inv_ln2;
-        g_a = a_wins ? g : -g;                                                             // d loss / d s_a; s_b gets the negative
+        float p0, lp;
+        if (__any(act && !(fabsf(x) <= 80.0f))) {
+            p0 = 1.0f / (1.0f + expf(-x));
+            lp = p0 >= eps ? -log1pf(expf(-x)) * inv_ln2 : log2_eps;
+        } else {
+            // e = exp(-|x|) is a normal float; the larger probability is 1 / (1 + e) by v_rcp + one Newton step, log2 p = min(x, 0) log2(e) -
+            // log2(1 + e) with one v_log_f32 (1 ulp: 1e-7 absolute near p = 1)
+            const float e = __expf(-fabsf(x));
+            const float dd = 1.0f + e;
+            float pb = __builtin_amdgcn_rcpf(dd);
+            pb = fmaf(pb, fmaf(-dd, pb, 1.0f), pb);
+            p0 = x >= 0.0f ? pb : e * pb;
+            lp = p0 >= eps ? fminf(x, 0.0f) * inv_ln2 - __builtin_amdgcn_logf(dd) : log2_eps;
+        }
+        if (act) {
+            const float z = w * lp;
+            const bool wp_ok = z >= log2_eps;
+            lacc = -(wp_ok ? z : log2_eps);                                                // :118-119,132
+            float g = 0.0f;
+            if (p0 >= eps && wp_ok) g = -(w * sigma * (1.0f - p0)) * inv_ln2;
+            g_a = a_wins ? g : -g;                                                         // d loss / d s_a; s_b gets the negative
+        }
+        const float loss = wave_sum_dpp(lacc);
+        // ---- gradient of record r = lane: its kk - 1 pairs, gathered from the pair lanes (pair (a, b) sits in lane a (kk - 1) - a (a - 1) / 2
+        //      + b - a - 1)
+        float gr = 0.0f;
+        for (int o = 0; o < kk; ++o) {
+            const int a_ = lane < o ? lane : o, b_ = lane < o ? o : lane;
+            const int pl = a_ * (kk - 1) - ((a_ * (a_ - 1)) >> 1) + (b_ - a_ - 1);
+            const float gv = __shfl(g_a, pl & 63, 64);
+            if (o != lane && lane < kk) gr += lane < o ? gv : -gv;
+        }
+        // ---- gradient row: zeros + the kk records' entries
+        f32x4 o4[V];
+#pragma unroll
+        for (int m = 0; m < V; ++m) o4[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < kk; ++r) {
+            const int idx = __builtin_amdgcn_readlane(ri, r);
+            const float gq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gr), r));
+            if (idx < 0) break;                                                            // records are filled in order
+            const bool mine = lane == ((idx >> 2) & 63);
+#pragma unroll
+            for (int m = 0; m < V; ++m)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if ((idx >> 8) == m && (idx & 3) == e) o4[m][e] = mine ? gq : o4[m][e];   // scalar condition: one select per record
+        }
+        f32x4 *go = reinterpret_cast<f32x4 *>(grad + (size_t)q * L);
+#pragma unroll
+        for (int m = 0; m < V; ++m) {
+            const int c = lane + 64 * m;
+            if (c < L4) go[c] = o4[m];
+        }
+        if (lane == 0) loss_q[q] = loss;
     }
-    const float loss = wave_sum_dpp(lacc);
-    // ---- gradient row: zeros + the kk records' entries
-    f32x4 o[V];
-#pragma unroll
-    for (int m = 0; m < V; ++m) o[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int r = 0; r < kk; ++r) {
-        const float gr = wave_sum_dpp((has && aa == r ? g_a : 0.0f) - (has && b == r ? g_a : 0.0f));
-        const int idx = __shfl(ri, r, 64);
-#pragma unroll
-        for (int m = 0; m < V; ++m)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (4 * (lane + 64 * m) + e == idx) o[m][e] = gr;
-    }
-    f32x4 *go = reinterpret_cast<f32x4 *>(grad + (size_t)q * L);
-#pragma unroll
-    for (int m = 0; m < V; ++m) {
-        const int c = lane + 64 * m;
-        if (c < L4) go[c] = o[m];
-    }
-    if (lane == 0) loss_q[q] = loss;
 }
 
 }  // namespace ptr
@@ -348,7 +428,8 @@ extern "C" int ptr_lambdaloss_fwd_bwd(const float *preds, const float *labels, c
     if (B > 0 && topk) {
         // small cut-off on presorted labels: wavefront arg-max selection instead of a sort, one pair per lane (lambdaloss_topk_kernel)
         auto go = [&](auto kern) -> int {
-            hipLaunchKernelGGL(kern, dim3((B + 3) / 4), dim3(kBlock), 0, st, preds, labels, lens, B, L, k, sigma, mu, loss_type, loss_q, grad);
+            const int blocks = (B + 3) / 4;                        // persistent wavefronts: at most 8 blocks of 4 per CU, each walks its queries
+            hipLaunchKernelGGL(kern, dim3(blocks < 2048 ? blocks : 2048), dim3(kBlock), 0, st, preds, labels, lens, B, L, k, sigma, mu, loss_type, loss_q, grad);
             return check_hip(hipGetLastError(), who);
         };
         if (int rc = L <= 256 ? go(lambdaloss_topk_kernel<1>) : (L <= 512 ? go(lambdaloss_topk_kernel<2>) : go(lambdaloss_topk_kernel<4>))) return rc;

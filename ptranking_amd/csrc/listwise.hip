@@ -247,12 +247,6 @@ listmle_kernel(const float *__restrict__ preds, const int64_t *__restrict__ perm
 // likewise (DPP).  exp / log on the transcendental pipe while the list's score range is below 24 (argument error <= 24 * 2^-24: 1.4e-6
 // relative), libm otherwise (EXACT: denormal tail sums, ranges up to the fp32 exponent) — decided per wavefront.
 using i64x2 = __attribute__((ext_vector_type(2))) long long;
-__device__ __forceinline__ float dpp_wave_shl1(float v) {      // lane t <- lane t + 1, lane 63 <- 0
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float dpp_wave_shr1(float v) {      // lane t <- lane t - 1, lane 0 <- 0
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138 /* wave_shr:1 */, 0xF, 0xF, true));
-}
 template <int V, bool EXACT>
 __device__ __forceinline__ void listmle_vec_body(const f32x4 (&a)[V], const int (&pi)[4 * V], int n, int lane, float m, float *S,
                                                  float &loss_out, f32x4 (&gout)[V]) {
@@ -505,7 +499,66 @@ __device__ __forceinline__ uint32_t tie_hash(uint32_t qkey, uint32_t i) { return
 
 // perm = argsort by (label descending, random key ascending, index ascending): a uniformly random order inside every
 // group of equal labels — the distribution arg_shuffle_ties draws from (sampling_utils.py:13-28).
-// Integer grades in [0, 63] (MultiLabel) take the fast path: label and an 18-bit random field are packed into ONE float key
+//
+// r5, lists of up to 1024 documents (one wavefront per query): integer grades in [0, 63] (MultiLabel) are packed with the random field and
+// the document index into ONE 32-bit key   label : 6 | (2^FB - 1 - field) : FB | (N - 1 - index) : IB   (N = 64 DPT padded positions,
+// IB = log2 N, FB = 26 - IB: 18 bits at 256 documents), the keys are sorted in registers by the bitonic network and the permutation is READ
+// OFF the sorted keys' index bits: no rank search, no LDS, 16-byte loads and stores (lane t owns positions 4t .. 4t+3).  Equal fields order
+// by index, as in the counting form.  Other labels (or another wave's query in the same launch) take the exact three-way comparison below.
+typedef long i64x2_t __attribute__((ext_vector_type(2)));
+template <int DPT>
+__device__ __forceinline__ bool shuffle_ties_wave(const float *__restrict__ labels, int q, int n, int L, uint32_t qkey, int t,
+                                                  int64_t *__restrict__ perm) {
+    constexpr int N = kWave * DPT;
+    constexpr int IB = DPT == 1 ? 6 : DPT == 2 ? 7 : DPT == 4 ? 8 : DPT == 8 ? 9 : 10, FB = 26 - IB;
+    const float *row = labels + (size_t)q * L;
+    const bool vec = DPT % 4 == 0 && (L & 3) == 0;
+    float y[DPT];
+    if (vec) {
+#pragma unroll
+        for (int r4 = 0; r4 < DPT; r4 += 4) {
+            const int i = t * DPT + r4;
+            const f32x4 v = i < L ? *reinterpret_cast<const f32x4 *>(row + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) y[r4 + c] = v[c];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < DPT; ++r) y[r] = t * DPT + r < n ? row[t * DPT + r] : 0.0f;
+    }
+    uint32_t key[DPT];
+    bool small_int = true;
+#pragma unroll
+    for (int r = 0; r < DPT; ++r) {
+        const int i = t * DPT + r;
+        const bool in = i < n;
+        small_int &= !in || (y[r] >= 0.0f && y[r] < 64.0f && y[r] == floorf(y[r]));
+        const uint32_t field = tie_hash(qkey, (uint32_t)i) >> (32 - FB);
+        key[r] = in ? ((uint32_t)y[r] << (FB + IB)) | ((((1u << FB) - 1u) - field) << IB) | (uint32_t)(N - 1 - i) : 0u;
+    }
+    if (!__all(small_int)) return false;
+    wave_sort_desc<DPT>(key, t);                               // padded positions (key 0) sort behind every document
+    int64_t *orow = perm + (size_t)q * L;
+    if (vec) {
+#pragma unroll
+        for (int r2 = 0; r2 < DPT; r2 += 2) {
+            const int p = t * DPT + r2;
+            i64x2_t o;
+            o[0] = p < n ? (long)(N - 1 - (int)(key[r2] & (N - 1))) : (long)p;
+            o[1] = p + 1 < n ? (long)(N - 1 - (int)(key[r2 + 1] & (N - 1))) : (long)(p + 1);
+            if (p < L) *reinterpret_cast<i64x2_t *>(orow + p) = o;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < DPT; ++r) {
+            const int p = t * DPT + r;
+            if (p < L) orow[p] = p < n ? (int64_t)(N - 1 - (int)(key[r] & (N - 1))) : (int64_t)p;
+        }
+    }
+    return true;
+}
+
+// Longer lists (four wavefronts per query) and the general path: label and an 18-bit random field are packed into ONE float key
 // (exact below 2^24) and ranked by the shared counting sort; field collisions fall back to index order inside count_ranks'
 // tie pass.  Anything else ranks with the exact three-way comparison.
 template <int G, int DPT>
@@ -515,16 +568,20 @@ shuffle_ties_kernel(const float *__restrict__ labels, const int32_t *__restrict_
     constexpr int QPB = kBlock / G;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, grp = tid / G, t = tid % G;
-    const int q = blockIdx.x * QPB + grp;
+    const int q = G == kWave ? __builtin_amdgcn_readfirstlane(blockIdx.x * QPB + grp) : blockIdx.x * QPB + grp;   // one wavefront per query: scalar
     const bool valid = q < B;
     const int n = valid ? query_len(lens, q, L) : 0;
     float *keys = smem + (size_t)grp * 3 * Lp;                 // packed keys (fast path) / labels (general path)
     uint32_t *rnd = reinterpret_cast<uint32_t *>(keys + Lp);
     int *out = reinterpret_cast<int *>(keys + 2 * Lp);
+    const uint32_t qkey = tie_query_key(seed, (uint32_t)q);
+    if constexpr (G == kWave) {
+        if (!valid) return;                                    // the waves of a block are independent: no workgroup barrier on this path
+        if (shuffle_ties_wave<DPT>(labels, q, n, L, qkey, t, perm)) return;
+    }
     float y[DPT], key[DPT];
     uint32_t r[DPT];
     bool small_int = true;
-    const uint32_t qkey = tie_query_key(seed, (uint32_t)q);
 #pragma unroll
     for (int m = 0; m < DPT; ++m) {
         const int i = t + m * G;
@@ -536,7 +593,7 @@ shuffle_ties_kernel(const float *__restrict__ labels, const int32_t *__restrict_
     }
     bool fast;
     if constexpr (G == kWave) {
-        fast = __all(small_int);                  // one wavefront per query: the waves of a block are independent, no workgroup barrier anywhere
+        fast = false;                             // the packed-key path above declined: labels that are not small integer grades
     } else {
         // one decision per workgroup keeps the barriers below uniform
         int *all_small = reinterpret_cast<int *>(smem + (size_t)QPB * 3 * Lp);   // carved from the dynamic region (no static LDS in

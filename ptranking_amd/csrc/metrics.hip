@@ -23,11 +23,73 @@ sort_desc_kernel(const float *__restrict__ preds, const int32_t *__restrict__ le
     constexpr int QPB = kBlock / G;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, grp = tid / G, t = tid % G;
-    const int q = blockIdx.x * QPB + grp;
+    const int q = G == kWave ? __builtin_amdgcn_readfirstlane(blockIdx.x * QPB + grp) : blockIdx.x * QPB + grp;   // one wavefront per query: scalar
     const bool valid = q < B;
     const int n = valid ? query_len(lens, q, L) : 0;
     float *keys = smem + (size_t)grp * 3 * Lp, *sv = keys + Lp;
     int *si_ = reinterpret_cast<int *>(sv + Lp);
+    if constexpr (G == kWave) {
+        // r5, one wavefront per query: blocked layout (lane t owns documents / positions t*DPT ..), 16-byte loads and stores
+        if (!valid) return;
+        float own[DPT], v[DPT];
+        int rk[DPT];
+        load_blocked<DPT>(preds + (size_t)q * L, n, L, t, -INFINITY, own);
+        float *vrow = vals + (size_t)q * L;
+        int64_t *irow = idx + (size_t)q * L;
+        typedef long i64x2_t __attribute__((ext_vector_type(2)));
+        if constexpr (DPT == 2 || DPT == 4) {
+            // 65 .. 256 documents: packed (score, index) keys, the permutation read off the sorted keys (no rank search)
+            float sc[DPT];
+            int id[DPT];
+            if (sort_scores_packed<DPT>(keys, n, t, own, sc, id)) {
+                if (DPT == 4 && (L & 3) == 0) {
+                    const int p = t * 4;
+                    if (p < L) {
+                        *reinterpret_cast<float4 *>(vrow + p) = float4{p < n ? sc[0] : 0.0f, p + 1 < n ? sc[1] : 0.0f, p + 2 < n ? sc[2] : 0.0f, p + 3 < n ? sc[3] : 0.0f};
+                        *reinterpret_cast<i64x2_t *>(irow + p) = i64x2_t{p < n ? (long)id[0] : (long)p, p + 1 < n ? (long)id[1] : (long)(p + 1)};
+                        *reinterpret_cast<i64x2_t *>(irow + p + 2) = i64x2_t{p + 2 < n ? (long)id[2] : (long)(p + 2), p + 3 < n ? (long)id[3] : (long)(p + 3)};
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < DPT; ++r) {
+                        const int p = t * DPT + r;
+                        if (p < L) { vrow[p] = p < n ? sc[r] : 0.0f; irow[p] = p < n ? (int64_t)id[r] : (int64_t)p; }
+                    }
+                }
+                return;
+            }
+            wave_lds_sync();
+        }
+        rank_blocked_wave<DPT>(keys, sv, n, t, own, rk, v);
+#pragma unroll
+        for (int r = 0; r < DPT; ++r) {
+            const int i = t * DPT + r;
+            if (i < n) { sv[rk[r]] = own[r]; si_[rk[r]] = i; }
+        }
+        wave_lds_sync();
+        if (DPT % 4 == 0 && (L & 3) == 0) {
+#pragma unroll
+            for (int r = 0; r < DPT; r += 4) {
+                const int p = t * DPT + r;
+                if (p < L) {
+                    const float4 sv4 = *reinterpret_cast<const float4 *>(sv + p);
+                    const int4 si4 = *reinterpret_cast<const int4 *>(si_ + p);
+                    *reinterpret_cast<float4 *>(vrow + p) = float4{p < n ? sv4.x : 0.0f, p + 1 < n ? sv4.y : 0.0f, p + 2 < n ? sv4.z : 0.0f, p + 3 < n ? sv4.w : 0.0f};
+                    *reinterpret_cast<i64x2_t *>(irow + p) = i64x2_t{p < n ? (long)si4.x : (long)p, p + 1 < n ? (long)si4.y : (long)(p + 1)};
+                    *reinterpret_cast<i64x2_t *>(irow + p + 2) = i64x2_t{p + 2 < n ? (long)si4.z : (long)(p + 2), p + 3 < n ? (long)si4.w : (long)(p + 3)};
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < DPT; ++r) {
+                const int p = t * DPT + r;
+                if (p < L) {
+                    vrow[p] = p < n ? sv[p] : 0.0f;
+                    irow[p] = p < n ? (int64_t)si_[p] : (int64_t)p;
+                }
+            }
+        }
+    } else {
     float own[DPT];
     int rk[DPT];
 #pragma unroll
@@ -36,17 +98,15 @@ sort_desc_kernel(const float *__restrict__ preds, const int32_t *__restrict__ le
         own[m] = i < n ? preds[(size_t)q * L + i] : -INFINITY;
         if (i < Lp) keys[i] = own[m];
     }
-    if constexpr (G == kWave) wave_lds_sync(); else __syncthreads();               // one wavefront per query: no workgroup barrier (r5)
-    if constexpr (G == kWave) count_ranks_wave<DPT>(keys, sv, n, Lp, t, own, rk);   // leaves sv = keys in descending order
-    else count_ranks_fast<G, DPT>(keys, si_, n, t, own, rk);      // si_ doubles as the permutation-check scratch before it is filled
-    if constexpr (G == kWave) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-    else __syncthreads();
+    __syncthreads();
+    count_ranks_fast<G, DPT>(keys, si_, n, t, own, rk);      // si_ doubles as the permutation-check scratch before it is filled
+    __syncthreads();
 #pragma unroll
     for (int m = 0; m < DPT; ++m) {
         const int i = t + m * G;
         if (i < n) { sv[rk[m]] = own[m]; si_[rk[m]] = i; }
     }
-    if constexpr (G == kWave) wave_lds_sync(); else __syncthreads();
+    __syncthreads();
     if (valid) {
 #pragma unroll
         for (int m = 0; m < DPT; ++m) {
@@ -56,6 +116,7 @@ sort_desc_kernel(const float *__restrict__ preds, const int32_t *__restrict__ le
                 idx[(size_t)q * L + r] = r < n ? (int64_t)si_[r] : (int64_t)r;
             }
         }
+    }
     }
 }
 
@@ -98,11 +159,51 @@ metrics_kernel(const float *__restrict__ preds, const float *__restrict__ labels
     constexpr int QPB = kBlock / G;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, grp = tid / G, t = tid % G;
-    const int q = blockIdx.x * QPB + grp;
+    const int q = G == kWave ? __builtin_amdgcn_readfirstlane(blockIdx.x * QPB + grp) : blockIdx.x * QPB + grp;   // one wavefront per query: scalar
     const bool valid = q < B;
     const int n = valid ? query_len(lens, q, L) : 0;
     float *S_id = smem + (size_t)grp * 3 * Lp, *Y_id = S_id + Lp, *Y_sys = Y_id + Lp;
 
+    if constexpr (G == kWave) {
+        // r5, one wavefront per query (lists of up to 1024 documents): the documents sit in the BLOCKED layout (lane t owns documents
+        // t*DPT ..: 16-byte loads, no LDS staging ahead of the sorts), the waves of a block are independent (no workgroup barrier)
+        if (!valid) return;
+        float si[DPT], li[DPT], v[DPT];
+        int rk[DPT];
+        load_blocked<DPT>(preds + (size_t)q * L, n, L, t, -INFINITY, si);
+        load_blocked<DPT>(labels + (size_t)q * L, n, L, t, 0.0f, li);
+        // NOTE: the reference sorts the predictions in ORIGINAL order (ranker.py:50) — ties are broken by original index —
+        // and sorts the labels separately for the ideal ranking (ranker.py:53-56).
+        bool packed = false;
+        if constexpr (DPT == 2 || DPT == 4) {
+            // 65 .. 256 documents: packed (score, index) keys; the labels by predicted rank are gathered through the sorted keys' index bits
+            int id[DPT];
+            lds_store_blocked<DPT>(Y_id, t, li);                        // labels by document (Y_id is staged below)
+            packed = sort_scores_packed<DPT>(S_id, n, t, si, v, id);
+            if (packed) {
+                float ls[DPT];
+#pragma unroll
+                for (int r = 0; r < DPT; ++r) ls[r] = Y_id[id[r]];      // torch.gather(labels, idx), ranker.py:52 (positions >= n: never walked)
+                lds_store_blocked<DPT>(Y_sys, t, ls);
+            }
+            wave_lds_sync();
+        }
+        if (!packed) {
+            rank_blocked_wave<DPT>(S_id, Y_sys, n, t, si, rk, v);      // bitonic sort + binary search (Y_sys: scratch of the exact recount)
+#pragma unroll
+            for (int r = 0; r < DPT; ++r) { if (t * DPT + r < n) Y_sys[rk[r]] = li[r]; }
+        }
+        if (!presort) {
+            // only the ideal LABELS are walked below, and equal labels are interchangeable: a value-only sort, no tie handling
+#pragma unroll
+            for (int r = 0; r < DPT; ++r) v[r] = t * DPT + r < n ? li[r] : -INFINITY;
+            wave_sort_desc<DPT>(v, t);
+#pragma unroll
+            for (int r = 0; r < DPT; ++r) li[r] = t * DPT + r < n ? v[r] : 0.0f;
+        }
+        lds_store_blocked<DPT>(Y_id, t, li);
+        wave_lds_sync();
+    } else {
     float si[DPT], li[DPT];
     int ipos[DPT];
 #pragma unroll
@@ -112,48 +213,24 @@ metrics_kernel(const float *__restrict__ preds, const float *__restrict__ labels
         si[m] = in ? preds[(size_t)q * L + i] : -INFINITY;
         li[m] = in ? labels[(size_t)q * L + i] : 0.0f;
     }
-    // NOTE: the reference sorts the predictions in ORIGINAL order (ranker.py:50) — ties are broken by original index —
-    // and sorts the labels separately for the ideal ranking (ranker.py:53-56).  So rank by score first, on the raw tile.
+    // rank by score first, on the raw tile (see the note above)
 #pragma unroll
     for (int m = 0; m < DPT; ++m) {
         const int i = t + m * G;
         if (i < Lp) S_id[i] = si[m];
     }
-    if constexpr (G == kWave) wave_lds_sync(); else __syncthreads();       // one wavefront per query: its LDS region is its own
+    __syncthreads();
     int rk[DPT];
     // ranks by packed fma-clamp counting (one VALU slot per compare; ties / overflow fall back to the exact compares) — the O(L^2) count
     // is what the kernel's time is made of: 0.54 -> 0.2 ms for 65 536 x 256.  Y_id (not staged yet) is the permutation-check scratch.
-    if constexpr (G == kWave) count_ranks_wave<DPT>(S_id, Y_id, n, Lp, t, si, rk);  // bitonic sort + binary search (Y_id: scratch)
-    else count_ranks_fast<G, DPT>(S_id, reinterpret_cast<int *>(Y_id), n, t, si, rk);
+    count_ranks_fast<G, DPT>(S_id, reinterpret_cast<int *>(Y_id), n, t, si, rk);
 #pragma unroll
     for (int m = 0; m < DPT; ++m) {
         const int i = t + m * G;
         if (i < n) Y_sys[rk[m]] = li[m];                    // torch.gather(labels, idx), ranker.py:52
     }
-    if constexpr (G == kWave) wave_lds_sync(); else __syncthreads();
-    if constexpr (G == kWave) {
-        // only the ideal LABELS are walked below, and equal labels are interchangeable: a value-only sort, no tie handling
-        (void)ipos;
-#pragma unroll
-        for (int m = 0; m < DPT; ++m) {
-            const int i = t + m * G;
-            if (i < Lp) Y_id[i] = i < n ? li[m] : (presort ? 0.0f : -INFINITY);
-        }
-        if (!presort) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            float v[DPT];
-#pragma unroll
-            for (int r = 0; r < DPT; ++r) v[r] = t * DPT + r < Lp ? Y_id[t * DPT + r] : -INFINITY;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            wave_sort_desc<DPT>(v, t);
-#pragma unroll
-            for (int r = 0; r < DPT; ++r) { if (t * DPT + r < Lp) Y_id[t * DPT + r] = t * DPT + r < n ? v[r] : 0.0f; }
-        }
-        wave_lds_sync();
-    } else {
-        stage_ideal_order<G, DPT>(S_id, Y_id, n, Lp, t, presort != 0, si, li, ipos);   // ends with a barrier
+    __syncthreads();
+    stage_ideal_order<G, DPT>(S_id, Y_id, n, Lp, t, presort != 0, si, li, ipos);   // ends with a barrier
     }
 
     // ---- wave 0 of the group walks the two rankings
@@ -167,9 +244,15 @@ metrics_kernel(const float *__restrict__ preds, const float *__restrict__ labels
         float *r_nerr = w_nerr ? o_nerr + (size_t)q * ck.nk : nullptr;
         float *r_ap = w_ap ? o_ap + (size_t)q * ck.nk : nullptr;
         float *r_p = w_p ? o_p + (size_t)q * ck.nk : nullptr;
-        int used = 0;
-        for (int c = 0; c < ck.nk; ++c) used += (ck.k[c] >= 1 && ck.k[c] <= n) ? 1 : 0;
-        if (lane < ck.nk && lane >= used) {                  // zero padding goes last (adhoc_metric.py:255-258)
+        // lane s of the wave holds the cut-off of output slot s (the cut-offs that fit the list, in order; zero padding goes last,
+        // adhoc_metric.py:255-258): the walk's results are gathered from the lanes at rank k-1 and stored as ONE row per metric
+        int used = 0, kslot = 0;
+        for (int c = 0; c < ck.nk; ++c) {
+            const bool use = ck.k[c] >= 1 && ck.k[c] <= n;
+            if (use && lane == used) kslot = ck.k[c];
+            used += use ? 1 : 0;
+        }
+        if (lane < ck.nk && lane >= used) {
             if (r_ndcg) r_ndcg[lane] = 0.0f;
             if (r_nerr) r_nerr[lane] = 0.0f;
             if (r_ap) r_ap[lane] = 0.0f;
@@ -212,18 +295,14 @@ metrics_kernel(const float *__restrict__ preds, const float *__restrict__ labels
                 serr = wave_incl_sum(in ? rr * ssat * (s_excl * c_sun) : 0.0f, lane) + c_serr;
                 ierr = wave_incl_sum(in ? rr * isat * (i_excl * c_iun) : 0.0f, lane) + c_ierr;
             }
-            if (in) {
-                int slot = 0;
-                for (int c = 0; c < ck.nk; ++c) {
-                    const bool use = ck.k[c] >= 1 && ck.k[c] <= n;
-                    if (use && ck.k[c] == r + 1) {
-                        if (r_ndcg) r_ndcg[slot] = sdcg / idcg;
-                        if (r_nerr) r_nerr[slot] = serr / ierr;
-                        if (r_ap) r_ap[slot] = cumprec / cumideal;
-                        if (r_p) r_p[slot] = pr;
-                    }
-                    slot += use ? 1 : 0;
-                }
+            {
+                const int src = kslot - 1 - ch * 64;                       // lane of this chunk that holds rank kslot - 1
+                const bool mine = lane < used && src >= 0 && src < 64;
+                const int sel = (src & 63) << 2;
+                if (r_ndcg) { const float o = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sel, __builtin_bit_cast(int, sdcg / idcg))); if (mine) r_ndcg[lane] = o; }
+                if (r_nerr) { const float o = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sel, __builtin_bit_cast(int, serr / ierr))); if (mine) r_nerr[lane] = o; }
+                if (r_ap) { const float o = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sel, __builtin_bit_cast(int, cumprec / cumideal))); if (mine) r_ap[lane] = o; }
+                if (r_p) { const float o = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sel, __builtin_bit_cast(int, pr))); if (mine) r_p[lane] = o; }
             }
             c_sdcg = __shfl(sdcg, 63, 64); c_idcg = __shfl(idcg, 63, 64); c_rel = __shfl(cumrel, 63, 64);
             c_prec = __shfl(cumprec, 63, 64); c_ideal = __shfl(cumideal, 63, 64);

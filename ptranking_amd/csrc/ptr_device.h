@@ -207,7 +207,8 @@ __device__ __forceinline__ float gain_of(float label) { return exp2f(label) - 1.
 // Descending rank of each owned key among keys[0..n): rank = #{j : k_j > k_i  or (k_j == k_i and j < i)}, i.e. the
 // position torch.sort(descending=True) gives on tie-free input, with ties broken by original index.
 // keys[] is in LDS, padded with -inf up to a multiple of 4 (float4 broadcast reads).  own[m] / index t + m*G.
-template <int G, int DPT>
+// BLK: own[m] is document t*DPT + m (the blocked layout of the one-wavefront paths) instead of t + m*G.
+template <int G, int DPT, bool BLK = false>
 __device__ __forceinline__ void count_ranks(const float *keys, int n, int t, const float (&own)[DPT], int (&rk)[DPT]) {
     // Fast path (tie-free lists, the common case): rank = #{j : k_j > k_i} — one compare + one add-with-carry per pair.
     // #{j : k_j >= k_i} is counted alongside; a lane whose two counts differ by more than its own element has a tie, and
@@ -228,11 +229,11 @@ __device__ __forceinline__ void count_ranks(const float *keys, int n, int t, con
     }
     bool tie = false;
 #pragma unroll
-    for (int m = 0; m < DPT; ++m) tie |= (t + m * G < n) && (ge[m] - rk[m] != 1);
+    for (int m = 0; m < DPT; ++m) tie |= ((BLK ? t * DPT + m : t + m * G) < n) && (ge[m] - rk[m] != 1);
     if (__any(tie)) {
 #pragma unroll
         for (int m = 0; m < DPT; ++m) {
-            const int i = t + m * G;
+            const int i = BLK ? t * DPT + m : t + m * G;
             const float s = own[m];
             if (i < n && ge[m] - rk[m] != 1) {
                 int extra = 0;
@@ -337,16 +338,19 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 // the result (v_readlane of lane 63).
 #define PTR_DPP_STEP(v, ident, ctrl, rows) __builtin_amdgcn_update_dpp((ident), (v), (ctrl), (rows), 0xF, false)
 __device__ __forceinline__ float wave_max_dpp(float x) {
-    const int ninf = __builtin_bit_cast(int, -INFINITY);
-    int v = __builtin_bit_cast(int, x);
-    auto mx = [](int a, int b) { return __builtin_bit_cast(int, fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b))); };
-    v = mx(v, PTR_DPP_STEP(v, ninf, 0xB1, 0xF));
-    v = mx(v, PTR_DPP_STEP(v, ninf, 0x4E, 0xF));
-    v = mx(v, PTR_DPP_STEP(v, ninf, 0x141, 0xF));
-    v = mx(v, PTR_DPP_STEP(v, ninf, 0x140, 0xF));
-    v = mx(v, PTR_DPP_STEP(v, ninf, 0x142, 0xA));
-    v = mx(v, PTR_DPP_STEP(v, ninf, 0x143, 0xC));
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 63));
+    // one v_max_f32 with a DPP source per step (r5: the builtin form cost five instructions a step — the identity for the lanes without a
+    // source, the move and two canonicalising maxima); lanes a step does not write (row_mask, no source lane) keep their value.  The
+    // s_nop covers the VALU-write -> DPP-read hazard the assembler does not see inside an asm block.
+    float v = x;
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ int wave_min_i32_dpp(int v) {
     const int big = 0x7fffffff;
@@ -387,51 +391,66 @@ __device__ __forceinline__ float dpp_rol1(float v) {
 // ---- one wavefront sorts 64*E keys held E per lane (bitonic network in registers)
 // Value of lane (lane ^ X): DPP inside the 16-lane rows where a control exists (quad_perm, row_half_mirror, row_mirror, row_ror:8),
 // the LDS crossbar otherwise (ds_swizzle bit mode inside 32 lanes, ds_bpermute across the halves).
-template <int X> __device__ __forceinline__ float lane_xor(float v, int lane) {
-    const int s = __builtin_bit_cast(int, v);
-    int r;
-    if constexpr (X == 1) r = __builtin_amdgcn_update_dpp(s, s, 0xB1, 0xF, 0xF, false);            // quad_perm:[1,0,3,2]
-    else if constexpr (X == 2) r = __builtin_amdgcn_update_dpp(s, s, 0x4E, 0xF, 0xF, false);       // quad_perm:[2,3,0,1]
-    else if constexpr (X == 3) r = __builtin_amdgcn_update_dpp(s, s, 0x1B, 0xF, 0xF, false);       // quad_perm:[3,2,1,0]
-    else if constexpr (X == 7) r = __builtin_amdgcn_update_dpp(s, s, 0x141, 0xF, 0xF, false);      // row_half_mirror
-    else if constexpr (X == 15) r = __builtin_amdgcn_update_dpp(s, s, 0x140, 0xF, 0xF, false);     // row_mirror
-    else if constexpr (X == 8) r = __builtin_amdgcn_update_dpp(s, s, 0x128, 0xF, 0xF, false);      // row_ror:8
-    else if constexpr (X == 4 || X == 16 || X == 31) r = __builtin_amdgcn_ds_swizzle(s, (X << 10) | 0x1F);   // bit mode: and 0x1F, xor X
-    else r = __builtin_amdgcn_ds_bpermute((lane ^ X) << 2, s);
-    return __builtin_bit_cast(float, r);
+template <int X> __device__ __forceinline__ int lane_xor_bits(int s, int lane) {
+    if constexpr (X == 1) return __builtin_amdgcn_mov_dpp(s, 0xB1, 0xF, 0xF, true);            // quad_perm:[1,0,3,2]
+    else if constexpr (X == 2) return __builtin_amdgcn_mov_dpp(s, 0x4E, 0xF, 0xF, true);       // quad_perm:[2,3,0,1]
+    else if constexpr (X == 3) return __builtin_amdgcn_mov_dpp(s, 0x1B, 0xF, 0xF, true);       // quad_perm:[3,2,1,0]
+    else if constexpr (X == 7) return __builtin_amdgcn_mov_dpp(s, 0x141, 0xF, 0xF, true);      // row_half_mirror
+    else if constexpr (X == 15) return __builtin_amdgcn_mov_dpp(s, 0x140, 0xF, 0xF, true);     // row_mirror
+    else if constexpr (X == 8) return __builtin_amdgcn_mov_dpp(s, 0x128, 0xF, 0xF, true);      // row_ror:8
+    else if constexpr (X == 4 || X == 16 || X == 31) return __builtin_amdgcn_ds_swizzle(s, (X << 10) | 0x1F);   // bit mode: and 0x1F, xor X
+    else return __builtin_amdgcn_ds_bpermute((lane ^ X) << 2, s);
+}
+// (every source lane of these controls is inside the row: v_mov_b32_dpp without an `old` operand — the tied form cost a register copy
+// per exchange, r5)
+template <int X, class T> __device__ __forceinline__ T lane_xor(T v, int lane) {
+    return __builtin_bit_cast(T, lane_xor_bits<X>(__builtin_bit_cast(int, v), lane));
 }
 constexpr int top_bit(int x) { int b = 1; while (b * 2 <= x) b *= 2; return b; }
+// The two key types of the network: float (v_med3_f32 against +-inf is max / min without the canonicalising extra instruction
+// fmaxf / fminf bring, and returns one of its inputs bit for bit; NaNs are screened before the sort) and uint32_t (packed integer keys).
+__device__ __forceinline__ float sort_hi(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, INFINITY); }
+__device__ __forceinline__ float sort_lo(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, -INFINITY); }
+__device__ __forceinline__ uint32_t sort_hi(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t sort_lo(uint32_t a, uint32_t b) { return a < b ? a : b; }
+// bound: the key type's maximum where the lane keeps the larger key, its minimum where it keeps the smaller one
+__device__ __forceinline__ float sort_bound(float, bool keep_min) { return __builtin_bit_cast(float, 0x7F800000 | (keep_min ? (int)0x80000000 : 0)); }
+__device__ __forceinline__ uint32_t sort_bound(uint32_t, bool keep_min) { return keep_min ? 0u : 0xFFFFFFFFu; }
+__device__ __forceinline__ float sort_med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+__device__ __forceinline__ uint32_t sort_med3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 // Compare-exchange of positions p and p ^ X inside the lane's registers (X < E); the lower position keeps the larger key.
-// v_med3_f32 against +-inf is max / min without the canonicalising extra instruction fmaxf / fminf bring, and returns one of its inputs
-// bit for bit (NaNs are screened before the sort).
-template <int E, int X> __device__ __forceinline__ void bitonic_local(float (&v)[E]) {
+template <int E, int X, class T> __device__ __forceinline__ void bitonic_local(T (&v)[E]) {
 #pragma unroll
     for (int r = 0; r < E; ++r) {
         if ((r & top_bit(X)) == 0) {
-            const float a = v[r], b = v[r ^ X];
-            v[r] = __builtin_amdgcn_fmed3f(a, b, INFINITY);
-            v[r ^ X] = __builtin_amdgcn_fmed3f(a, b, -INFINITY);
+            const T a = v[r], b = v[r ^ X];
+            v[r] = sort_hi(a, b);
+            v[r ^ X] = sort_lo(a, b);
         }
     }
 }
 // Compare-exchange with lane (lane ^ LX); FLIP: against the partner's register E-1-r (the mirror step of a merge), else register r.
-// The lane whose top differing bit is clear keeps the maximum: one v_med3_f32 against a per-lane +-inf.
-template <int E, int LX, bool FLIP> __device__ __forceinline__ void bitonic_cross(float (&v)[E], int lane) {
-    const float bound = __builtin_bit_cast(float, 0x7F800000 | ((lane & top_bit(LX)) ? (int)0x80000000 : 0));
-    float p[E];
+// The lane whose top differing bit is clear keeps the maximum: one med3 against a per-lane bound.
+template <int E, int LX, bool FLIP, class T> __device__ __forceinline__ void bitonic_cross(T (&v)[E], int lane) {
+    const T bound = sort_bound(T(), (lane & top_bit(LX)) != 0);
+    T p[E];
 #pragma unroll
     for (int r = 0; r < E; ++r) p[r] = lane_xor<LX>(v[FLIP ? E - 1 - r : r], lane);
 #pragma unroll
-    for (int r = 0; r < E; ++r) v[r] = __builtin_amdgcn_fmed3f(v[r], p[r], bound);
+    for (int r = 0; r < E; ++r) v[r] = sort_med3(v[r], p[r], bound);
 }
-template <int E, int J> __device__ __forceinline__ void bitonic_halves(float (&v)[E], int lane) {   // half-cleaners J, J/2, ..., 1
+template <int E, int J, class T> __device__ __forceinline__ void bitonic_halves(T (&v)[E], int lane) {   // half-cleaners J, J/2, ..., 1
     if constexpr (J >= 1) {
         if constexpr (J < E) bitonic_local<E, J>(v);
         else bitonic_cross<E, J / E, false>(v, lane);
         bitonic_halves<E, J / 2>(v, lane);
     }
 }
-template <int E, int K> __device__ __forceinline__ void bitonic_phases(float (&v)[E], int lane) {   // merges of size K, 2K, ..., 64E
+template <int E, int K, class T> __device__ __forceinline__ void bitonic_phases(T (&v)[E], int lane) {   // merges of size K, 2K, ..., 64E
     if constexpr (K <= 64 * E) {
         if constexpr (K <= E) bitonic_local<E, K - 1>(v);                   // mirror step p <-> p ^ (K-1): every direction is "descending"
         else bitonic_cross<E, K / E - 1, true>(v, lane);
@@ -439,9 +458,10 @@ template <int E, int K> __device__ __forceinline__ void bitonic_phases(float (&v
         bitonic_phases<E, K * 2>(v, lane);
     }
 }
-// Sorts the 64*E keys v[r] = key at position lane*E + r into descending order (position 0 = maximum).  No NaNs.  36 compare-exchange
-// stages for 256 keys = ~230 VALU / crossbar instructions per wavefront, against 65 536 / 64 packed compares of the counting form.
-template <int E> __device__ __forceinline__ void wave_sort_desc(float (&v)[E], int lane) { bitonic_phases<E, 2>(v, lane); }
+// Sorts the 64*E keys v[r] = key at position lane*E + r into descending order (position 0 = maximum).  float keys: no NaNs.  36
+// compare-exchange stages for 256 keys = ~230 VALU / crossbar instructions per wavefront, against 65 536 / 64 packed compares of the
+// counting form.
+template <int E, class T> __device__ __forceinline__ void wave_sort_desc(T (&v)[E], int lane) { bitonic_phases<E, 2>(v, lane); }
 
 // count_ranks_fast() for a group of ONE wavefront: sort the keys, then each document finds its rank in the sorted row by binary search
 // (rank = #{k_j > k_i}); ties among the n valid keys (adjacent equal entries) and NaNs send the wave to the exact count_ranks().
@@ -475,6 +495,137 @@ __device__ __forceinline__ void count_ranks_wave(const float *keys, float *sorte
     for (int step = N / 2; step >= 1; step >>= 1) {
 #pragma unroll
         for (int m = 0; m < DPT; ++m) rk[m] += sorted[rk[m] + step - 1] > own[m] ? step : 0;
+    }
+}
+
+// r5: count_ranks_wave() for documents held in the BLOCKED layout — lane t owns documents t*DPT .. t*DPT + DPT-1 (16-byte global loads,
+// no LDS staging of the keys before the sort): own[r] = key of document t*DPT + r (-inf beyond n).  Leaves v[] = the keys in descending
+// order (v[r] = position t*DPT + r; garbage if a key is NaN), sorted[] (LDS, 64*DPT floats) = the same row, rk[r] = rank of document
+// t*DPT + r.  Ties / NaNs: the keys go to `scratch` (LDS, 64*DPT floats) and the wave recounts exactly.  Wave-level barriers only; both
+// LDS rows may be overwritten by the caller on return.
+template <int DPT> __device__ __forceinline__ void lds_store_blocked(float *row, int t, const float (&v)[DPT]) {
+    if constexpr (DPT % 4 == 0) {
+#pragma unroll
+        for (int r = 0; r < DPT; r += 4) *reinterpret_cast<float4 *>(row + t * DPT + r) = float4{v[r], v[r + 1], v[r + 2], v[r + 3]};
+    } else if constexpr (DPT == 2) {
+        *reinterpret_cast<float2 *>(row + t * 2) = float2{v[0], v[1]};
+    } else {
+#pragma unroll
+        for (int r = 0; r < DPT; ++r) row[t * DPT + r] = v[r];
+    }
+}
+template <int DPT>
+__device__ __forceinline__ void rank_blocked_wave(float *sorted, float *scratch, int n, int t, const float (&own)[DPT], int (&rk)[DPT],
+                                                  float (&v)[DPT]) {
+    constexpr int N = kWave * DPT;
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < DPT; ++r) { v[r] = own[r]; bad |= v[r] != v[r]; }
+    wave_sort_desc<DPT>(v, t);
+    const float nxt = __shfl_down(v[0], 1, 64);                              // first key of the next lane (lane 63: unused, its pairs end past n)
+#pragma unroll
+    for (int r = 0; r < DPT; ++r) bad |= t * DPT + r + 1 < n && v[r] == (r + 1 < DPT ? v[(r + 1) % DPT] : nxt);
+    lds_store_blocked<DPT>(sorted, t, v);
+    if (__any(bad)) {
+        lds_store_blocked<DPT>(scratch, t, own);
+        wave_lds_sync();
+        count_ranks<kWave, DPT, true>(scratch, n, t, own, rk);
+        wave_lds_sync();
+        return;
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int m = 0; m < DPT; ++m) rk[m] = 0;
+#pragma unroll
+    for (int step = N / 2; step >= 1; step >>= 1) {
+#pragma unroll
+        for (int m = 0; m < DPT; ++m) rk[m] += sorted[rk[m] + step - 1] > own[m] ? step : 0;
+    }
+    wave_lds_sync();
+}
+__device__ __forceinline__ float dpp_wave_shl1(float v) {      // lane t <- lane t + 1, lane 63 <- 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_wave_shr1(float v) {      // lane t <- lane t - 1, lane 0 <- 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138 /* wave_shr:1 */, 0xF, 0xF, true));
+}
+__device__ __forceinline__ int dpp_wave_shl1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xF, 0xF, true); }
+__device__ __forceinline__ int dpp_wave_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, true); }
+
+// r5: the (score descending, index ascending) order of 128 / 256 documents from ONE register sort, without a rank search.
+// Key = order-preserving integer image of the score with its low IB bits replaced by (N - 1 - index) (N = 64 DPT, IB = log2 N), sorted
+// descending by the integer network; position p's document is read off the key, its true score gathered from the row staged in LDS.
+// The truncated order is wrong only between documents whose scores agree in the top 32 - IB bits (about one pair in three lists of 256
+// N(0,1) scores): one odd-even transposition round on the true (score, index) pairs repairs isolated pairs, every adjacent pair is then
+// CHECKED — a sorted row is exactly one whose adjacent pairs are ordered — and the wave returns false (caller: the float sort + search /
+// exact count) if any is not, or if a score is NaN.  -0.0 keys as +0.0 (torch.sort compares them equal; the index decides).
+// own[r] = score of document t*DPT + r (-inf beyond n); raw: LDS, N floats (left holding the scores by document).  On success sc[r] / id[r]
+// = score / document of position t*DPT + r (positions >= n: -inf / N-1).
+template <int DPT>
+__device__ __forceinline__ bool sort_scores_packed(float *raw, int n, int t, const float (&own)[DPT], float (&sc)[DPT], int (&id)[DPT]) {
+    static_assert(DPT == 2 || DPT == 4, "lists of 65 .. 256 documents");
+    constexpr int N = kWave * DPT;
+    uint32_t key[DPT];
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < DPT; ++r) {
+        const int i = t * DPT + r;
+        const float x = own[r] + 0.0f;
+        bad |= x != x;
+        const int b = __builtin_bit_cast(int, x);
+        const uint32_t o = (uint32_t)b ^ ((uint32_t)(b >> 31) | 0x80000000u);
+        key[r] = i < n ? (o & ~(uint32_t)(N - 1)) | (uint32_t)(N - 1 - i) : 0u;
+    }
+    lds_store_blocked<DPT>(raw, t, own);
+    if (__any(bad)) return false;
+    wave_sort_desc<DPT>(key, t);
+    wave_lds_sync();
+#pragma unroll
+    for (int r = 0; r < DPT; ++r) {
+        id[r] = N - 1 - (int)(key[r] & (uint32_t)(N - 1));
+        sc[r] = raw[id[r]];
+    }
+    auto wrong = [](float sa, int ia, float sb, int ib) { return sa < sb || (sa == sb && ia > ib); };
+    auto fix = [&](int a, int b) {
+        const bool w = wrong(sc[a], id[a], sc[b], id[b]);
+        const float s0 = w ? sc[b] : sc[a], s1 = w ? sc[a] : sc[b];
+        const int i0 = w ? id[b] : id[a], i1 = w ? id[a] : id[b];
+        sc[a] = s0; sc[b] = s1; id[a] = i0; id[b] = i1;
+    };
+#pragma unroll
+    for (int r = 0; r + 1 < DPT; r += 2) fix(r, r + 1);                      // even pairs (p, p+1): inside the lane
+#pragma unroll
+    for (int r = 1; r + 1 < DPT; r += 2) fix(r, r + 1);                      // odd pairs inside the lane
+    {                                                                        // the odd pair across the lane boundary
+        const float ns = dpp_wave_shl1(sc[0]), ps = dpp_wave_shr1(sc[DPT - 1]);
+        const int ni = dpp_wave_shl1(id[0]), pi = dpp_wave_shr1(id[DPT - 1]);
+        const bool w_hi = t < 63 && wrong(sc[DPT - 1], id[DPT - 1], ns, ni), w_lo = t > 0 && wrong(ps, pi, sc[0], id[0]);
+        if (w_hi) { sc[DPT - 1] = ns; id[DPT - 1] = ni; }
+        if (w_lo) { sc[0] = ps; id[0] = pi; }
+    }
+    bool still = false;
+#pragma unroll
+    for (int r = 0; r + 1 < DPT; ++r) still |= wrong(sc[r], id[r], sc[r + 1], id[r + 1]);
+    const float vs = dpp_wave_shl1(sc[0]);                                   // (outside the condition: a DPP read of a lane that a branch has
+    const int vi = dpp_wave_shl1(id[0]);                                     //  switched off returns the bound value, not the lane's register)
+    still |= t < 63 && wrong(sc[DPT - 1], id[DPT - 1], vs, vi);
+    return !__any(still);
+}
+
+// 16-byte global loads of a row into the blocked layout (row base 16-byte aligned: L % 4 == 0), scalar loads otherwise; `pad` beyond n
+template <int DPT>
+__device__ __forceinline__ void load_blocked(const float *__restrict__ row, int n, int L, int t, float pad, float (&x)[DPT]) {
+    if (DPT % 4 == 0 && (L & 3) == 0) {
+#pragma unroll
+        for (int r = 0; r < DPT; r += 4) {
+            const int i = t * DPT + r;
+            float4 u = float4{pad, pad, pad, pad};
+            if (i < n) u = *reinterpret_cast<const float4 *>(row + i);
+            x[r] = u.x; x[r + 1] = i + 1 < n ? u.y : pad; x[r + 2] = i + 2 < n ? u.z : pad; x[r + 3] = i + 3 < n ? u.w : pad;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < DPT; ++r) x[r] = t * DPT + r < n ? row[t * DPT + r] : pad;
     }
 }
 
