@@ -8,6 +8,7 @@
 //   * the mask is `label_i > label_j` AND both predicted ranks < k (a full-matrix mask: every unordered pair with
 //     different grades contributes exactly one term, seen from its winner);
 //   * clamp(min=1e-8) before and after the power, log2 (not ln), score differences clamped to +-1e8, NaN -> 0.
+#include <utility>
 #include "ptr_device.h"
 #include "ptr_dropout.h"          // f32x4
 
@@ -241,11 +242,15 @@ lambdaloss_topk_kernel(const float *__restrict__ preds, const float *__restrict_
     int kk_tab = -1, aa = 0, b = 0;                                                        // the lane's pair (aa < b < kk) for kk == kk_tab
     bool has = false;
     float delta = 0.0f, dpos = 0.0f;
+    int plo[11];                                                                           // record lane r: byte address (ds_bpermute) of the lane
+#pragma unroll                                                                             // that holds pair (r, o); lane 63 (no pair: zero) otherwise
+    for (int o = 0; o < 11; ++o) plo[o] = 63 << 2;
     for (int q = wave0; q < B; q += nwaves) {                                              // waves are independent
         const int n = query_len(lens, q, L);
         const f32x4 *ps = reinterpret_cast<const f32x4 *>(preds + (size_t)q * L), *py = reinterpret_cast<const f32x4 *>(labels + (size_t)q * L);
         float s[E], y[E];
         float part = 0.0f;
+        const bool full = n == 256 * V;
 #pragma unroll
         for (int m = 0; m < V; ++m) {
             const int c = lane + 64 * m;
@@ -253,7 +258,7 @@ lambdaloss_topk_kernel(const float *__restrict__ preds, const float *__restrict_
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int i = 4 * c + e;
-                const bool in = i < n;
+                const bool in = full || i < n;                                             // full lists (n == L == 256 V): no masks
                 s[4 * m + e] = in ? a4[e] : -INFINITY;
                 y[4 * m + e] = in ? b4[e] : 0.0f;
                 part += in ? (__builtin_amdgcn_exp2f(b4[e]) - 1.0f) * disc[4 * m + e] : 0.0f;   // IDCG of the (presorted = ideal) label order,
@@ -275,41 +280,67 @@ lambdaloss_topk_kernel(const float *__restrict__ preds, const float *__restrict_
             const float id0 = __shfl(rinv, dist > 0 ? dist - 1 : 0, 64), id1 = __shfl(rinv, dist, 64);
             delta = fabsf(id0 - id1);                                                      // :44
             dpos = fabsf(ia - ib);                                                         // :57
+#pragma unroll
+            for (int o = 0; o < 11; ++o) {                                                 // pair (a, b) sits in lane a (kk - 1) - a (a - 1) / 2 + b - a - 1
+                const int a_ = lane < o ? lane : o, b_ = lane < o ? o : lane;
+                const int pl = a_ * (kk - 1) - ((a_ * (a_ - 1)) >> 1) + (b_ - a_ - 1);
+                plo[o] = (o != lane && lane < kk && o < kk ? pl : 63) << 2;
+            }
         }
         // ---- the kk best documents, in rank order: record r lives in lane r
         float rs = 0.0f, ry = 0.0f;
         int ri = -1;
         if constexpr (V == 1) {
-            float hs[4], hy[4];
+            float hs[4];
             int hi[4];
+            bool nan = false;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int i = 4 * lane + e;
-                const bool live = i < n && s[e] == s[e];                                   // NaN scores never win (the reference sorts them last)
-                hs[e] = live ? s[e] : -INFINITY; hy[e] = y[e]; hi[e] = live ? i : kDead;
+            for (int e = 0; e < 4; ++e) nan |= s[e] != s[e];
+            if (full && !__any(nan)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { hs[e] = s[e]; hi[e] = 4 * lane + e; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * lane + e;
+                    const bool live = i < n && s[e] == s[e];                               // NaN scores never win (the reference sorts them last)
+                    hs[e] = live ? s[e] : -INFINITY; hi[e] = live ? i : kDead;
+                }
             }
             auto cx = [&](int u, int w) {                                                  // position u keeps the better (score desc, index asc)
                 const bool sw = hs[w] > hs[u] || (hs[w] == hs[u] && hi[w] < hi[u]);
-                const float s0 = sw ? hs[w] : hs[u], s1 = sw ? hs[u] : hs[w], y0 = sw ? hy[w] : hy[u], y1 = sw ? hy[u] : hy[w];
+                const float s0 = sw ? hs[w] : hs[u], s1 = sw ? hs[u] : hs[w];
                 const int i0 = sw ? hi[w] : hi[u], i1 = sw ? hi[u] : hi[w];
-                hs[u] = s0; hs[w] = s1; hy[u] = y0; hy[w] = y1; hi[u] = i0; hi[w] = i1;
+                hs[u] = s0; hs[w] = s1; hi[u] = i0; hi[w] = i1;
             };
             cx(0, 1); cx(2, 3); cx(0, 2); cx(1, 3); cx(1, 2);
-            for (int r = 0; r < kk; ++r) {
+            int rsb = 0, ryb = 0;                                                          // records as bits: written lane by lane (v_writelane)
+            auto round = [&]<int R>() -> bool {
                 const float gmax = wave_max_dpp(hs[0]);                                    // DPP ladder: no LDS crossbar round trips in the selection
                 const uint64_t own = __builtin_amdgcn_ballot_w64(hi[0] != kDead && hs[0] == gmax);
-                if (own == 0) break;                                                       // fewer than kk rankable documents (all NaN)
+                if (own == 0) return false;                                                // fewer than kk rankable documents (all NaN)
                 const int wl = (int)__builtin_ctzll(own);                                  // the lowest lane holds the lowest index
-                const float wy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hy[0]), wl));
                 const int wi = __builtin_amdgcn_readlane(hi[0], wl);
-                if (lane == r) { rs = gmax; ry = wy; ri = wi; }
+                const int we = wi & 3;                                                     // the winner's label: register we of lane wl
+                const float ysel = we == 0 ? y[0] : (we == 1 ? y[1] : (we == 2 ? y[2] : y[3]));   // scalar conditions
+                const int wy = __builtin_amdgcn_readlane(__builtin_bit_cast(int, ysel), wl);
+                const int gb = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, gmax));
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(rsb) : "s"(gb), "n"(R));
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(ryb) : "s"(wy), "n"(R));
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(ri) : "s"(wi), "n"(R));
                 if (lane == wl) {
-                    hs[0] = hs[1]; hy[0] = hy[1]; hi[0] = hi[1];
-                    hs[1] = hs[2]; hy[1] = hy[2]; hi[1] = hi[2];
-                    hs[2] = hs[3]; hy[2] = hy[3]; hi[2] = hi[3];
+                    hs[0] = hs[1]; hi[0] = hi[1];
+                    hs[1] = hs[2]; hi[1] = hi[2];
+                    hs[2] = hs[3]; hi[2] = hi[3];
                     hs[3] = -INFINITY; hi[3] = kDead;
                 }
-            }
+                return true;
+            };
+            [&]<int... R>(std::integer_sequence<int, R...>) {
+                bool go = true;
+                ((go = go && R < kk && round.template operator()<R>()), ...);
+            }(std::make_integer_sequence<int, 11>{});
+            rs = __builtin_bit_cast(float, rsb); ry = __builtin_bit_cast(float, ryb);
         } else {
             for (int r = 0; r < kk; ++r) {
                 float best = -INFINITY, blab = 0.0f;
@@ -377,11 +408,12 @@ lambdaloss_topk_kernel(const float *__restrict__ preds, const float *__restrict_
         // ---- gradient of record r = lane: its kk - 1 pairs, gathered from the pair lanes (pair (a, b) sits in lane a (kk - 1) - a (a - 1) / 2
         //      + b - a - 1)
         float gr = 0.0f;
-        for (int o = 0; o < kk; ++o) {
-            const int a_ = lane < o ? lane : o, b_ = lane < o ? o : lane;
-            const int pl = a_ * (kk - 1) - ((a_ * (a_ - 1)) >> 1) + (b_ - a_ - 1);
-            const float gv = __shfl(g_a, pl & 63, 64);
-            if (o != lane && lane < kk) gr += lane < o ? gv : -gv;
+#pragma unroll
+        for (int o = 0; o < 11; ++o) {
+            if (o < kk) {                                                                  // uniform
+                const float gv = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(plo[o], __builtin_bit_cast(int, g_a)));
+                gr += lane < o ? gv : -gv;                                                 // lanes without this pair read lane 63's zero
+            }
         }
         // ---- gradient row: zeros + the kk records' entries
         f32x4 o4[V];
@@ -428,8 +460,8 @@ extern "C" int ptr_lambdaloss_fwd_bwd(const float *preds, const float *labels, c
     if (B > 0 && topk) {
         // small cut-off on presorted labels: wavefront arg-max selection instead of a sort, one pair per lane (lambdaloss_topk_kernel)
         auto go = [&](auto kern) -> int {
-            const int blocks = (B + 3) / 4;                        // persistent wavefronts: at most 8 blocks of 4 per CU, each walks its queries
-            hipLaunchKernelGGL(kern, dim3(blocks < 2048 ? blocks : 2048), dim3(kBlock), 0, st, preds, labels, lens, B, L, k, sigma, mu, loss_type, loss_q, grad);
+            const int blocks = persistent_grid(kern, kBlock, 0, (B + 3) / 4);   // persistent wavefronts: the resident set walks the queries
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(kBlock), 0, st, preds, labels, lens, B, L, k, sigma, mu, loss_type, loss_q, grad);
             return check_hip(hipGetLastError(), who);
         };
         if (int rc = L <= 256 ? go(lambdaloss_topk_kernel<1>) : (L <= 512 ? go(lambdaloss_topk_kernel<2>) : go(lambdaloss_topk_kernel<4>))) return rc;

@@ -41,7 +41,7 @@ sort_desc_kernel(const float *__restrict__ preds, const int32_t *__restrict__ le
             // 65 .. 256 documents: packed (score, index) keys, the permutation read off the sorted keys (no rank search)
             float sc[DPT];
             int id[DPT];
-            if (sort_scores_packed<DPT>(keys, n, t, own, sc, id)) {
+            if (sort_scores_packed<DPT, true>(keys, n, t, own, sc, id)) {
                 if (DPT == 4 && (L & 3) == 0) {
                     const int p = t * 4;
                     if (p < L) {
@@ -145,6 +145,29 @@ batch_max_kernel(const float *__restrict__ labels, const int32_t *__restrict__ l
     if (threadIdx.x == 0) atomicMax(out_key, float_to_ordered(mx));
 }
 
+// batch_max_kernel() without a length vector: a plain 16-byte-load stream over the B x L labels (r5: the scalar per-element walk reached
+// 1.8 TB/s).  total4 = B L / 4.
+__global__ void __launch_bounds__(kBlock)
+batch_max_vec_kernel(const float4 *__restrict__ labels4, size_t total4, int *__restrict__ out_key) {
+    __shared__ float red[4];
+    float mx = -INFINITY;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    for (; e + 7 * stride < total4; e += 8 * stride) {             // eight loads in flight
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = labels4[e + u * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mx = fmaxf(mx, fmaxf(fmaxf(v[u].x, v[u].y), fmaxf(v[u].z, v[u].w)));
+    }
+    for (; e < total4; e += stride) {
+        const float4 a = labels4[e];
+        mx = fmaxf(mx, fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)));
+    }
+    mx = group_max<kBlock>(mx, red, threadIdx.x);
+    if (threadIdx.x == 0) atomicMax(out_key, float_to_ordered(mx));
+}
+
 // ------------------------------------------------------------------------------------------------ metrics
 // 2^l - 1 on the transcendental pipe alone (v_exp_f32: exact for the integer grades, 1 ulp otherwise; labels are far from its denormal range)
 __device__ __forceinline__ float gain_fast(float label) { return __builtin_amdgcn_exp2f(label) - 1.0f; }
@@ -160,14 +183,15 @@ metrics_kernel(const float *__restrict__ preds, const float *__restrict__ labels
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, grp = tid / G, t = tid % G;
     const int q = G == kWave ? __builtin_amdgcn_readfirstlane(blockIdx.x * QPB + grp) : blockIdx.x * QPB + grp;   // one wavefront per query: scalar
-    const bool valid = q < B;
-    const int n = valid ? query_len(lens, q, L) : 0;
+    // (persistent wavefronts walking the queries with a grid stride were measured, r5: 88 registers instead of 52, 69 us against 66)
     float *S_id = smem + (size_t)grp * 3 * Lp, *Y_id = S_id + Lp, *Y_sys = Y_id + Lp;
+    const bool valid = q < B;
+    if (G == kWave && !valid) return;                          // the waves of a block are independent on this path
+    const int n = valid ? query_len(lens, q, L) : 0;
 
     if constexpr (G == kWave) {
         // r5, one wavefront per query (lists of up to 1024 documents): the documents sit in the BLOCKED layout (lane t owns documents
         // t*DPT ..: 16-byte loads, no LDS staging ahead of the sorts), the waves of a block are independent (no workgroup barrier)
-        if (!valid) return;
         float si[DPT], li[DPT], v[DPT];
         int rk[DPT];
         load_blocked<DPT>(preds + (size_t)q * L, n, L, t, -INFINITY, si);
@@ -179,7 +203,7 @@ metrics_kernel(const float *__restrict__ preds, const float *__restrict__ labels
             // 65 .. 256 documents: packed (score, index) keys; the labels by predicted rank are gathered through the sorted keys' index bits
             int id[DPT];
             lds_store_blocked<DPT>(Y_id, t, li);                        // labels by document (Y_id is staged below)
-            packed = sort_scores_packed<DPT>(S_id, n, t, si, v, id);
+            packed = sort_scores_packed<DPT, false>(S_id, n, t, si, v, id);
             if (packed) {
                 float ls[DPT];
 #pragma unroll
@@ -237,7 +261,12 @@ metrics_kernel(const float *__restrict__ preds, const float *__restrict__ labels
     if (valid && t < kWave) {
         const int lane = t;
         const float max_label = max_label_dev ? ordered_to_float(reinterpret_cast<const int *>(max_label_dev)[0]) : max_label_host;
-        const float rpow_max = 1.0f / exp2f(max_label);      // adhoc_metric.py:133 (2^max_label: the reciprocal of a power of two is exact)
+        // adhoc_metric.py:133: 1 / 2^max_label.  Integer grades (every MultiLabel set): 2^-max_label from v_exp_f32, exact, like the reciprocal
+        // of a power of two; anything else (or a grade beyond the normal range) keeps the library exp2 and the IEEE division
+        const float ml = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, max_label)));   // uniform
+        float rpow_max;
+        if (ml == floorf(ml) && fabsf(ml) <= 64.0f) rpow_max = __builtin_amdgcn_exp2f(-ml);
+        else rpow_max = 1.0f / exp2f(ml);
         const bool w_ndcg = WHICH < 0 ? o_ndcg != nullptr : (WHICH & 1) != 0, w_nerr = WHICH < 0 ? o_nerr != nullptr : (WHICH & 2) != 0;
         const bool w_ap = WHICH < 0 ? o_ap != nullptr : (WHICH & 4) != 0, w_p = WHICH < 0 ? o_p != nullptr : (WHICH & 8) != 0;
         float *r_ndcg = w_ndcg ? o_ndcg + (size_t)q * ck.nk : nullptr;
@@ -263,37 +292,50 @@ metrics_kernel(const float *__restrict__ preds, const float *__restrict__ labels
         float c_sdcg = 0.f, c_idcg = 0.f, c_rel = 0.f, c_prec = 0.f, c_ideal = 0.f, c_serr = 0.f, c_ierr = 0.f, c_sun = 1.f, c_iun = 1.f;
         const int nchunk = (kmax + 63) >> 6;
         for (int ch = 0; ch < nchunk; ++ch) {
+            // ranks >= kmax (inside the last chunk; r < 64 DPT: inside the rows) are NOT masked: inclusive prefix scans flow from low lanes
+            // to high lanes only, no cut-off reads those lanes, and the chunk carries (lane 63) of the last chunk are never used
             const int r = ch * 64 + lane;
-            const bool in = r < kmax;
-            const float ys = in ? Y_sys[r] : 0.0f, yi = in ? Y_id[r] : 0.0f;
+            const bool in = true;
+            const float ys = Y_sys[r], yi = Y_id[r];
             const float rdisc = __builtin_amdgcn_rcpf(__builtin_amdgcn_logf((float)r + 2.0f));   // 1 / log2(rank + 2): v_log_f32, v_rcp_f32 (1 ulp each)
             // DCG gain: 2^l - 1 for graded labels, the raw label for LABEL_TYPE.Permutation (adhoc_metric.py:207-212,225-230)
             const float gs = in ? (linear_gain ? ys : gain_fast(ys)) : 0.0f, gi = in ? (linear_gain ? yi : gain_fast(yi)) : 0.0f;
             float sdcg = 0.0f, idcg = 1.0f;
             if (w_ndcg) {
-                sdcg = wave_incl_sum(in ? gs * rdisc : 0.0f, lane) + c_sdcg;     // adhoc_metric.py:233-234
-                idcg = wave_incl_sum(in ? gi * rdisc : 0.0f, lane) + c_idcg;
+                sdcg = gs * rdisc; idcg = gi * rdisc;
+                wave_incl_sum2(sdcg, idcg);                                      // adhoc_metric.py:233-234
+                sdcg += c_sdcg; idcg += c_idcg;
             }
             const float rel = in ? fminf(fmaxf(ys, 0.0f), 1.0f) : 0.0f;                // binary relevance (:106)
             const float cumrel = (w_ap || w_p) ? wave_incl_sum(rel, lane) + c_rel : 0.0f;
-            const float rr = __builtin_amdgcn_rcpf((float)r + 1.0f);
-            const float pr = cumrel / ((float)r + 1.0f);                 // rank-wise precision (:111): the reference's correctly rounded division — a
-                                                                         // perfect prefix gives P@k = AP = 1.0 exactly, not 0.99999994; rr (1 ulp) stays
-                                                                         // for the nERR cascade below
+            const float rpos = (float)r + 1.0f;
+            const float rr = __builtin_amdgcn_rcpf(rpos);                // 1 ulp: the nERR cascade below
+            // rank-wise precision cumrel / (r + 1) (:111), correctly rounded like the reference's division — a perfect prefix gives P@k = AP =
+            // 1.0 exactly, not 0.99999994 — by the Newton steps of the IEEE expansion WITHOUT its range scaling (v_div_scale /
+            // v_div_fmas / v_div_fixup): the divisor is an integer in [1, 4096] and 0 <= cumrel <= r + 1, nothing scales, nothing is special
+            const float y0 = fmaf(fmaf(-rpos, rr, 1.0f), rr, rr);
+            const float q0 = cumrel * y0;
+            const float q1 = fmaf(fmaf(-rpos, q0, cumrel), y0, q0);
+            const float pr = fmaf(fmaf(-rpos, q1, cumrel), y0, q1);
             float cumprec = 0.0f, cumideal = 1.0f;
             if (w_ap) {
-                cumprec = wave_incl_sum(pr * rel, lane) + c_prec;               // (:112)
-                cumideal = wave_incl_sum(yi, lane) + c_ideal;                   // GRADED ideal labels (:114)
+                cumprec = pr * rel; cumideal = yi;                              // (:112); GRADED ideal labels (:114)
+                wave_incl_sum2(cumprec, cumideal);
+                cumprec += c_prec; cumideal += c_ideal;
             }
             float serr = 0.0f, ierr = 1.0f, s_incl = 1.0f, i_incl = 1.0f;
             if (w_nerr) {
                 const float ssat = gs * rpow_max, isat = gi * rpow_max;                       // (:133)
                 // cascade: product of (1 - sat) over EARLIER ranks (:135-143) = exclusive prefix product
-                s_incl = wave_incl_prod(in ? 1.0f - ssat : 1.0f, lane); i_incl = wave_incl_prod(in ? 1.0f - isat : 1.0f, lane);
-                float s_excl = __shfl_up(s_incl, 1, 64), i_excl = __shfl_up(i_incl, 1, 64);
-                if (lane == 0) { s_excl = 1.0f; i_excl = 1.0f; }
-                serr = wave_incl_sum(in ? rr * ssat * (s_excl * c_sun) : 0.0f, lane) + c_serr;
-                ierr = wave_incl_sum(in ? rr * isat * (i_excl * c_iun) : 0.0f, lane) + c_ierr;
+                s_incl = 1.0f - ssat; i_incl = 1.0f - isat;
+                wave_incl_prod2(s_incl, i_incl);
+                // lane t <- lane t - 1 (wave_shr:1), lane 0 keeps the identity
+                const int one = __builtin_bit_cast(int, 1.0f);
+                const float s_excl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(one, __builtin_bit_cast(int, s_incl), 0x138, 0xF, 0xF, false));
+                const float i_excl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(one, __builtin_bit_cast(int, i_incl), 0x138, 0xF, 0xF, false));
+                serr = rr * ssat * (s_excl * c_sun); ierr = rr * isat * (i_excl * c_iun);
+                wave_incl_sum2(serr, ierr);
+                serr += c_serr; ierr += c_ierr;
             }
             {
                 const int src = kslot - 1 - ch * 64;                       // lane of this chunk that holds rank kslot - 1
@@ -304,10 +346,13 @@ metrics_kernel(const float *__restrict__ preds, const float *__restrict__ labels
                 if (r_ap) { const float o = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sel, __builtin_bit_cast(int, cumprec / cumideal))); if (mine) r_ap[lane] = o; }
                 if (r_p) { const float o = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sel, __builtin_bit_cast(int, pr))); if (mine) r_p[lane] = o; }
             }
-            c_sdcg = __shfl(sdcg, 63, 64); c_idcg = __shfl(idcg, 63, 64); c_rel = __shfl(cumrel, 63, 64);
-            c_prec = __shfl(cumprec, 63, 64); c_ideal = __shfl(cumideal, 63, 64);
-            c_serr = __shfl(serr, 63, 64); c_ierr = __shfl(ierr, 63, 64);
-            c_sun *= __shfl(s_incl, 63, 64); c_iun *= __shfl(i_incl, 63, 64);
+            if (ch + 1 < nchunk) {                                         // carries into the next chunk: lane 63's totals (v_readlane)
+                auto last = [](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63)); };
+                c_sdcg = last(sdcg); c_idcg = last(idcg); c_rel = last(cumrel);
+                c_prec = last(cumprec); c_ideal = last(cumideal);
+                c_serr = last(serr); c_ierr = last(ierr);
+                c_sun *= last(s_incl); c_iun *= last(i_incl);
+            }
         }
     }
 }
@@ -356,9 +401,15 @@ extern "C" int ptr_metrics_at_ks(const float *preds, const float *labels, const 
     const float *ml_dev = nullptr;
     if (nerr && max_label < 0.0f) {
         if (int rc = check_hip(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(max_label_ws), (int)0x80000000, 1, st), who)) return rc;
-        const size_t cells = ((size_t)B * L + kBlock - 1) / kBlock;
-        hipLaunchKernelGGL(batch_max_kernel, dim3((unsigned)(cells < 2048 ? cells : 2048)), dim3(kBlock), 0, st, labels, lens, B, L,
-                           reinterpret_cast<int *>(max_label_ws));
+        const size_t total = (size_t)B * L;
+        const size_t cells = (total + kBlock - 1) / kBlock;
+        if (!lens && (total & 3) == 0 && (reinterpret_cast<uintptr_t>(labels) & 15) == 0) {
+            const size_t c4 = (total / 4 + kBlock - 1) / kBlock;
+            hipLaunchKernelGGL(batch_max_vec_kernel, dim3((unsigned)(c4 < 512 ? c4 : 512)), dim3(kBlock), 0, st,       // 512 atomics on the one key
+                               reinterpret_cast<const float4 *>(labels), total / 4, reinterpret_cast<int *>(max_label_ws));
+        } else
+            hipLaunchKernelGGL(batch_max_kernel, dim3((unsigned)(cells < 2048 ? cells : 2048)), dim3(kBlock), 0, st, labels, lens, B, L,
+                               reinterpret_cast<int *>(max_label_ws));
         if (int rc = check_hip(hipGetLastError(), who)) return rc;
         ml_dev = max_label_ws;
     }

@@ -4,6 +4,7 @@
 // query; a 256-thread workgroup therefore holds 256/G queries.  Per-query tiles (scores, gains, discounts, partial
 // gradients) live in LDS; each thread owns the documents i = t, t+G, t+2G, ... (DPT of them, compile-time bound).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -65,6 +66,25 @@ template <class F> inline int dispatch_wave256_tiling(int L, F &&f) {
     if (L <= 128) return f.template operator()<64, 2>();
     if (L <= 256) return f.template operator()<64, 4>();
     return dispatch_tiling(L, f);
+}
+
+// Grid of a PERSISTENT kernel (its wavefronts walk the work with a grid stride): the blocks the device keeps resident at once — CUs x the
+// occupancy of `kernel` at `block` threads and `lds` bytes of dynamic LDS — capped by the blocks the work needs.  Cached per kernel.
+template <class K> inline int persistent_grid(K kernel, int block, size_t lds, int want) {
+    static int resident = 0;                                       // (kernels of one signature share this instantiation: keyed below)
+    static const void *cached_for = nullptr;
+    if (cached_for != reinterpret_cast<const void *>(kernel) || resident <= 0) {
+        int dev = 0, per_cu = 0;
+        hipDeviceProp_t pr;
+        int cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kernel), block, lds) != hipSuccess || per_cu <= 0) per_cu = 4;
+        resident = cus * per_cu;
+        cached_for = reinterpret_cast<const void *>(kernel);
+    }
+    static const int mult = [] { const char *e = getenv("PTR_PERSIST_MULT"); return e ? atoi(e) : 1; }();   // 0: one block per unit of work (measurements)
+    if (mult <= 0) return want > 0 ? want : 1;
+    const long cap = (long)resident * mult;
+    return want < cap ? (want > 0 ? want : 1) : (int)cap;
 }
 
 // Raises the dynamic-LDS cap of `kernel` when a launch needs more than the 64 KiB default.
@@ -165,29 +185,44 @@ template <int G> __device__ __forceinline__ float group_max(float v, float *red,
 // Inclusive prefix scans over one wavefront (lane order) out of the VALU alone: DPP row shifts inside the 16-lane rows, then the row
 // totals carried across rows by row_bcast:15 / :31 — 6 instructions per scan (the __shfl_up form goes through the LDS crossbar six
 // times and needs a select per step).  Lanes without a source (row_shr beyond the row start, unwritten rows) take the identity.
-#define PTR_DPP_SRC(v, ident, ctrl, rows) \
-    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(ident)), __builtin_bit_cast(int, (v)), (ctrl), (rows), 0xF, false))
+// r5: written as v_add_f32 / v_mul_f32 with a DPP source — one instruction per step (the builtin form cost an identity move, the DPP move
+// and the operation for the row_bcast steps and for every product step); a lane a step does not write (no source lane inside the row,
+// rows outside row_mask) keeps its value, which is the identity's effect.  s_nop: the VALU-write -> DPP-read hazard (2 wait states) that
+// the assembler does not see inside an asm block.  The *2 forms run two independent scans interleaved (one wait state filled by the
+// other scan's instruction).  Same operations in the same order as before: bit-identical results.
+#define PTR_SCAN_STEPS(op, n0)                                                          \
+    n0 op " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                       \
+    "s_nop 1\n\t" op " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"           \
+    "s_nop 1\n\t" op " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"           \
+    "s_nop 1\n\t" op " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"           \
+    "s_nop 1\n\t" op " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"        \
+    "s_nop 1\n\t" op " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"        \
+    "s_nop 1"
+#define PTR_SCAN2_STEP(op, ctl) op " %0, %0, %0 " ctl "\n\t" op " %1, %1, %1 " ctl "\n\ts_nop 0\n\t"
+#define PTR_SCAN2_STEPS(op)                                                             \
+    "s_nop 1\n\t"                                                                      \
+    PTR_SCAN2_STEP(op, "row_shr:1 row_mask:0xf bank_mask:0xf")                          \
+    PTR_SCAN2_STEP(op, "row_shr:2 row_mask:0xf bank_mask:0xf")                          \
+    PTR_SCAN2_STEP(op, "row_shr:4 row_mask:0xf bank_mask:0xf")                          \
+    PTR_SCAN2_STEP(op, "row_shr:8 row_mask:0xf bank_mask:0xf")                          \
+    PTR_SCAN2_STEP(op, "row_bcast:15 row_mask:0xa bank_mask:0xf")                       \
+    PTR_SCAN2_STEP(op, "row_bcast:31 row_mask:0xc bank_mask:0xf")                       \
+    "s_nop 0"
 __device__ __forceinline__ float wave_incl_sum(float v, int lane) {
     (void)lane;
-    v += PTR_DPP_SRC(v, 0.0f, 0x111, 0xF);      // row_shr:1
-    v += PTR_DPP_SRC(v, 0.0f, 0x112, 0xF);      // row_shr:2
-    v += PTR_DPP_SRC(v, 0.0f, 0x114, 0xF);      // row_shr:4
-    v += PTR_DPP_SRC(v, 0.0f, 0x118, 0xF);      // row_shr:8: every lane holds the prefix inside its row
-    v += PTR_DPP_SRC(v, 0.0f, 0x142, 0xA);      // row_bcast:15 into rows 1 and 3
-    v += PTR_DPP_SRC(v, 0.0f, 0x143, 0xC);      // row_bcast:31 into rows 2 and 3
+    asm(PTR_SCAN_STEPS("v_add_f32_dpp", "s_nop 1\n\t") : "+v"(v));
     return v;
 }
 __device__ __forceinline__ float wave_incl_prod(float v, int lane) {
     (void)lane;
-    v *= PTR_DPP_SRC(v, 1.0f, 0x111, 0xF);
-    v *= PTR_DPP_SRC(v, 1.0f, 0x112, 0xF);
-    v *= PTR_DPP_SRC(v, 1.0f, 0x114, 0xF);
-    v *= PTR_DPP_SRC(v, 1.0f, 0x118, 0xF);
-    v *= PTR_DPP_SRC(v, 1.0f, 0x142, 0xA);
-    v *= PTR_DPP_SRC(v, 1.0f, 0x143, 0xC);
+    asm(PTR_SCAN_STEPS("v_mul_f32_dpp", "s_nop 1\n\t") : "+v"(v));
     return v;
 }
-#undef PTR_DPP_SRC
+__device__ __forceinline__ void wave_incl_sum2(float &a, float &b) { asm(PTR_SCAN2_STEPS("v_add_f32_dpp") : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void wave_incl_prod2(float &a, float &b) { asm(PTR_SCAN2_STEPS("v_mul_f32_dpp") : "+v"(a), "+v"(b)); }
+#undef PTR_SCAN_STEPS
+#undef PTR_SCAN2_STEP
+#undef PTR_SCAN2_STEPS
 // Inclusive SUFFIX sum over one wavefront (lane i gets sum of lanes i..63).
 __device__ __forceinline__ float wave_incl_suffix_sum(float v, int lane) {
 #pragma unroll
@@ -561,30 +596,43 @@ __device__ __forceinline__ int dpp_wave_shr1(int v) { return __builtin_amdgcn_up
 // exact count) if any is not, or if a score is NaN.  -0.0 keys as +0.0 (torch.sort compares them equal; the index decides).
 // own[r] = score of document t*DPT + r (-inf beyond n); raw: LDS, N floats (left holding the scores by document).  On success sc[r] / id[r]
 // = score / document of position t*DPT + r (positions >= n: -inf / N-1).
-template <int DPT>
+template <int DPT, bool NEED_SC>
 __device__ __forceinline__ bool sort_scores_packed(float *raw, int n, int t, const float (&own)[DPT], float (&sc)[DPT], int (&id)[DPT]) {
     static_assert(DPT == 2 || DPT == 4, "lists of 65 .. 256 documents");
     constexpr int N = kWave * DPT;
     uint32_t key[DPT];
     bool bad = false;
+    auto build = [&](auto full) {
 #pragma unroll
-    for (int r = 0; r < DPT; ++r) {
-        const int i = t * DPT + r;
-        const float x = own[r] + 0.0f;
-        bad |= x != x;
-        const int b = __builtin_bit_cast(int, x);
-        const uint32_t o = (uint32_t)b ^ ((uint32_t)(b >> 31) | 0x80000000u);
-        key[r] = i < n ? (o & ~(uint32_t)(N - 1)) | (uint32_t)(N - 1 - i) : 0u;
-    }
+        for (int r = 0; r < DPT; ++r) {
+            const int i = t * DPT + r;
+            const float x = own[r] + 0.0f;
+            bad |= x != x;
+            const int b = __builtin_bit_cast(int, x);
+            const uint32_t o = (uint32_t)b ^ ((uint32_t)(b >> 31) | 0x80000000u);
+            const uint32_t kv = (o & ~(uint32_t)(N - 1)) | (uint32_t)(N - 1 - i);
+            key[r] = (decltype(full)::value || i < n) ? kv : 0u;
+        }
+    };
+    if (n == N) build(std::true_type{}); else build(std::false_type{});     // uniform: full lists carry no padding masks
     lds_store_blocked<DPT>(raw, t, own);
     if (__any(bad)) return false;
     wave_sort_desc<DPT>(key, t);
     wave_lds_sync();
+    // documents whose scores agree in the key's score bits sit next to each other: no such pair among the n documents -> the order is exact
+    bool coll = false;
 #pragma unroll
-    for (int r = 0; r < DPT; ++r) {
-        id[r] = N - 1 - (int)(key[r] & (uint32_t)(N - 1));
-        sc[r] = raw[id[r]];
+    for (int r = 0; r + 1 < DPT; ++r) coll |= (key[r] ^ key[r + 1]) < (uint32_t)N && t * DPT + r + 1 < n;
+    const uint32_t nkey = (uint32_t)dpp_wave_shl1((int)key[0]);
+    coll |= (key[DPT - 1] ^ nkey) < (uint32_t)N && t * DPT + DPT < n && t < 63;
+#pragma unroll
+    for (int r = 0; r < DPT; ++r) id[r] = N - 1 - (int)(key[r] & (uint32_t)(N - 1));
+    const bool repair = __any(coll);
+    if (NEED_SC || repair) {
+#pragma unroll
+        for (int r = 0; r < DPT; ++r) sc[r] = raw[id[r]];
     }
+    if (!repair) return true;
     auto wrong = [](float sa, int ia, float sb, int ib) { return sa < sb || (sa == sb && ia > ib); };
     auto fix = [&](int a, int b) {
         const bool w = wrong(sc[a], id[a], sc[b], id[b]);
@@ -615,7 +663,13 @@ __device__ __forceinline__ bool sort_scores_packed(float *raw, int n, int t, con
 // 16-byte global loads of a row into the blocked layout (row base 16-byte aligned: L % 4 == 0), scalar loads otherwise; `pad` beyond n
 template <int DPT>
 __device__ __forceinline__ void load_blocked(const float *__restrict__ row, int n, int L, int t, float pad, float (&x)[DPT]) {
-    if (DPT % 4 == 0 && (L & 3) == 0) {
+    if (DPT % 4 == 0 && n == kWave * DPT) {                                  // full row (n == L == 64 DPT): no masks
+#pragma unroll
+        for (int r = 0; r < DPT; r += 4) {
+            const float4 u = *reinterpret_cast<const float4 *>(row + t * DPT + r);
+            x[r] = u.x; x[r + 1] = u.y; x[r + 2] = u.z; x[r + 3] = u.w;
+        }
+    } else if (DPT % 4 == 0 && (L & 3) == 0) {
 #pragma unroll
         for (int r = 0; r < DPT; r += 4) {
             const int i = t * DPT + r;
