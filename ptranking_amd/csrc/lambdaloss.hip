@@ -291,49 +291,39 @@ lambdaloss_topk_kernel(const float *__restrict__ preds, const float *__restrict_
         float rs = 0.0f, ry = 0.0f;
         int ri = -1;
         if constexpr (V == 1) {
+            // a lane's four documents stay where they are; a document that cannot win any more (padding, a NaN score — the reference sorts
+            // those last —, taken in an earlier round) is a quiet NaN, which v_max ignores and no comparison matches
             float hs[4];
-            int hi[4];
-            bool nan = false;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) nan |= s[e] != s[e];
-            if (full && !__any(nan)) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { hs[e] = s[e]; hi[e] = 4 * lane + e; }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int i = 4 * lane + e;
-                    const bool live = i < n && s[e] == s[e];                               // NaN scores never win (the reference sorts them last)
-                    hs[e] = live ? s[e] : -INFINITY; hi[e] = live ? i : kDead;
-                }
-            }
-            auto cx = [&](int u, int w) {                                                  // position u keeps the better (score desc, index asc)
-                const bool sw = hs[w] > hs[u] || (hs[w] == hs[u] && hi[w] < hi[u]);
-                const float s0 = sw ? hs[w] : hs[u], s1 = sw ? hs[u] : hs[w];
-                const int i0 = sw ? hi[w] : hi[u], i1 = sw ? hi[u] : hi[w];
-                hs[u] = s0; hs[w] = s1; hi[u] = i0; hi[w] = i1;
+            for (int e = 0; e < 4; ++e) hs[e] = (full || 4 * lane + e < n) ? __builtin_canonicalizef(s[e]) : __builtin_nanf("");
+            float hm;                                                                      // the lane's best score and its register
+            int he;
+            auto head = [&]() __attribute__((always_inline)) {
+                float m3;
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m3) : "v"(hs[0]), "v"(hs[1]), "v"(hs[2]));
+                asm("v_max_f32 %0, %1, %2" : "=v"(hm) : "v"(m3), "v"(hs[3]));
+                he = hs[0] == hm ? 0 : (hs[1] == hm ? 1 : (hs[2] == hm ? 2 : 3));         // equal scores: the lowest index
             };
-            cx(0, 1); cx(2, 3); cx(0, 2); cx(1, 3); cx(1, 2);
+            head();
             int rsb = 0, ryb = 0;                                                          // records as bits: written lane by lane (v_writelane)
-            auto round = [&]<int R>() -> bool {
-                const float gmax = wave_max_dpp(hs[0]);                                    // DPP ladder: no LDS crossbar round trips in the selection
-                const uint64_t own = __builtin_amdgcn_ballot_w64(hi[0] != kDead && hs[0] == gmax);
+            auto round = [&]<int R>() __attribute__((always_inline)) -> bool {
+                const float gmax = wave_max_dpp(hm);                                       // DPP ladder: no LDS crossbar round trips in the selection
+                const uint64_t own = __builtin_amdgcn_ballot_w64(hm == gmax);
                 if (own == 0) return false;                                                // fewer than kk rankable documents (all NaN)
                 const int wl = (int)__builtin_ctzll(own);                                  // the lowest lane holds the lowest index
-                const int wi = __builtin_amdgcn_readlane(hi[0], wl);
-                const int we = wi & 3;                                                     // the winner's label: register we of lane wl
+                const int we = __builtin_amdgcn_readlane(he, wl);
+                const int wi = 4 * wl + we;
                 const float ysel = we == 0 ? y[0] : (we == 1 ? y[1] : (we == 2 ? y[2] : y[3]));   // scalar conditions
                 const int wy = __builtin_amdgcn_readlane(__builtin_bit_cast(int, ysel), wl);
                 const int gb = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, gmax));
                 asm("v_writelane_b32 %0, %1, %2" : "+v"(rsb) : "s"(gb), "n"(R));
                 asm("v_writelane_b32 %0, %1, %2" : "+v"(ryb) : "s"(wy), "n"(R));
                 asm("v_writelane_b32 %0, %1, %2" : "+v"(ri) : "s"(wi), "n"(R));
-                if (lane == wl) {
-                    hs[0] = hs[1]; hi[0] = hi[1];
-                    hs[1] = hs[2]; hi[1] = hi[2];
-                    hs[2] = hs[3]; hi[2] = hi[3];
-                    hs[3] = -INFINITY; hi[3] = kDead;
-                }
+                const bool mine = lane == wl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (we == e) hs[e] = mine ? __builtin_nanf("") : hs[e];                // scalar condition: one select
+                head();
                 return true;
             };
             [&]<int... R>(std::integer_sequence<int, R...>) {
