@@ -37,17 +37,20 @@ sort_desc_kernel(const float *__restrict__ preds, const int32_t *__restrict__ le
         float *vrow = vals + (size_t)q * L;
         int64_t *irow = idx + (size_t)q * L;
         typedef long i64x2_t __attribute__((ext_vector_type(2)));
-        if constexpr (DPT == 2 || DPT == 4) {
-            // 65 .. 256 documents: packed (score, index) keys, the permutation read off the sorted keys (no rank search)
+        if constexpr (DPT >= 2) {
+            // 65 .. 1024 documents: packed (score, index) keys, the permutation read off the sorted keys (no rank search)
             float sc[DPT];
             int id[DPT];
             if (sort_scores_packed<DPT, true>(keys, n, t, own, sc, id)) {
-                if (DPT == 4 && (L & 3) == 0) {
-                    const int p = t * 4;
-                    if (p < L) {
-                        *reinterpret_cast<float4 *>(vrow + p) = float4{p < n ? sc[0] : 0.0f, p + 1 < n ? sc[1] : 0.0f, p + 2 < n ? sc[2] : 0.0f, p + 3 < n ? sc[3] : 0.0f};
-                        *reinterpret_cast<i64x2_t *>(irow + p) = i64x2_t{p < n ? (long)id[0] : (long)p, p + 1 < n ? (long)id[1] : (long)(p + 1)};
-                        *reinterpret_cast<i64x2_t *>(irow + p + 2) = i64x2_t{p + 2 < n ? (long)id[2] : (long)(p + 2), p + 3 < n ? (long)id[3] : (long)(p + 3)};
+                if (DPT % 4 == 0 && (L & 3) == 0) {
+#pragma unroll
+                    for (int r = 0; r < DPT; r += 4) {
+                        const int p = t * DPT + r;
+                        if (p < L) {
+                            *reinterpret_cast<float4 *>(vrow + p) = float4{p < n ? sc[r] : 0.0f, p + 1 < n ? sc[r + 1] : 0.0f, p + 2 < n ? sc[r + 2] : 0.0f, p + 3 < n ? sc[r + 3] : 0.0f};
+                            *reinterpret_cast<i64x2_t *>(irow + p) = i64x2_t{p < n ? (long)id[r] : (long)p, p + 1 < n ? (long)id[r + 1] : (long)(p + 1)};
+                            *reinterpret_cast<i64x2_t *>(irow + p + 2) = i64x2_t{p + 2 < n ? (long)id[r + 2] : (long)(p + 2), p + 3 < n ? (long)id[r + 3] : (long)(p + 3)};
+                        }
                     }
                 } else {
 #pragma unroll
@@ -199,8 +202,8 @@ metrics_kernel(const float *__restrict__ preds, const float *__restrict__ labels
         // NOTE: the reference sorts the predictions in ORIGINAL order (ranker.py:50) — ties are broken by original index —
         // and sorts the labels separately for the ideal ranking (ranker.py:53-56).
         bool packed = false;
-        if constexpr (DPT == 2 || DPT == 4) {
-            // 65 .. 256 documents: packed (score, index) keys; the labels by predicted rank are gathered through the sorted keys' index bits
+        if constexpr (DPT >= 2) {
+            // 65 .. 1024 documents: packed (score, index) keys; the labels by predicted rank are gathered through the sorted keys' index bits
             int id[DPT];
             lds_store_blocked<DPT>(Y_id, t, li);                        // labels by document (Y_id is staged below)
             packed = sort_scores_packed<DPT, false>(S_id, n, t, si, v, id);

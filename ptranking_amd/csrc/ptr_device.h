@@ -587,18 +587,18 @@ __device__ __forceinline__ float dpp_wave_shr1(float v) {      // lane t <- lane
 __device__ __forceinline__ int dpp_wave_shl1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xF, 0xF, true); }
 __device__ __forceinline__ int dpp_wave_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, true); }
 
-// r5: the (score descending, index ascending) order of 128 / 256 documents from ONE register sort, without a rank search.
+// r5: the (score descending, index ascending) order of 65 .. 1024 documents from ONE register sort, without a rank search.
 // Key = order-preserving integer image of the score with its low IB bits replaced by (N - 1 - index) (N = 64 DPT, IB = log2 N), sorted
 // descending by the integer network; position p's document is read off the key, its true score gathered from the row staged in LDS.
-// The truncated order is wrong only between documents whose scores agree in the top 32 - IB bits (about one pair in three lists of 256
-// N(0,1) scores): one odd-even transposition round on the true (score, index) pairs repairs isolated pairs, every adjacent pair is then
+// The truncated order is wrong only between documents whose scores agree in the top 32 - IB bits (about one pair in eight lists of 256
+// N(0,1) scores, a handful of pairs in a list of 1024): one odd-even transposition round on the true (score, index) pairs repairs isolated pairs, every adjacent pair is then
 // CHECKED — a sorted row is exactly one whose adjacent pairs are ordered — and the wave returns false (caller: the float sort + search /
 // exact count) if any is not, or if a score is NaN.  -0.0 keys as +0.0 (torch.sort compares them equal; the index decides).
 // own[r] = score of document t*DPT + r (-inf beyond n); raw: LDS, N floats (left holding the scores by document).  On success sc[r] / id[r]
 // = score / document of position t*DPT + r (positions >= n: -inf / N-1).
 template <int DPT, bool NEED_SC>
 __device__ __forceinline__ bool sort_scores_packed(float *raw, int n, int t, const float (&own)[DPT], float (&sc)[DPT], int (&id)[DPT]) {
-    static_assert(DPT == 2 || DPT == 4, "lists of 65 .. 256 documents");
+    static_assert(DPT == 2 || DPT == 4 || DPT == 8 || DPT == 16, "lists of 65 .. 1024 documents");
     constexpr int N = kWave * DPT;
     uint32_t key[DPT];
     bool bad = false;
