@@ -439,3 +439,66 @@ def test_c_abi_direct_calls_and_errors():
     with pytest.raises(RuntimeError, match="sigma"):
         from ptranking_amd import functional
         functional.lambdarank_loss(torch.zeros(1, 4, device="cuda"), torch.zeros(1, 4, device="cuda"), sigma=-1.0)
+
+
+@pytest.mark.parametrize("L", [100, 128, 256, 333, 512, 1024])
+def test_sort_and_metrics_with_scores_that_collide_in_the_packed_keys(F, L):
+    """r5: lists of 65 .. 1024 documents are ordered by ONE register sort of packed keys (the score's top 32 - log2(64 DPT) bits | the
+    index).  Scores that agree in those bits reach the repair round (isolated pairs, inside a lane and across a lane boundary) or the
+    fallback (runs of three and more); exact ties, signed zeros and infinities must keep the (score descending, index ascending) order of
+    torch.sort(stable=True).  Bit-exact values and indices; the metric kernel on the same rows against the C oracle."""
+    from oracle import c_oracle as CO
+    rng = np.random.default_rng(L)
+    B = 12
+    P = np.empty((B, L), np.float32)
+    base = np.linspace(3.0, -3.0, L).astype(np.float32)
+    P[0] = base[rng.permutation(L)]
+    for a, b in ((10, 11), (63, 64), (3, 4), (L - 2, L - 1), (40, 90)):      # pairs one ulp apart, the larger score at the larger index
+        x = np.float32(0.5 + 0.01 * a)
+        P[0, a], P[0, b] = x, np.nextafter(x, np.float32(4.0))
+    P[1] = (np.float32(1.0) + rng.permutation(L).astype(np.float32) * np.float32(2.0 ** -23))      # one long run in the truncated keys
+    P[2] = rng.choice(np.array([0.0, -0.0, 1.0, -1.0], np.float32), size=L)
+    P[3] = np.float32(0.75)
+    P[4] = base[rng.permutation(L)]
+    P[4, [1, 5, L - 1]] = np.inf
+    P[4, [0, 7, L - 3]] = -np.inf
+    P[5] = np.round(rng.standard_normal(L) * 8).astype(np.float32) / np.float32(8)                 # many exact ties
+    P[6] = (np.float32(-2.0) - rng.permutation(L).astype(np.float32) * np.float32(2.0 ** -22))     # negative scores, runs
+    P[7:] = rng.standard_normal((B - 7, L)).astype(np.float32) * np.float32(1e-3) + np.float32(0.5)   # dense: several colliding pairs
+    vals, idx = F.sort_desc(dev(P))
+    tv, ti = torch.sort(torch.from_numpy(P), dim=1, descending=True, stable=True)
+    assert np.array_equal(idx.cpu().numpy(), ti.numpy())
+    assert np.array_equal(vals.cpu().numpy().view(np.int32), tv.numpy().view(np.int32))
+    ln = np.array([L, L - 1, L // 2 + 1, 70, L, 66, L - 3, L, 65, L, L - 2, L], np.int32)
+    vals, idx = F.sort_desc(dev(P), lens=dev(ln))
+    rv, ri = CO.sort_desc(P, lens=ln)
+    assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(vals.cpu().numpy().view(np.int32), rv.view(np.int32))
+    labels = rng.integers(0, 5, size=(B, L)).astype(np.float32)
+    ks = [1, 3, 5, 10, 20, 50, 100]
+    for lens in (None, ln):
+        out = F.metrics_at_ks(dev(P), dev(labels), ks, presort=False, lens=None if lens is None else dev(lens))
+        ref = CO.metrics_at_ks(P, labels, ks, False, lens=lens)
+        for m in ("ndcg", "nerr", "ap", "p"):
+            G.assert_close(out[m].cpu().numpy(), ref[m], m)
+
+
+def test_tie_shuffle_key_paths(F):
+    """r5: integer grades up to 63 take the packed-key register sort (grade | random field | index in 32 bits: grades >= 32 set the key's top
+    bit); other labels take the exact comparison.  Every path returns a permutation that orders the labels descending, and different seeds
+    give different orders inside the tie groups."""
+    rng = np.random.default_rng(5)
+    for L in (64, 96, 256, 500, 1024):
+        for hi, frac in ((5, False), (64, False), (200, False), (5, True)):
+            y = rng.integers(0, hi, size=(9, L)).astype(np.float32)
+            if frac:
+                y = y + np.float32(0.5)
+            ln = rng.integers(1, L + 1, size=9).astype(np.int32)
+            for lens in (None, ln):
+                p1 = F.shuffle_ties_order(dev(y), seed=3, lens=None if lens is None else dev(lens)).cpu().numpy()
+                p2 = F.shuffle_ties_order(dev(y), seed=4, lens=None if lens is None else dev(lens)).cpu().numpy()
+                for b in range(9):
+                    n = L if lens is None else int(lens[b])
+                    assert sorted(p1[b, :n].tolist()) == list(range(n)) and np.array_equal(p1[b, n:], np.arange(n, L))
+                    assert np.all(np.diff(y[b, p1[b, :n]]) <= 0)
+                if L >= 256:
+                    assert not np.array_equal(p1, p2)
