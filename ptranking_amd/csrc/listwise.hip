@@ -508,11 +508,11 @@ __device__ __forceinline__ uint32_t tie_hash(uint32_t qkey, uint32_t i) { return
 typedef long i64x2_t __attribute__((ext_vector_type(2)));
 template <int DPT>
 __device__ __forceinline__ bool shuffle_ties_wave(const float *__restrict__ labels, int q, int n, int L, uint32_t qkey, int t,
-                                                  int64_t *__restrict__ perm) {
+                                                  int64_t *__restrict__ perm, bool aligned) {
     constexpr int N = kWave * DPT;
     constexpr int IB = DPT == 1 ? 6 : DPT == 2 ? 7 : DPT == 4 ? 8 : DPT == 8 ? 9 : 10, FB = 26 - IB;
     const float *row = labels + (size_t)q * L;
-    const bool vec = DPT % 4 == 0 && (L & 3) == 0;
+    const bool vec = DPT % 4 == 0 && (L & 3) == 0 && aligned;
     float y[DPT];
     if (vec) {
 #pragma unroll
@@ -564,7 +564,7 @@ __device__ __forceinline__ bool shuffle_ties_wave(const float *__restrict__ labe
 template <int G, int DPT>
 __global__ void __launch_bounds__(kBlock)
 shuffle_ties_kernel(const float *__restrict__ labels, const int32_t *__restrict__ lens, int B, int L, int Lp, uint64_t seed,
-                    int64_t *__restrict__ perm) {
+                    int64_t *__restrict__ perm, int aligned) {
     constexpr int QPB = kBlock / G;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, grp = tid / G, t = tid % G;
@@ -577,7 +577,7 @@ shuffle_ties_kernel(const float *__restrict__ labels, const int32_t *__restrict_
     const uint32_t qkey = tie_query_key(seed, (uint32_t)q);
     if constexpr (G == kWave) {
         if (!valid) return;                                    // the waves of a block are independent: no workgroup barrier on this path
-        if (shuffle_ties_wave<DPT>(labels, q, n, L, qkey, t, perm)) return;
+        if (shuffle_ties_wave<DPT>(labels, q, n, L, qkey, t, perm, aligned != 0)) return;
     }
     float y[DPT], key[DPT];
     uint32_t r[DPT];
@@ -771,7 +771,8 @@ extern "C" int ptr_shuffle_ties_order(const float *labels, const int32_t *lens, 
         auto kern = shuffle_ties_kernel<G, DPT>;
         const size_t lds = ((size_t)QPB * 3 * Lp + 4) * sizeof(float);
         if (int e = allow_lds(kern, lds)) return e;
-        hipLaunchKernelGGL(kern, dim3((B + QPB - 1) / QPB), dim3(kBlock), lds, as_stream(stream), labels, lens, B, L, Lp, seed, perm);
+        hipLaunchKernelGGL(kern, dim3((B + QPB - 1) / QPB), dim3(kBlock), lds, as_stream(stream), labels, lens, B, L, Lp, seed, perm,
+                           (int)(((reinterpret_cast<uintptr_t>(labels) | reinterpret_cast<uintptr_t>(perm)) & 15) == 0));
         return check_hip(hipGetLastError(), who);
     });
 }

@@ -19,7 +19,7 @@ struct Cutoffs { int nk; int k[PTR_MAX_CUTOFFS]; };
 template <int G, int DPT>
 __global__ void __launch_bounds__(kBlock)
 sort_desc_kernel(const float *__restrict__ preds, const int32_t *__restrict__ lens, int B, int L, int Lp, float *__restrict__ vals,
-                 int64_t *__restrict__ idx) {
+                 int64_t *__restrict__ idx, int aligned) {
     constexpr int QPB = kBlock / G;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, grp = tid / G, t = tid % G;
@@ -33,7 +33,7 @@ sort_desc_kernel(const float *__restrict__ preds, const int32_t *__restrict__ le
         if (!valid) return;
         float own[DPT], v[DPT];
         int rk[DPT];
-        load_blocked<DPT>(preds + (size_t)q * L, n, L, t, -INFINITY, own);
+        load_blocked<DPT>(preds + (size_t)q * L, n, L, t, -INFINITY, own, aligned != 0);
         float *vrow = vals + (size_t)q * L;
         int64_t *irow = idx + (size_t)q * L;
         typedef long i64x2_t __attribute__((ext_vector_type(2)));
@@ -42,7 +42,7 @@ sort_desc_kernel(const float *__restrict__ preds, const int32_t *__restrict__ le
             float sc[DPT];
             int id[DPT];
             if (sort_scores_packed<DPT, true>(keys, n, t, own, sc, id)) {
-                if (DPT % 4 == 0 && (L & 3) == 0) {
+                if (DPT % 4 == 0 && (L & 3) == 0 && aligned) {
 #pragma unroll
                     for (int r = 0; r < DPT; r += 4) {
                         const int p = t * DPT + r;
@@ -70,7 +70,7 @@ sort_desc_kernel(const float *__restrict__ preds, const int32_t *__restrict__ le
             if (i < n) { sv[rk[r]] = own[r]; si_[rk[r]] = i; }
         }
         wave_lds_sync();
-        if (DPT % 4 == 0 && (L & 3) == 0) {
+        if (DPT % 4 == 0 && (L & 3) == 0 && aligned) {
 #pragma unroll
             for (int r = 0; r < DPT; r += 4) {
                 const int p = t * DPT + r;
@@ -181,7 +181,7 @@ template <int G, int DPT, int WHICH>
 __global__ void __launch_bounds__(kBlock)
 metrics_kernel(const float *__restrict__ preds, const float *__restrict__ labels, const int32_t *__restrict__ lens, int B, int L,
                int Lp, Cutoffs ck, int presort, int linear_gain, float max_label_host, const float *__restrict__ max_label_dev,
-               float *__restrict__ o_ndcg, float *__restrict__ o_nerr, float *__restrict__ o_ap, float *__restrict__ o_p) {
+               float *__restrict__ o_ndcg, float *__restrict__ o_nerr, float *__restrict__ o_ap, float *__restrict__ o_p, int aligned) {
     constexpr int QPB = kBlock / G;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, grp = tid / G, t = tid % G;
@@ -197,8 +197,8 @@ metrics_kernel(const float *__restrict__ preds, const float *__restrict__ labels
         // t*DPT ..: 16-byte loads, no LDS staging ahead of the sorts), the waves of a block are independent (no workgroup barrier)
         float si[DPT], li[DPT], v[DPT];
         int rk[DPT];
-        load_blocked<DPT>(preds + (size_t)q * L, n, L, t, -INFINITY, si);
-        load_blocked<DPT>(labels + (size_t)q * L, n, L, t, 0.0f, li);
+        load_blocked<DPT>(preds + (size_t)q * L, n, L, t, -INFINITY, si, aligned != 0);
+        load_blocked<DPT>(labels + (size_t)q * L, n, L, t, 0.0f, li, aligned != 0);
         // NOTE: the reference sorts the predictions in ORIGINAL order (ranker.py:50) — ties are broken by original index —
         // and sorts the labels separately for the ideal ranking (ranker.py:53-56).
         bool packed = false;
@@ -299,7 +299,8 @@ metrics_kernel(const float *__restrict__ preds, const float *__restrict__ labels
             // to high lanes only, no cut-off reads those lanes, and the chunk carries (lane 63) of the last chunk are never used
             const int r = ch * 64 + lane;
             const bool in = true;
-            const float ys = Y_sys[r], yi = Y_id[r];
+            const int rl = G == kWave ? r : (r < Lp ? r : Lp - 1);   // four waves per query: the rows hold round_up(L, 4) entries
+            const float ys = Y_sys[rl], yi = Y_id[rl];
             const float rdisc = __builtin_amdgcn_rcpf(__builtin_amdgcn_logf((float)r + 2.0f));   // 1 / log2(rank + 2): v_log_f32, v_rcp_f32 (1 ulp each)
             // DCG gain: 2^l - 1 for graded labels, the raw label for LABEL_TYPE.Permutation (adhoc_metric.py:207-212,225-230)
             const float gs = in ? (linear_gain ? ys : gain_fast(ys)) : 0.0f, gi = in ? (linear_gain ? yi : gain_fast(yi)) : 0.0f;
@@ -374,7 +375,8 @@ extern "C" int ptr_sort_desc(const float *preds, const int32_t *lens, int B, int
         auto kern = sort_desc_kernel<G, DPT>;
         const size_t lds = (size_t)QPB * 3 * Lp * sizeof(float);
         if (int e = allow_lds(kern, lds)) return e;
-        hipLaunchKernelGGL(kern, dim3((B + QPB - 1) / QPB), dim3(kBlock), lds, as_stream(stream), preds, lens, B, L, Lp, vals, idx);
+        hipLaunchKernelGGL(kern, dim3((B + QPB - 1) / QPB), dim3(kBlock), lds, as_stream(stream), preds, lens, B, L, Lp, vals, idx,
+                           (int)(((reinterpret_cast<uintptr_t>(preds) | reinterpret_cast<uintptr_t>(vals) | reinterpret_cast<uintptr_t>(idx)) & 15) == 0));
         return check_hip(hipGetLastError(), who);
     });
 }
@@ -424,7 +426,7 @@ extern "C" int ptr_metrics_at_ks(const float *preds, const float *labels, const 
             const size_t lds = (size_t)QPB * 3 * Lp * sizeof(float);
             if (int e = allow_lds(kern, lds)) return e;
             hipLaunchKernelGGL(kern, dim3((B + QPB - 1) / QPB), dim3(kBlock), lds, st, preds, labels, lens, B, L, Lp, ck, presort, label_type == PTR_LABEL_PERMUTATION ? 1 : 0, max_label,
-                               ml_dev, ndcg, nerr, ap, prec);
+                               ml_dev, ndcg, nerr, ap, prec, (int)(((reinterpret_cast<uintptr_t>(preds) | reinterpret_cast<uintptr_t>(labels)) & 15) == 0));
             return check_hip(hipGetLastError(), who);
         };
         // the Evaluator's calls: one metric (ndcg_at_k(s), nerr_at_k, ap_at_k, p_at_k) or all four (adhoc_performance_at_ks)

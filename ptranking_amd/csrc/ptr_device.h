@@ -660,16 +660,17 @@ __device__ __forceinline__ bool sort_scores_packed(float *raw, int n, int t, con
     return !__any(still);
 }
 
-// 16-byte global loads of a row into the blocked layout (row base 16-byte aligned: L % 4 == 0), scalar loads otherwise; `pad` beyond n
+// 16-byte global loads of a row into the blocked layout (row base 16-byte aligned: L % 4 == 0 and `aligned` = the tensor's base is), scalar
+// loads otherwise; `pad` beyond n
 template <int DPT>
-__device__ __forceinline__ void load_blocked(const float *__restrict__ row, int n, int L, int t, float pad, float (&x)[DPT]) {
-    if (DPT % 4 == 0 && n == kWave * DPT) {                                  // full row (n == L == 64 DPT): no masks
+__device__ __forceinline__ void load_blocked(const float *__restrict__ row, int n, int L, int t, float pad, float (&x)[DPT], bool aligned = true) {
+    if (DPT % 4 == 0 && n == kWave * DPT && aligned) {                                  // full row (n == L == 64 DPT): no masks
 #pragma unroll
         for (int r = 0; r < DPT; r += 4) {
             const float4 u = *reinterpret_cast<const float4 *>(row + t * DPT + r);
             x[r] = u.x; x[r + 1] = u.y; x[r + 2] = u.z; x[r + 3] = u.w;
         }
-    } else if (DPT % 4 == 0 && (L & 3) == 0) {
+    } else if (DPT % 4 == 0 && (L & 3) == 0 && aligned) {
 #pragma unroll
         for (int r = 0; r < DPT; r += 4) {
             const int i = t * DPT + r;

@@ -502,3 +502,22 @@ def test_tie_shuffle_key_paths(F):
                     assert np.all(np.diff(y[b, p1[b, :n]]) <= 0)
                 if L >= 256:
                     assert not np.array_equal(p1, p2)
+
+
+@pytest.mark.parametrize("L", [64, 256, 1024])
+def test_sort_family_on_rows_that_are_not_16_byte_aligned(F, L):
+    """The one-wavefront sort / metric / tie-shuffle paths use 16-byte loads and stores only when the tensors' bases allow it: a view that
+    starts one float into its buffer gives the same results as an aligned copy."""
+    torch.manual_seed(L)
+    B = 7
+    buf_p = torch.randn(B * L + 1, device="cuda"); buf_y = torch.randint(0, 5, (B * L + 1,), device="cuda").float()
+    p_un, y_un = buf_p[1:].view(B, L), buf_y[1:].view(B, L)
+    assert p_un.data_ptr() % 16 != 0 and y_un.data_ptr() % 16 != 0
+    p_al, y_al = p_un.clone(), y_un.clone()
+    ks = [1, 5, 10, 50]
+    for a, b in zip(F.sort_desc(p_un), F.sort_desc(p_al)):
+        assert torch.equal(a, b)
+    ma, mb = F.metrics_at_ks(p_un, y_un, ks, presort=False), F.metrics_at_ks(p_al, y_al, ks, presort=False)
+    for m in ("ndcg", "nerr", "ap", "p"):
+        assert torch.equal(ma[m], mb[m]), m
+    assert torch.equal(F.shuffle_ties_order(y_un, seed=3), F.shuffle_ties_order(y_al, seed=3))
