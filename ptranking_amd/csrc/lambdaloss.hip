@@ -223,10 +223,8 @@ lambdaloss_kernel(const float *__restrict__ preds, const float *__restrict__ lab
 // documents ordered, so a selection round is one DPP max ladder, a ballot and a pop in the winning lane (the lowest lane among equal
 // heads holds the lowest index); the pair body runs on the transcendental pipe while every pair of the query has |sigma ds| <= 80 (the
 // RankNet kernel's policy: pairwise.hip), the library functions otherwise.
-// (up to 256 documents: at least 7 wavefronts per SIMD — 72 registers instead of the 92 the allocator takes when left alone, a handful of
-// per-wavefront constants in scratch: 58.0 -> 56.5 us at 65 536 x 256; 8 wavefronts spill into the selection rounds: 66 us)
 template <int V>
-__global__ void __launch_bounds__(kBlock, V == 1 ? 7 : 1)
+__global__ void __launch_bounds__(kBlock)
 lambdaloss_topk_kernel(const float *__restrict__ preds, const float *__restrict__ labels, const int32_t *__restrict__ lens, int B, int L,
                        int k, float sigma, float mu, int loss_type, float *__restrict__ loss_q, float *__restrict__ grad) {
     constexpr int E = 4 * V;

@@ -1,5 +1,4 @@
+#!/bin/bash
 cd /root/repo
-for v in "" ll_w6 ll_w7 ll_w8; do
-  if [ -n "$v" ]; then export PTR_LIB=$PWD/ptranking_amd/libptranking_amd.$v.so; else unset PTR_LIB; fi
-  echo "== ${v:-product}"; bash scratch/r5_kprof.sh 2>&1 | grep "lambdaloss_topk"
-done
+timeout 900 python -m pytest tests/test_parity_gpu.py tests/test_sort_gpu.py tests/test_siblings_gpu.py -q -m gpu -x 2>&1 | tail -3
+python scratch/r5_small.py 2>&1 | grep -v amdgpu
