@@ -39,27 +39,18 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-MFMA_F32_PEAK_TFLOPS = 157.3      # dense fp32-input MFMA peak = fp32 vector peak (same guide)
-BF16X6_PEAK_TFLOPS = 2500.0 / 6   # effective fp32 peak of the bf16x6 formulation: dense bf16 MFMA peak (same guide) / six products per fp32 product
+from ptranking_amd.peaks import (HBM_PEAK_GBPS, MFMA_F32_PEAK_TFLOPS, BF16X6_PEAK_TFLOPS, NUM_SIMD, PEAK_CLOCK_HZ,   # noqa: E402 — ONE set of
+                                 VALU_CYCLES_PER_INSTR, TRANS_CYCLES_PER_INSTR, RING_MIN_FMA_OPS_PER_PAIR, RING_TRANS_PER_PAIR,
+                                 RING_MIN_ISSUE_CYCLES_PER_PAIR, RING_PAIR_PEAK_PER_S)    # hardware constants, shared with profiles/prof_kernels.py
 MSLR_P = [0.5147, 0.3250, 0.1339, 0.0183, 0.0081]   # label histogram of MSLR-WEB30K
 SEED = 137                        # ptranking/ltr_global.py:7
 EVENT_EVERY = 4                   # per-kernel HIP-event brackets on every 4th step of the timed region
-NUM_SIMD = 256 * 4                # 256 CUs x 4 SIMDs
-PEAK_CLOCK_HZ = 2.4e9
 # pair-loop VALU instructions per pair evaluation of lambdarank_ring_kernel<DPT> read off the gfx950 ISA, 3 of them
-# transcendental (v_exp/v_rcp/v_log).  A wave64 VALU instruction (packed or not) occupies its SIMD for 4 cycles, a transcendental
-# for 8: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4.6 cycles for the kernel's mix (profiles/r02_sq_c2.txt)
+# transcendental (v_exp/v_rcp/v_log).  Issue cycles come from ptranking_amd/peaks.py (the guide's constants: 2 cycles per plain wave64
+# VALU instruction, 8 per transcendental) — r5 priced a plain instruction at 4 here and at 2 in profiles/prof_kernels.py.
+# The kernel's measured mix takes SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4.6 cycles per instruction (profiles/r02_sq_c2.txt: packed fp32
+# and DPP forms issue slower than the 2-cycle constant), which is why the fraction against this bound is low.
 RING_INSTR_PER_PAIR = {1: 25.0, 2: 16.75, 4: 15.5625}
-RING_TRANS_PER_PAIR = 3.0
-VALU_CYCLES_PER_INSTR = 4.0
-TRANS_CYCLES_PER_INSTR = 8.0
-# MINIMAL op count of one LambdaRank pair, independent of our ISA: 3 transcendentals (exp2, rcp, log2) + 16 FMA-class
-# scalar ops — ds, |ds|*c, 1+e, dG, dD, dG*dD, target select (sub, bfi, sub, add), max(log, clamp), loss fma, gradient factor (fract, bfi),
-# two gradient fmas — of which all 16 pack two pairs per v_pk_* instruction: 8 packed + 3 transcendental issue slots per pair.  (Our
-# kernel spends 2 more on a Newton step that reproduces the reference's correctly rounded 1/(1+e), and op_sel / mask overheads.)
-RING_MIN_FMA_OPS_PER_PAIR = 16.0
-RING_MIN_ISSUE_CYCLES_PER_PAIR = RING_MIN_FMA_OPS_PER_PAIR / 2.0 * VALU_CYCLES_PER_INSTR + RING_TRANS_PER_PAIR * TRANS_CYCLES_PER_INSTR   # 56
 
 
 def synth_batch(gen, B, L, F, device):
@@ -575,7 +566,7 @@ def main():
             st = ring_stats.get(Lk, {})
             evaluated = pairs * (1.0 - st.get("blocks_skipped_frac", 0.0))
             cyc_own = (RING_INSTR_PER_PAIR[dpt] - RING_TRANS_PER_PAIR) * VALU_CYCLES_PER_INSTR + RING_TRANS_PER_PAIR * TRANS_CYCLES_PER_INSTR
-            bound = NUM_SIMD * PEAK_CLOCK_HZ * 64.0 / RING_MIN_ISSUE_CYCLES_PER_PAIR
+            bound = RING_PAIR_PEAK_PER_S
             return {"kernel": f"lambdarank_ring_kernel<{dpt}> (fused LambdaRank dNDCG loss + gradient, one wavefront per query, register/DPP ring, "
                               "equal-label slot blocks skipped)",
                     "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
@@ -584,13 +575,13 @@ def main():
                     "effective_pairs_per_s": pairs * (1.0 - st.get("zero_weight_pairs_frac", 0.0)) / (t_ms * 1e-3),
                     "pair_statistics": st,
                     "valu_roofline": {"bound": "valu-issue", "achieved": evaluated / (t_ms * 1e-3), "unit": "evaluated pairs/s", "peak": bound,
-                                      "frac": evaluated / (t_ms * 1e-3) / bound,
+                                      "frac": evaluated / (t_ms * 1e-3) / bound, "frac_all_pairs": pairs / (t_ms * 1e-3) / bound,
                                       "min_fma_class_ops_per_pair": RING_MIN_FMA_OPS_PER_PAIR, "transcendentals_per_pair": RING_TRANS_PER_PAIR,
                                       "cycles_per_wave64_valu_instr": VALU_CYCLES_PER_INSTR, "cycles_per_transcendental": TRANS_CYCLES_PER_INSTR,
                                       "min_issue_cycles_per_pair": RING_MIN_ISSUE_CYCLES_PER_PAIR,
                                       "kernel_issue_cycles_per_pair": cyc_own, "kernel_instr_per_pair": RING_INSTR_PER_PAIR[dpt],
                                       "note": "peak = 1024 SIMDs x 2.4 GHz x 64 lanes / MINIMAL issue cycles per pair: 16 FMA-class ops packed two "
-                                              "pairs per instruction (8 x 4 cycles) + exp2, rcp, log2 (3 x 8 cycles) = 56 — a count of the "
+                                              "pairs per instruction (8 x 2 cycles) + exp2, rcp, log2 (3 x 8 cycles) = 40 — a count of the "
                                               "arithmetic, not of our ISA (our pair loop issues kernel_issue_cycles_per_pair); achieved counts "
                                               "the pairs the kernel EVALUATES (equal-label blocks are skipped, pair_statistics); the shader "
                                               "clock sustained under this kernel is ~2.1 GHz; avg_launch_ms = 40 back-to-back launches inside "
@@ -644,7 +635,9 @@ def main():
                         "formulation": "bf16x6 (fp32 results)" if bwd_x6 else "fp32 MFMA",
                         "bound": "mfma", "achieved": tf, "peak": bwd_peak, "unit": "TFLOP/s (effective fp32)" if bwd_x6 else "TFLOP/s", "frac": tf / bwd_peak,
                         "frac_of_fp32_mfma_peak": tf / MFMA_F32_PEAK_TFLOPS,
-                        "traffic": pmc_bytes("ptr::mlp_bwd_x6_kernel" if bwd_x6 else "ptr::mlp_bwd_fused_kernel"), "avg_launch_ms": t_bwd, "algorithmic_flop_per_launch": bwd_flop,
+                        "traffic": pmc_bytes("ptr::mlp_bwd_x6_kernel" if bwd_x6 else "ptr::mlp_bwd_fused_kernel"),
+                        "traffic_measured_in_run": False,      # PMC passes cannot run inside the timed process: the committed collection of the same kernels (hash-guarded)
+                        "avg_launch_ms": t_bwd, "algorithmic_flop_per_launch": bwd_flop,
                         "algorithmic_bytes_per_launch": R * (4 * F + 4),
                         "design_bytes_per_launch": NL * R * 448 + 256 * 4 * (100 * F + 100 + (NL - 1) * 10100 + 101),
                         "entry_point": "ptr_mlp_backward_step" if bwd_fused_step else "ptr_mlp_backward",

@@ -73,7 +73,7 @@ def run(B):
 # measure here) and two kernels came out ABOVE that "peak" (RankNet 1.18, ListNet 1.04: DPP moves, selects and integer
 # ops issue faster) — a bound below the achieved rate is not a bound.  Against the 2-cycle constant no kernel can
 # exceed 1; transcendental, packed and quarter-rate instructions cost more than 2 cycles, so a real mix saturates well below it.
-VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0
+from ptranking_amd.peaks import VALU_PEAK_GINST, HBM_PEAK_GBPS, VALU_CYCLES_PER_INSTR, TRANS_CYCLES_PER_INSTR, NUM_SIMD, PEAK_CLOCK_HZ, RING_PAIR_PEAK_PER_S, RING_MIN_ISSUE_CYCLES_PER_PAIR   # noqa: E402 — shared with bench.py
 
 
 def summarise(stats_csv, out_json, B, fetch_csv=None, write_csv=None, valu_csv=None):
@@ -110,11 +110,16 @@ def summarise(stats_csv, out_json, B, fetch_csv=None, write_csv=None, valu_csv=N
         gbps = bytes_ / (avg_us * 1e-6) / 1e9
         tr = next((v for k, v in traffic.items() if sub.split("<")[0] in k and (("<" not in sub) or sub in k)), None)
         out["kernels"][label] = {"kernel": r["Name"].split("(")[0], "calls": int(r["Calls"]), "avg_us": avg_us, "queries": Bq, "list_len": L,
-                                 "algorithmic_bytes": bytes_, "achieved_GBps": gbps, "frac_of_hbm_peak": gbps / 8000.0,
+                                 "algorithmic_bytes": bytes_, "achieved_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS,
                                  "traffic_bytes": tr}
         if slot_sum_us is not None and not any(x in label for x in ("metrics", "sort", "shuffle", "approx")):
             e_us = avg_us + slot_sum_us                 # whole entry point = loss kernel + slot sum (ApproxNDCG: its own finish kernel instead)
-            out["kernels"][label]["entry_point"] = {"avg_us": e_us, "achieved_GBps": bytes_ / (e_us * 1e-6) / 1e9, "frac_of_hbm_peak": bytes_ / (e_us * 1e-6) / 1e9 / 8000.0}
+            out["kernels"][label]["entry_point"] = {"avg_us": e_us, "achieved_GBps": bytes_ / (e_us * 1e-6) / 1e9, "frac_of_hbm_peak": bytes_ / (e_us * 1e-6) / 1e9 / HBM_PEAK_GBPS}
+        if label.startswith("lambdarank"):          # the same minimal-op pair bound bench.py's `valu_roofline` uses (ptranking_amd/peaks.py), on ALL L(L-1)/2 pairs
+            pps = Bq * (L * (L - 1) / 2.0) / (avg_us * 1e-6)
+            out["kernels"][label]["pair_roofline"] = {"bound": "valu-issue", "pairs_per_s_all_pairs": pps, "peak": RING_PAIR_PEAK_PER_S, "frac_all_pairs": pps / RING_PAIR_PEAK_PER_S,
+                                                      "min_issue_cycles_per_pair": RING_MIN_ISSUE_CYCLES_PER_PAIR, "cycles_per_wave64_valu_instr": VALU_CYCLES_PER_INSTR,
+                                                      "cycles_per_transcendental": TRANS_CYCLES_PER_INSTR}
         vi = next((v for k, v in valu.items() if sub.split("<")[0] in k and (("<" not in sub) or sub in k)), None)
         if vi:
             ach = vi / (avg_us * 1e-6) / 1e9

@@ -42,6 +42,7 @@ def test_bench_prints_one_contract_json_line():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["traffic_measured_in_run"] is False
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
@@ -67,6 +68,24 @@ def test_bench_prints_one_contract_json_line():
                 else:
                     yield from fracs(v)
     assert all(0.0 <= f <= 1.0 for f in fracs(d)), list(fracs(d))
+
+
+def test_one_set_of_issue_constants():
+    """bench.py and profiles/prof_kernels.py price VALU issue with the SAME constants (ptranking_amd/peaks.py = the guide's 2 cycles per
+    wave64 VALU instruction, 8 per transcendental) — r5 carried 4 cycles in one file and 2 in the other."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    import bench
+    import prof_kernels
+    from ptranking_amd import peaks
+    for name in ("VALU_CYCLES_PER_INSTR", "TRANS_CYCLES_PER_INSTR", "NUM_SIMD", "PEAK_CLOCK_HZ", "HBM_PEAK_GBPS", "RING_PAIR_PEAK_PER_S", "RING_MIN_ISSUE_CYCLES_PER_PAIR"):
+        assert getattr(bench, name) is getattr(peaks, name) or getattr(bench, name) == getattr(peaks, name), name
+        assert getattr(prof_kernels, name) == getattr(peaks, name), name
+    assert peaks.VALU_CYCLES_PER_INSTR == 2.0 and peaks.TRANS_CYCLES_PER_INSTR == 8.0 and peaks.RING_MIN_ISSUE_CYCLES_PER_PAIR == 40.0
+    assert prof_kernels.VALU_PEAK_GINST == peaks.NUM_SIMD * peaks.PEAK_CLOCK_HZ / peaks.VALU_CYCLES_PER_INSTR / 1e9
+    for f in ("bench.py", os.path.join("profiles", "prof_kernels.py")):          # no second definition creeps back in
+        src = open(os.path.join(ROOT, f)).read()
+        assert "VALU_CYCLES_PER_INSTR =" not in src and "TRANS_CYCLES_PER_INSTR =" not in src, f
 
 
 def test_pmc_traffic_is_refused_when_stale(tmp_path, monkeypatch):
