@@ -153,6 +153,8 @@ int ptr_sum_f32(const float *x, int n, float scale, float *out, void *stream);
  * opaque to the caller (ABI v4: TILE-MAJOR [NL][ceil(R / 16)][7][16][16] — every block of 16 rows x 16 of the PTR_MLP_ACT_LD = 112
  * padded features is one contiguous KB, the unit a forward store instruction writes and a backward LDS-DMA piece reads; element
  * (layer, row, col) at layer * ceil16(R) * 112 + (row / 16) * 1792 + (col / 16) * 256 + (row % 16) * 16 + col % 16).
+ * SIZE IT WITH ptr_mlp_acts_floats(R, NL): the forward writes WHOLE 16-row tiles, so a buffer allocated as the pre-v4 [NL][R][112] is up to
+ * 15 rows per layer too small whenever R % 16 != 0 (an out-of-bounds write).
  * ptr_mlp_backward: dpreds [R] -> grad (every entry overwritten); ws (ptr_mlp_backward_ws_floats) and dz (ptr_mlp_backward_dz_floats
  * floats: [NL][R][PTR_MLP_ACT_LD] for the layer-wise kernels, 0 => may be NULL when the single-pass fused backward serves the
  * configuration — NL = 3, F in {132, 136, 140}) are caller-provided scratch; p_drop / seed must be the forward call's.

@@ -501,16 +501,20 @@ __device__ __forceinline__ uint32_t tie_hash(uint32_t qkey, uint32_t i) { return
 // group of equal labels — the distribution arg_shuffle_ties draws from (sampling_utils.py:13-28).
 //
 // r5, lists of up to 1024 documents (one wavefront per query): integer grades in [0, 63] (MultiLabel) are packed with the random field and
-// the document index into ONE 32-bit key   label : 6 | (2^FB - 1 - field) : FB | (N - 1 - index) : IB   (N = 64 DPT padded positions,
-// IB = log2 N, FB = 26 - IB: 18 bits at 256 documents), the keys are sorted in registers by the bitonic network and the permutation is READ
-// OFF the sorted keys' index bits: no rank search, no LDS, 16-byte loads and stores (lane t owns positions 4t .. 4t+3).  Equal fields order
-// by index, as in the counting form.  Other labels (or another wave's query in the same launch) take the exact three-way comparison below.
+// the document index into ONE 32-bit key   label : LB | (2^FB - 1 - field) : FB | (N - 1 - index) : IB   (N = 64 DPT padded positions,
+// IB = log2 N; LB = 3 when every grade of the list is below 8 — the reference's 0..4 — else 6; FB = 32 - LB - IB: 21 bits at 256 documents,
+// 19 at 1024), the keys are sorted in registers by the bitonic network and the permutation is READ OFF the sorted keys' index bits: no rank
+// search, no LDS, 16-byte loads and stores (lane t owns positions 4t .. 4t+3).  r6: two documents of one grade that draw the
+// SAME field would be ordered by index — a small systematic departure from arg_shuffle_ties' uniform order (6-8 pairs per query in a tie
+// group of 1000 documents at the 16 bits r5 left there).  Such keys end up ADJACENT in the sorted order, so one neighbour compare per position
+// finds them, and a list that has any draws its fields again (up to four times; then the exact (label, 32-bit hash, index) comparison below,
+// which other labels — or another wave's query in the same launch — take anyway).
 typedef long i64x2_t __attribute__((ext_vector_type(2)));
 template <int DPT>
 __device__ __forceinline__ bool shuffle_ties_wave(const float *__restrict__ labels, int q, int n, int L, uint32_t qkey, int t,
                                                   int64_t *__restrict__ perm, bool aligned) {
     constexpr int N = kWave * DPT;
-    constexpr int IB = DPT == 1 ? 6 : DPT == 2 ? 7 : DPT == 4 ? 8 : DPT == 8 ? 9 : 10, FB = 26 - IB;
+    constexpr int IB = DPT == 1 ? 6 : DPT == 2 ? 7 : DPT == 4 ? 8 : DPT == 8 ? 9 : 10;
     const float *row = labels + (size_t)q * L;
     const bool vec = DPT % 4 == 0 && (L & 3) == 0 && aligned;
     float y[DPT];
@@ -526,18 +530,42 @@ __device__ __forceinline__ bool shuffle_ties_wave(const float *__restrict__ labe
 #pragma unroll
         for (int r = 0; r < DPT; ++r) y[r] = t * DPT + r < n ? row[t * DPT + r] : 0.0f;
     }
-    uint32_t key[DPT];
-    bool small_int = true;
+    bool small_int = true, below8 = true;
 #pragma unroll
     for (int r = 0; r < DPT; ++r) {
-        const int i = t * DPT + r;
-        const bool in = i < n;
+        const bool in = t * DPT + r < n;
         small_int &= !in || (y[r] >= 0.0f && y[r] < 64.0f && y[r] == floorf(y[r]));
-        const uint32_t field = tie_hash(qkey, (uint32_t)i) >> (32 - FB);
-        key[r] = in ? ((uint32_t)y[r] << (FB + IB)) | ((((1u << FB) - 1u) - field) << IB) | (uint32_t)(N - 1 - i) : 0u;
+        below8 &= !in || y[r] < 8.0f;
     }
     if (!__all(small_int)) return false;
-    wave_sort_desc<DPT>(key, t);                               // padded positions (key 0) sort behind every document
+    const int FB = __all(below8) ? 29 - IB : 26 - IB;         // wave-uniform: the shifts below take it from a scalar register
+    const uint32_t fmask = (1u << FB) - 1u;
+    uint32_t key[DPT];
+    // Fields are drawn until no two documents of one grade share one (rejection sampling: the fields are i.i.d., so the order given
+    // "all distinct" is still uniform over every tie group's permutations); 0.3 % of 1024-document lists with a 500-document tie group
+    // exhaust the four draws and take the exact comparison
+    bool done = false;
+#pragma unroll 1
+    for (uint32_t attempt = 0; attempt < 4u && !done; ++attempt) {
+        const uint32_t akey = qkey + attempt * 0xC2B2AE3Du;
+#pragma unroll
+        for (int r = 0; r < DPT; ++r) {
+            const int i = t * DPT + r;
+            const uint32_t field = tie_hash(akey, (uint32_t)i) >> (32 - FB);
+            key[r] = i < n ? ((uint32_t)y[r] << (FB + IB)) | ((fmask - field) << IB) | (uint32_t)(N - 1 - i) : 0u;
+        }
+        wave_sort_desc<DPT>(key, t);                           // padded positions (key 0) sort behind every document
+        // two documents with one (grade, field) are neighbours now: position p against p + 1 (the next lane's first key for a lane's last one)
+        const uint32_t next_first = (uint32_t)__shfl_down((int)key[0], 1, 64);
+        bool collide = false;
+#pragma unroll
+        for (int r = 0; r < DPT; ++r) {
+            const uint32_t nx = r + 1 < DPT ? key[r + 1] : next_first;
+            collide |= t * DPT + r + 1 < n && ((key[r] ^ nx) >> IB) == 0u;
+        }
+        done = !__any(collide);
+    }
+    if (!done) return false;
     int64_t *orow = perm + (size_t)q * L;
     if (vec) {
 #pragma unroll

@@ -295,12 +295,13 @@ metrics_kernel(const float *__restrict__ preds, const float *__restrict__ labels
         float c_sdcg = 0.f, c_idcg = 0.f, c_rel = 0.f, c_prec = 0.f, c_ideal = 0.f, c_serr = 0.f, c_ierr = 0.f, c_sun = 1.f, c_iun = 1.f;
         const int nchunk = (kmax + 63) >> 6;
         for (int ch = 0; ch < nchunk; ++ch) {
-            // ranks >= kmax (inside the last chunk; r < 64 DPT: inside the rows) are NOT masked: inclusive prefix scans flow from low lanes
-            // to high lanes only, no cut-off reads those lanes, and the chunk carries (lane 63) of the last chunk are never used
+            // ranks in [kmax, n) of the last chunk are NOT masked (inclusive prefix scans flow from low lanes to high lanes only, no cut-off
+            // reads those lanes, the chunk carries of the last chunk are never used); ranks >= n ARE: Y_sys[n ..] is never written on the
+            // counting paths, and whatever bits lie there must not enter gain_fast and the scans (two v_cndmask per chunk)
             const int r = ch * 64 + lane;
             const bool in = true;
             const int rl = G == kWave ? r : (r < Lp ? r : Lp - 1);   // four waves per query: the rows hold round_up(L, 4) entries
-            const float ys = Y_sys[rl], yi = Y_id[rl];
+            const float ys = r < n ? Y_sys[rl] : 0.0f, yi = r < n ? Y_id[rl] : 0.0f;
             const float rdisc = __builtin_amdgcn_rcpf(__builtin_amdgcn_logf((float)r + 2.0f));   // 1 / log2(rank + 2): v_log_f32, v_rcp_f32 (1 ulp each)
             // DCG gain: 2^l - 1 for graded labels, the raw label for LABEL_TYPE.Permutation (adhoc_metric.py:207-212,225-230)
             const float gs = in ? (linear_gain ? ys : gain_fast(ys)) : 0.0f, gi = in ? (linear_gain ? yi : gain_fast(yi)) : 0.0f;

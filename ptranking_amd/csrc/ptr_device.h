@@ -71,15 +71,25 @@ template <class F> inline int dispatch_wave256_tiling(int L, F &&f) {
 // Grid of a PERSISTENT kernel (its wavefronts walk the work with a grid stride): the blocks the device keeps resident at once — CUs x the
 // occupancy of `kernel` at `block` threads and `lds` bytes of dynamic LDS — capped by the blocks the work needs.  Cached per kernel.
 template <class K> inline int persistent_grid(K kernel, int block, size_t lds, int want) {
-    static int resident = 0;                                       // (kernels of one signature share this instantiation: keyed below)
-    static const void *cached_for = nullptr;
-    if (cached_for != reinterpret_cast<const void *>(kernel) || resident <= 0) {
-        int dev = 0, per_cu = 0;
+    // Keyed by (kernel, device, block, lds) and thread_local: kernels of one signature share this instantiation, a process may drive several
+    // GPUs (data parallel) and several host threads (unsynchronised statics raced / reused another device's occupancy)
+    struct Entry { const void *kernel; int dev, block; size_t lds; int resident; };
+    thread_local Entry cache[8] = {};
+    thread_local int next_slot = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const void *kp = reinterpret_cast<const void *>(kernel);
+    int resident = 0;
+    for (const Entry &e : cache)
+        if (e.kernel == kp && e.dev == dev && e.block == block && e.lds == lds && e.resident > 0) { resident = e.resident; break; }
+    if (resident <= 0) {
+        int per_cu = 0;
         hipDeviceProp_t pr;
-        int cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kernel), block, lds) != hipSuccess || per_cu <= 0) per_cu = 4;
+        int cus = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kp, block, lds) != hipSuccess || per_cu <= 0) per_cu = 4;
         resident = cus * per_cu;
-        cached_for = reinterpret_cast<const void *>(kernel);
+        cache[next_slot] = Entry{kp, dev, block, lds, resident};
+        next_slot = (next_slot + 1) % 8;
     }
     static const int mult = [] { const char *e = getenv("PTR_PERSIST_MULT"); return e ? atoi(e) : 1; }();   // 0: one block per unit of work (measurements)
     if (mult <= 0) return want > 0 ? want : 1;

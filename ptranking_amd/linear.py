@@ -96,7 +96,7 @@ def linear(x, weight, bias=None):
     from the reference run where no GPU is (state_dict round trips, the reference's kfold_cv_eval loop on the installed classes in
     tests/test_host_cpu.py, golden-fixture generation).  It is NOT a fallback for the product path: a GPU tensor never takes it, the device
     entry points of _lib refuse CPU tensors, and this branch is an ERROR by default too (r5: strict is the default); the CPU
-    tests that exercise the host plumbing opt out with PTR_STRICT_DEVICE=0 (tests/conftest.py sets it for the `not gpu` suite)."""
+    tests that exercise the host plumbing opt out with PTR_STRICT_DEVICE=0 (tests/conftest.py sets it for the `not gpu` suite and for the `gpu` test modules that declare CPU_REFERENCE_MODULES)."""
     if not x.is_cuda:
         if os.environ.get("PTR_STRICT_DEVICE", "1") != "0":
             raise _lib.NativeLibraryError(f"linear: tensor on {x.device} — the hand-written kernels run on the GPU only "

@@ -101,7 +101,7 @@ class FusedStepMixin:
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0      # same CPU-generator draw as FusedPointScorer.forward
         if p > 0.0:
             seed = dp.local_dropout_seed(seed, R, local_queries=B)
-            dp.end_step()                        # the recorded query slice described this batch only
+        dp.end_step()                            # the recorded query slice described this batch only — with or without dropout (as _fused_step does)
         loss = torch.empty(1, device=dev)
         entry, params = spec
         distributed = self.data_parallel and dp.is_distributed()

@@ -25,11 +25,20 @@ def _deterministic_torch_seed():
 
 
 @pytest.fixture(autouse=True)
-def _tests_opt_out_of_strict_device():
-    """The product default is strict: FusedLinear / FusedStack refuse CPU tensors (ptranking_amd/linear.py).  The test suites opt out: the
-    `not gpu` tests exercise the host-side plumbing on CPU tensors (state_dict round trips, the reference's own kfold loop on the installed
-    classes), and the `gpu` tests build their float64 / fp32 REFERENCE by running the very same module objects on CPU — where a FusedLinear
-    is torch's nn.Linear and executes torch's F.linear, not a kernel of ours.  tests/test_host_cpu.py checks the strict default itself."""
+def _tests_opt_out_of_strict_device(request):
+    """The product default is strict: FusedLinear / FusedStack refuse CPU tensors (ptranking_amd/linear.py).  Only the `not gpu` suite opts
+    out wholesale: it exercises the host-side plumbing on CPU tensors (state_dict round trips, the reference's own kfold loop on the
+    installed classes); tests/test_host_cpu.py checks the strict default itself.  A `gpu` test runs under the product default — a module
+    that accidentally runs on the CPU fails instead of falling through to torch's F.linear — unless its module sets
+    `CPU_REFERENCE_MODULES = True`: those build their float64 / fp32 REFERENCE by running the very same module objects on CPU, where a
+    FusedLinear is torch's nn.Linear and executes torch's F.linear, not a kernel of ours."""
+    is_gpu = request.node.get_closest_marker("gpu") is not None
+    if is_gpu and not getattr(request.module, "CPU_REFERENCE_MODULES", False):
+        prev = os.environ.pop("PTR_STRICT_DEVICE", None)
+        yield
+        if prev is not None:
+            os.environ["PTR_STRICT_DEVICE"] = prev
+        return
     prev = os.environ.get("PTR_STRICT_DEVICE")        # (not monkeypatch: tests that call monkeypatch.undo() mid-way would drop it)
     os.environ["PTR_STRICT_DEVICE"] = "0"
     yield

@@ -325,6 +325,29 @@ def test_tie_shuffle_is_uniform_enough(F):
     assert not np.array_equal(perm, perm2)
 
 
+@pytest.mark.parametrize("L", [256, 1024])
+def test_tie_shuffle_has_no_index_order_bias_in_long_tie_groups(F, L):
+    """two documents of one grade that draw the same random field were ordered by INDEX (r5 left 16 field bits at 513..1024
+    documents: 6-8 such pairs per query in a tie group of 1000).  Such pairs sit next to each other in ascending index order, so they show
+    as an excess of ASCENTS (perm[k] < perm[k+1]) inside the group: a uniform permutation of m items has (m - 1) / 2 ascents with variance
+    (m + 1) / 12.  The kernel now re-draws a list's fields until none collide; the mean ascent count over 512 lists must sit within 4
+    standard errors of (m - 1) / 2 (the 16-bit form was 9 standard errors off at L = 1024)."""
+    B, m = 512, L - 24
+    labels = np.zeros((B, L), np.float32)
+    labels[:, :24] = np.sort(np.random.default_rng(L).integers(1, 5, size=(B, 24)), axis=1)[:, ::-1]
+    perm = F.shuffle_ties_order(dev(labels), seed=77).cpu().numpy()
+    for b in range(0, B, 37):
+        assert sorted(perm[b].tolist()) == list(range(L)) and np.all(np.diff(labels[b, perm[b]]) <= 0)
+    tail = perm[:, 24:]                                            # the grade-0 group: documents 24 .. L-1 in random order
+    assert np.all(tail >= 24)
+    ascents = (np.diff(tail, axis=1) > 0).sum(axis=1).astype(np.float64)
+    stderr = np.sqrt((m + 1) / 12.0 / B)
+    assert abs(ascents.mean() - (m - 1) / 2.0) < 4.0 * stderr, (ascents.mean(), (m - 1) / 2.0, stderr)
+    # first-position uniformity over the group (chi-square-free: 16 equal bins of the index range, 512 draws)
+    bins = np.bincount((tail[:, 0] - 24) * 16 // m, minlength=16)
+    assert bins.min() >= 10 and bins.max() <= 60, bins
+
+
 @pytest.mark.parametrize("B,L", [(6, 5), (32, 128), (9, 333), (4, 1024), (2, 4096)])
 @pytest.mark.parametrize("use_lens", [False, True])
 def test_oracle_metrics_and_sort(F, B, L, use_lens):

@@ -16,6 +16,7 @@ import torch
 import golden_util as G
 
 pytestmark = pytest.mark.gpu
+CPU_REFERENCE_MODULES = True      # tests/conftest.py: this module evaluates build_pointsf() module objects on the CPU as its reference (torch ops, not our kernels)
 
 
 def close(a, b, tol, what):

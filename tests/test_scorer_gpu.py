@@ -7,6 +7,7 @@ import torch
 from ptranking_amd import scorer as _scorer
 
 pytestmark = pytest.mark.gpu
+CPU_REFERENCE_MODULES = True      # tests/conftest.py: this module evaluates build_pointsf() module objects on the CPU as its reference (torch ops, not our kernels)
 
 
 @pytest.fixture(autouse=True, params=["0", "2"], ids=["fp32mfma", "bf16x6"])

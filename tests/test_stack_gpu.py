@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 pytestmark = pytest.mark.gpu
+CPU_REFERENCE_MODULES = True      # tests/conftest.py: this module evaluates build_pointsf() module objects on the CPU as its reference (torch ops, not our kernels)
 
 DEFAULT = dict(num_layers=5, AF='GE', TL_AF='S', apply_tl_af=True, BN=True, bn_type='BN', bn_affine=True)
 

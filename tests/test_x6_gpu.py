@@ -10,6 +10,7 @@ import torch
 from ptranking_amd import scorer as _scorer
 
 pytestmark = pytest.mark.gpu
+CPU_REFERENCE_MODULES = True      # tests/conftest.py: this module evaluates build_pointsf() module objects on the CPU as its reference (torch ops, not our kernels)
 
 
 def _pair(F, NL, seed=0, scale_w=None):
