@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PTR_ABI_VERSION 4
+#define PTR_ABI_VERSION 5
 #define PTR_MAX_LIST_LEN 4096
 #define PTR_MAX_CUTOFFS 32
 #define PTR_MLP_ACT_LD 112
@@ -209,6 +209,43 @@ int ptr_rmsprop_step(float *param, const float *grad, float *square_avg, int64_t
 size_t ptr_mlp_x6_ws_bytes(int F, int NL);
 int ptr_mlp_forward_x6(const float *X, const float *params, int R, int F, int NL, int train, float p_drop, uint64_t seed,
                        float *preds, float *acts, void *wimg, void *stream);
+/* ---- one train step as ONE call (ABI v5, csrc/train_step.hip) ------------------------------------------------------------------------
+ * Replaces ptranking/base/ranker.py:589-603 (`NeuralRanker.train_op`: forward -> custom_loss_function = loss, zero_grad, backward,
+ * optimizer.step) for the pointsf scorer (ptranking/base/point_ranker.py:45-55) with one of the single-kernel losses: the SAME three
+ * entry points a caller would chain — ptr_mlp_forward[_x6] -> ptr_<loss>_fwd_bwd -> ptr_mlp_backward_step — enqueued from C on
+ * `stream`, with the same arguments in the same order, so the parameters after the step are bit-identical to the separate calls.
+ * What it removes is the host work between the launches (three foreign-function calls with ~60 marshalled arguments: the step was
+ * host-bound below ~1024 queries).  The descriptor is caller-owned and may be kept across steps (only seed / step / lr change).
+ *   loss_kind      PTR_LOSS_*; loss_f / loss_i carry that loss's parameters:
+ *                    RANKNET, LAMBDARANK  loss_f[0] = sigma
+ *                    LAMBDALOSS           loss_i[0] = k, loss_i[1] = loss_type (PTR_LAMBDALOSS_*), loss_i[2] = presort; loss_f[0] = sigma, loss_f[1] = mu
+ *                    LISTNET              none
+ *   X [B*L][F], labels [B][L], lens [B] or NULL; params / grad / state1 / state2: the flat buffers of ptr_mlp_backward_step
+ *   scratch        preds [B*L], acts (ptr_mlp_acts_floats), loss_q [B], dpreds [B*L], ws (ptr_mlp_backward_ws_floats), dz
+ *                  (ptr_mlp_backward_dz_floats, NULL when 0), wimg (ptr_mlp_x6_ws_bytes; NULL selects the fp32-MFMA forward)
+ *   loss_out [1]   sum of the per-query losses (written by the backward's reduction launch)
+ * Errors: the first failing stage's code; ptr_last_error() names the stage's entry point. */
+#define PTR_LOSS_RANKNET 1
+#define PTR_LOSS_LAMBDARANK 2
+#define PTR_LOSS_LAMBDALOSS 3
+#define PTR_LOSS_LISTNET 4
+typedef struct ptr_train_step_desc {
+    int32_t struct_bytes;                 /* sizeof(ptr_train_step_desc): a binding built against another layout is refused */
+    int32_t loss_kind;
+    int32_t B, L, F, NL;
+    int32_t opt_kind, step;
+    int32_t loss_i[4];
+    float loss_f[4];
+    float p_drop, lr, hyper1, hyper2, eps, weight_decay;
+    uint64_t seed;
+    const float *X, *labels;
+    const int32_t *lens;
+    float *params, *grad, *state1, *state2;
+    float *preds, *acts, *loss_q, *dpreds, *dz, *ws;
+    void *wimg;
+    float *loss_out;
+} ptr_train_step_desc;
+int ptr_train_step(const ptr_train_step_desc *d, void *stream);
 /* Test helper: the dropout keep-mask (1.0 / 0.0) of dropout site `site` for an [R][n_feat] activation. */
 int ptr_mlp_dropout_mask(int R, int n_feat, int site, float p_drop, uint64_t seed, float *out, void *stream);
 

@@ -11,7 +11,7 @@ import torch  # noqa: F401  — must be imported first so that OUR .so binds to 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PTR_LIB") or os.path.join(_PKG, "libptranking_amd.so")   # PTR_LIB: an experiment build (build.py --variant)
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_LIST_LEN = 4096
 MAX_CUTOFFS = 32
 
@@ -44,6 +44,7 @@ SIGNATURES = {
     "ptr_mlp_backward": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _vp, _vp, _vp, _vp],
     "ptr_mlp_backward_step": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "ptr_opt_step_loss": [_vp, _vp, C.c_int64, _i, _f, _f, _f, _f, _f, _i, _vp, _vp, _vp, _i, _vp, _vp],
+    "ptr_train_step": [_vp, _vp],
     "ptr_mlp_x6_ws_bytes": [_i, _i],
     "ptr_mlp_forward_x6": [_vp, _vp, _i, _i, _i, _i, _f, _u64, _vp, _vp, _vp, _vp],
     "ptr_adam_step": [_vp, _vp, _vp, _vp, C.c_int64, _f, _f, _f, _f, _f, _i, _vp],
@@ -75,6 +76,22 @@ _RESTYPES = {"ptr_last_error": C.c_char_p, "ptr_mlp_num_params": C.c_size_t, "pt
 OPTIONAL = set()
 
 _lib = None
+
+LOSS_KINDS = {"ptr_ranknet_fwd_bwd": 1, "ptr_lambdarank_fwd_bwd": 2, "ptr_lambdaloss_fwd_bwd": 3, "ptr_listnet_fwd_bwd": 4}   # PTR_LOSS_*
+
+
+class TrainStepDesc(C.Structure):
+    """`ptr_train_step_desc` of include/ptranking_amd.h (ABI v5), field for field."""
+    _fields_ = [("struct_bytes", C.c_int32), ("loss_kind", C.c_int32),
+                ("B", C.c_int32), ("L", C.c_int32), ("F", C.c_int32), ("NL", C.c_int32),
+                ("opt_kind", C.c_int32), ("step", C.c_int32),
+                ("loss_i", C.c_int32 * 4), ("loss_f", C.c_float * 4),
+                ("p_drop", C.c_float), ("lr", C.c_float), ("hyper1", C.c_float), ("hyper2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float),
+                ("seed", C.c_uint64),
+                ("X", C.c_void_p), ("labels", C.c_void_p), ("lens", C.c_void_p),
+                ("params", C.c_void_p), ("grad", C.c_void_p), ("state1", C.c_void_p), ("state2", C.c_void_p),
+                ("preds", C.c_void_p), ("acts", C.c_void_p), ("loss_q", C.c_void_p), ("dpreds", C.c_void_p), ("dz", C.c_void_p), ("ws", C.c_void_p),
+                ("wimg", C.c_void_p), ("loss_out", C.c_void_p)]
 
 
 class NativeLibraryError(RuntimeError):

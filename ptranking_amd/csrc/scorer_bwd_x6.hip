@@ -75,8 +75,12 @@ __device__ __forceinline__ void b6_bdma16(b6_srd srd, uint32_t voff, uint32_t so
 // four consecutive features of one document -> the three planes of an image (8 bytes each)
 __device__ __forceinline__ void b6_write4(uint32_t addr, int plane_bytes, const f32x4 v) {
     uint32_t a[3], b[3];
+#ifdef PTR_B6_ABL_NOVALU     // timing-only ablation (wrong results): no splitting
+    a[0] = a[1] = a[2] = __float_as_uint(v[0]); b[0] = b[1] = b[2] = __float_as_uint(v[2]);
+#else
     b6_split2(v[0], v[1], a[0], a[1], a[2]);
     b6_split2(v[2], v[3], b[0], b[1], b[2]);
+#endif
 #pragma unroll
     for (int p = 0; p < 3; ++p) *reinterpret_cast<lds_u32x2_b *>((uintptr_t)(addr + (uint32_t)(p * plane_bytes))) = u32x2{a[p], b[p]};
 }
@@ -108,6 +112,21 @@ __device__ __forceinline__ uint32_t b6_opaque(uint32_t x) { asm volatile("" : "+
 #endif
 #ifndef PTR_B6_STAGE_ORDER
 #define PTR_B6_STAGE_ORDER 0
+#endif
+#ifndef PTR_B6_TAILPRE
+#define PTR_B6_TAILPRE 1              /* r6: the chain's 16-deep tail operands are read beside the last full slice's MFMAs (in the registers the B-fragment prefetch no longer needs) */
+#endif
+#ifndef PTR_B6_CHAIN_ORDER
+#define PTR_B6_CHAIN_ORDER 0
+#endif
+#ifndef PTR_B6_W7_ILV
+#define PTR_B6_W7_ILV 0               /* experiment: wave 7's two tiles of a row as one interleaved stream (no back-to-back MFMAs on one accumulator) */
+#endif
+#ifndef PTR_B6_W7_DEPTH
+#define PTR_B6_W7_DEPTH 2             /* experiment: dZ tiles in flight for wave 7 (2 = one row ahead, 3 = two rows ahead) */
+#endif
+#ifndef PTR_B6_W7HOLD
+#define PTR_B6_W7HOLD 1               /* r6: wave 7 keeps the in-tile fragments its rows share in registers for the phase and streams only the dZ tiles */
 #endif
 #define B6_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16((A).v, (B).v, (C), 0, 0, 0)
 
@@ -213,11 +232,21 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
             f[p].u[0] = l2[0]; f[p].u[1] = l2[1]; f[p].u[2] = h2[0]; f[p].u[3] = h2[1];
         }
     };
-    auto mma6 = [&](f32x4 &c, const BFrag (&af)[3], const BFrag (&bf)[3]) __attribute__((always_inline)) {
+#ifdef PTR_B6_ABL_NOLDS      // timing-only ablation (wrong results): every LDS-sourced MFMA operand is ONE fragment read at kernel start — the operand reads are dead code
+    BFrag ablf[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) { ablf[p].q = *reinterpret_cast<lds_u32x4_b *>((uintptr_t)(lds0 + (uint32_t)(lane * 16 + p * 1024))); asm volatile("" : "+v"(ablf[p].q)); }
+#define B6_LDSOP(x) ablf
+#else
+#define B6_LDSOP(x) x
+#endif
+    auto mma6 = [&](f32x4 &c, const BFrag (&af_)[3], const BFrag (&bf_)[3]) __attribute__((always_inline)) {
+        const BFrag (&af)[3] = B6_LDSOP(af_); const BFrag (&bf)[3] = B6_LDSOP(bf_);
         c = B6_MFMA(af[0], bf[2], c); c = B6_MFMA(af[1], bf[1], c); c = B6_MFMA(af[2], bf[0], c);
         c = B6_MFMA(af[0], bf[1], c); c = B6_MFMA(af[1], bf[0], c); c = B6_MFMA(af[0], bf[0], c);
     };
-    auto mma6w = [&](f32x4 &c, int w0, const BFrag (&bf)[3]) __attribute__((always_inline)) {       // A = the W^T fragment kept in st[w0 .. w0 + 2]
+    auto mma6w = [&](f32x4 &c, int w0, const BFrag (&bf_)[3]) __attribute__((always_inline)) {       // A = the W^T fragment kept in st[w0 .. w0 + 2]
+        const BFrag (&bf)[3] = B6_LDSOP(bf_);
         const bf16x8 a0 = __builtin_bit_cast(bf16x8, st[w0]), a1 = __builtin_bit_cast(bf16x8, st[w0 + 1]), a2 = __builtin_bit_cast(bf16x8, st[w0 + 2]);
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bf[2].v, c, 0, 0, 0); c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bf[1].v, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, bf[0].v, c, 0, 0, 0); c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bf[1].v, c, 0, 0, 0);
@@ -336,7 +365,11 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
     uint32_t m2 = 0u, m1 = 0u;                         // gate bits (activation > 0) of this lane's 2 x 4 elements of layers 2 / 1, per slab
     auto staging = [&](uint32_t zdst, int dt0 = 0, int dt1 = 2) __attribute__((always_inline)) {        // zdst: LDS offset (from lds0) of the dZ buffer that receives dZ3; document tiles dt0 .. dt1 - 1
         if (dt0 == 0) { m2 = 0u; m1 = 0u; }
+#ifdef PTR_B6_ABL_NOSTAGE    // timing-only ablation (wrong results): no staging pass at all
+        if (false) {
+#else
         if (chain) {
+#endif
             const f32x4 wo4 = *reinterpret_cast<lds_f32x4_b *>((uintptr_t)(b6_opaque(lds0 + (uint32_t)(kB6_WO + 64 * W)) + (uint32_t)(16 * g)));
 #pragma unroll
             for (int dt = dt0; dt < dt1; ++dt) {
@@ -374,6 +407,11 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
 #else
 #define B6_STAMP() do { } while (0)
 #endif
+#if defined(PTR_B6_TRACE) && defined(PTR_B6_TRACE2)     // finer stamps inside the phases (12 per slab instead of 7)
+#define B6_STAMP2() B6_STAMP()
+#else
+#define B6_STAMP2() do { } while (0)
+#endif
 #if PTR_B6_PRIO
     if (W >= 4) __builtin_amdgcn_s_setprio(1);      // waves w and w + 4 share a SIMD and the older one wins every arbitration: static priority for the younger half
 #endif
@@ -393,11 +431,20 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
             const uint32_t zin = b6_opaque(lds0 + (c == 0 ? zi : zo)), zout = b6_opaque(lds0 + (c == 0 ? zo : zi) + (uint32_t)(32 * W));
             const uint32_t aim = b6_opaque(lds0 + (c == 0 ? kB6_A2 : kB6_A1));
             if (chain) {
+              auto chain_part = [&]() __attribute__((always_inline)) {
                 f32x4 cc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
                 auto read_b = [&](BFrag (&b)[3], int u) __attribute__((always_inline)) {       // u = 2 s + dt
 #pragma unroll
                     for (int p = 0; p < 3; ++p)
                         b[p].q = *reinterpret_cast<lds_u32x4_b *>((uintptr_t)(zin + rd_b + (uint32_t)(p * kB6ZPL + 16 * (u & 1) * kB6ZRS + 64 * (u >> 1))));
+                };
+                u32x2 bt[2][3];                                   // the 16-deep tail's B operands (features 96 + 4 g .. + 3 of both document tiles)
+                auto read_bt = [&]() __attribute__((always_inline)) {
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                        for (int p = 0; p < 3; ++p)
+                            bt[dt][p] = *reinterpret_cast<lds_u32x2_b *>((uintptr_t)(zin + wr_z + (uint32_t)(192 + p * kB6ZPL + 16 * dt * kB6ZRS)));
                 };
                 if (c != PTR_B6_X_PHASE || PTR_B6_PIPE_C2) {      // the chain phase without X in flight has the registers for a fragment in flight beside the one being multiplied
                     BFrag b[2][3];
@@ -405,6 +452,7 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
 #pragma unroll
                     for (int u = 0; u < 6; ++u) {
                         if (u + 1 < 6) read_b(b[(u + 1) & 1], u + 1);
+                        else if (PTR_B6_TAILPRE) read_bt();      // the last step has no fragment to prefetch: its 12 registers take the tail operands
                         __builtin_amdgcn_sched_barrier(0);
                         mma6w(cc[u & 1], 18 + 3 * (3 * c + (u >> 1)), b[u & 1]);
                         __builtin_amdgcn_sched_barrier(0);
@@ -414,19 +462,18 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
                     for (int u = 0; u < 6; ++u) {
                         BFrag b[3];
                         read_b(b, u);
+                        if (PTR_B6_TAILPRE && u == 5) read_bt();
                         mma6w(cc[u & 1], 18 + 3 * (3 * c + (u >> 1)), b);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+                if (!PTR_B6_TAILPRE) read_bt();
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    u32x2 bt[3];
-#pragma unroll
-                    for (int p = 0; p < 3; ++p)
-                        bt[p] = *reinterpret_cast<lds_u32x2_b *>((uintptr_t)(zin + wr_z + (uint32_t)(192 + p * kB6ZPL + 16 * dt * kB6ZRS)));
-                    mma6t(cc[dt], c, bt);
+                    mma6t(cc[dt], c, bt[dt]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                B6_STAMP2();                                      // chain MFMAs issued
                 const uint32_t m = c == 0 ? m2 : m1;
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
@@ -440,13 +487,60 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
                         b6_write4(zout + wr_z + (uint32_t)(16 * dt * kB6ZRS), kB6ZPL, dz);
                     }
                 }
-                // dW of the layer whose dZ is the chain's INPUT: row w, in-tiles 0..4 of the activations below it
+                B6_STAMP2();                                      // epilogue done (gating, split, image stores issued)
+              };
+              // dW of the layer whose dZ is the chain's INPUT: row w, in-tiles 0..4 of the activations below it
+              auto dw_part = [&]() __attribute__((always_inline)) {
                 if (c == 0) dw_row(std::integral_constant<int, 5>{}, std::bool_constant<PTR_B6_X_PHASE != 0 || PTR_B6_PIPE_C2 != 0>{}, 0, zin, W, aim + tr_z, kB6ZPL, kB6ZRS, 0);
                 else dw_row(std::integral_constant<int, 5>{}, std::bool_constant<PTR_B6_X_PHASE != 1 || PTR_B6_PIPE_C2 != 0>{}, 5, zin, W, aim + tr_z, kB6ZPL, kB6ZRS, 0);
+              };
+#if PTR_B6_CHAIN_ORDER
+              // r6 experiment: the two waves of a SIMD (w, w + 4) run the phase's two independent halves in OPPOSITE order, so that one wave's epilogue
+              // (vector ALU + LDS stores) runs beside the other's matrix instructions instead of beside its epilogue.  One copy of each body: a two-trip loop
+              const bool chain_first = W < 4;
+#pragma unroll 1
+              for (int h = 0; h < 2; ++h) {
+                  if ((h == 0) == chain_first) chain_part(); else dw_part();
+                  __builtin_amdgcn_sched_barrier(0);
+              }
+#else
+              chain_part();
+              dw_part();
+#endif
             } else {
+                B6_STAMP2(); B6_STAMP2();
+#if PTR_B6_W7HOLD
+                // wave 7: in-tiles 5, 6 of every row.  r6: the two activation fragments are the SAME for all seven rows — read once per phase
+                // (r5: seven times: 126 transpose reads per phase, now 54), only the dZ tile of the row streams, one row ahead of its MFMAs
+                constexpr int ZD = PTR_B6_W7_DEPTH;
+                BFrag ab5[3], ab6[3], zr[ZD][3];
+                read_tr(zr[0], zin + tr_z, kB6ZPL, kB6ZRS, 0);
+                read_tr(ab5, aim + tr_z, kB6ZPL, kB6ZRS, 5);
+                read_tr(ab6, aim + tr_z, kB6ZPL, kB6ZRS, 6);
+                if (ZD == 3) read_tr(zr[1], zin + tr_z + 32u, kB6ZPL, kB6ZRS, 0);
+#pragma unroll
+                for (int mo = 0; mo < 7; ++mo) {
+                    if (mo + ZD - 1 < 7) read_tr(zr[(mo + ZD - 1) % ZD], zin + tr_z + (uint32_t)(32 * (mo + ZD - 1)), kB6ZPL, kB6ZRS, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#if PTR_B6_W7_ILV
+                    {
+                        f32x4 &c0 = st[14 * c + 2 * mo], &c1 = st[14 * c + 2 * mo + 1];
+                        const BFrag (&af)[3] = zr[mo % ZD];
+                        c0 = B6_MFMA(af[0], ab5[2], c0); c1 = B6_MFMA(af[0], ab6[2], c1); c0 = B6_MFMA(af[1], ab5[1], c0); c1 = B6_MFMA(af[1], ab6[1], c1);
+                        c0 = B6_MFMA(af[2], ab5[0], c0); c1 = B6_MFMA(af[2], ab6[0], c1); c0 = B6_MFMA(af[0], ab5[1], c0); c1 = B6_MFMA(af[0], ab6[1], c1);
+                        c0 = B6_MFMA(af[1], ab5[0], c0); c1 = B6_MFMA(af[1], ab6[0], c1); c0 = B6_MFMA(af[0], ab5[0], c0); c1 = B6_MFMA(af[0], ab6[0], c1);
+                    }
+#else
+                    mma6(st[14 * c + 2 * mo], zr[mo % ZD], ab5);
+                    mma6(st[14 * c + 2 * mo + 1], zr[mo % ZD], ab6);
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#else
 #pragma unroll
                 for (int mo = 0; mo < 7; ++mo)       // wave 7: in-tiles 5, 6 of every row
                     dw_row(std::integral_constant<int, 2>{}, std::bool_constant<PTR_B6_PIPE_W7 != 0>{}, 14 * c + 2 * mo, zin, mo, aim + tr_z, kB6ZPL, kB6ZRS, 5);
+#endif
             }
             if constexpr (!TAIL) { if (c == PTR_B6_X_PHASE) stage_x(slab); }     // the XI image (read by dW_1 only: free since the last B4)
             // (the DMA goes BEHIND the X staging: hipcc's waitcnt for the X registers does not count the asm DMA, a wait placed behind it would
@@ -473,8 +567,21 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
                 if (chain) {
                     dw_row(std::integral_constant<int, 8>{}, std::true_type{}, 10, za, W, xi, kB6XPL, kB6XRS, 0);
                 } else {
+#if PTR_B6_W7HOLD
+                    BFrag xb[3], zr[2][3];                        // wave 7: in-tile 8 of X for every row — one fragment for the phase, the dZ tiles stream
+                    read_tr(zr[0], za + tr_z, kB6ZPL, kB6ZRS, 0);
+                    read_tr(xb, xi, kB6XPL, kB6XRS, 8);
+#pragma unroll
+                    for (int mo = 0; mo < 7; ++mo) {
+                        if (mo + 1 < 7) read_tr(zr[(mo + 1) & 1], za + tr_z + (uint32_t)(32 * (mo + 1)), kB6ZPL, kB6ZRS, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mma6(st[28 + mo], zr[mo & 1], xb);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#else
 #pragma unroll
                     for (int mo = 0; mo < 7; ++mo) dw_row(std::integral_constant<int, 1>{}, std::false_type{}, 28 + mo, za, mo, xi, kB6XPL, kB6XRS, 8);
+#endif
                 }
             };
 #if PTR_B6_STAGE_ORDER == 4
@@ -501,6 +608,7 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
 #elif PTR_B6_STAGE_ORDER == 0
             if (more) staging(zo);
             __builtin_amdgcn_sched_barrier(0);
+            B6_STAMP2();                                          // staging pass done
             dw1();
 #elif PTR_B6_STAGE_ORDER == 1
             dw1();

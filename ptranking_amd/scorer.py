@@ -107,12 +107,19 @@ def x6_workspace(dev, F, NL):
     return ws
 
 
-def mlp_forward(X2d, flat, R, F, NL, train, p, seed, preds, acts, dev):
-    """Scorer forward through the C ABI: the bf16x6 entry point when it serves (F, NL), the fp32-MFMA one otherwise."""
+def x6_wimg_for(X2d, R, F, NL, train, dev):
+    """The weight-image scratch when the bf16x6 forward serves this call (PTR_MLP_X6 mode, row threshold, run-time limits), else None (= the
+    fp32-MFMA forward).  The one place that makes the choice: mlp_forward and the single-call train step (ptr_train_step) both ask here."""
     mode = x6_mode()
     ws = x6_workspace(dev, F, NL) if (mode == "2" or (mode != "0" and R >= X6_MIN_ROWS)) else None
     if ws is not None and not x6_serves(X2d, R, F, NL, train):
         ws = None                            # the fp32-MFMA entry point serves what the bf16x6 one refuses (4 GB buffer resources, alignment)
+    return ws
+
+
+def mlp_forward(X2d, flat, R, F, NL, train, p, seed, preds, acts, dev):
+    """Scorer forward through the C ABI: the bf16x6 entry point when it serves (F, NL), the fp32-MFMA one otherwise."""
+    ws = x6_wimg_for(X2d, R, F, NL, train, dev)
     if ws is not None:
         _lib.call("ptr_mlp_forward_x6", _lib.ptr(X2d), _lib.ptr(flat), R, F, NL, int(train), C.c_float(p), C.c_uint64(seed),
                   _lib.ptr(preds), _lib.ptr(acts), _lib.ptr(ws), _lib.current_stream(dev))

@@ -21,6 +21,8 @@ torch.cuda.synchronize()
 NP = _lib.query("ptr_mlp_num_params", F, NL)
 tr = ws[256 * NP:256 * NP + 8 * 512].cpu().numpy().view(np.uint64).reshape(8, 256).astype(np.int64)
 names = ["chain3+dW3", "B2 wait", "chain2+dW2+X", "B3 wait", "dW1+staging(next)", "B4 wait", "prefetch issue"]
+if os.environ.get("TRACE2"):      # -DPTR_B6_TRACE2 builds: 12 stamps per slab
+    names = ["c3 chain MFMAs", "c3 epilogue", "c3 dW3 (+prefetch issue)", "B2 wait", "c2 chain MFMAs", "c2 epilogue", "c2 dW2+X stage", "B3 wait", "staging(next)", "dW1", "B4 wait", "loop"]
 NS = len(names)
 for w in (0, 3, 4, 7):
     t = tr[w]

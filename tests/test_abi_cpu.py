@@ -114,6 +114,27 @@ def test_opt_step_loss_validates_without_a_gpu():
     assert lib.ptr_opt_step_loss(one, one, ctypes.c_int64(0), 1, f(1e-3), f(0.9), f(0.999), f(1e-8), f(0.0), 1, one, one, None, 0, None, None) == 0
 
 
+def test_train_step_descriptor_layout_and_validation_without_a_gpu():
+    """ABI v5: `ptr_train_step` takes ONE descriptor; the ctypes mirror has the header's size, and a descriptor of another size, an unknown
+    loss or missing scratch is refused before any launch."""
+    from ptranking_amd import _lib
+    lib = _lib.load()
+    hdr = open(HEADER).read()
+    body = re.search(r"typedef struct ptr_train_step_desc \{(.*?)\} ptr_train_step_desc;", hdr, flags=re.S).group(1)
+    names = re.findall(r"[\s\*,]([A-Za-z_0-9]+)(?:\[4\])?\s*(?=[,;])", re.sub(r"/\*.*?\*/", "", body))
+    assert names == [f[0] for f in _lib.TrainStepDesc._fields_], names          # same fields, same order
+    assert ctypes.sizeof(_lib.TrainStepDesc) == 216
+    d = _lib.TrainStepDesc()
+    assert lib.ptr_train_step(None, None) == 1001
+    d.struct_bytes = 8
+    assert lib.ptr_train_step(ctypes.addressof(d), None) == 1001 and b"descriptor of 8 bytes" in lib.ptr_last_error()
+    d.struct_bytes = ctypes.sizeof(_lib.TrainStepDesc)
+    d.B, d.L, d.loss_kind = 2, 8, 0
+    assert lib.ptr_train_step(ctypes.addressof(d), None) == 1001 and b"unknown loss" in lib.ptr_last_error()
+    d.loss_kind = 2
+    assert lib.ptr_train_step(ctypes.addressof(d), None) == 1001 and b"NULL scratch" in lib.ptr_last_error()
+
+
 def test_product_path_fails_loudly_on_cpu_tensors():
     import ptranking_amd as pa
     p, y = torch.zeros(2, 8), torch.zeros(2, 8)

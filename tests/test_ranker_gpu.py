@@ -213,17 +213,21 @@ def test_direct_train_step_is_bit_identical_to_the_autograd_path(name, paras, dr
         return r
 
     a, b = make(True), make(False)
+    a3 = make(True)
+    a3.single_call_step = False                                  # r6: `a` takes ONE C-ABI call per step (ptr_train_step), `a3` the three calls it chains
+    assert a.single_call_step is True
     X, Y = make_data(5, 9, 70, 136)
     X, Y = X.cuda(), Y.cuda()
     lens = torch.tensor([70, 3, 70, 1, 55, 70, 64, 65, 2], dtype=torch.int32, device="cuda")
     for step, kw in enumerate([{}, {}, {"lens": lens}, {}]):
         out = []
-        for r in (a, b):
+        for r in (a, b, a3):
             torch.manual_seed(100 + step)                       # the dropout seed is drawn from torch's CPU generator
             out.append(r.train_op(X, Y, epoch_k=1 if step else 10, presort=True, label_type=pa.LABEL_TYPE.MultiLabel, **kw))
-        (la, sa), (lb, sb) = out
-        assert sa == sb and torch.equal(la.reshape(()), lb.reshape(())), (step, la, lb)
-        assert torch.equal(a.point_sf.flat, b.point_sf.flat), step
+        (la, sa), (lb, sb), (l3, s3) = out
+        assert sa == sb == s3 and torch.equal(la.reshape(()), lb.reshape(())) and torch.equal(la.reshape(()), l3.reshape(())), (step, la, lb, l3)
+        assert torch.equal(a.point_sf.flat, b.point_sf.flat) and torch.equal(a.point_sf.flat, a3.point_sf.flat), step
+    assert "desc" in next(iter(a._direct_buffers.values())) and "desc" not in next(iter(a3._direct_buffers.values()))
     sta, stb = a.optimizer.state[a.point_sf.flat], b.optimizer.state[b.point_sf.flat]
     assert sta["step"] == stb["step"] == 4 and torch.equal(sta["exp_avg_sq"], stb["exp_avg_sq"])
     assert "_direct_buffers" in a.__dict__ and "_direct_buffers" not in b.__dict__
@@ -239,3 +243,46 @@ def test_direct_train_step_is_bit_identical_to_the_autograd_path(name, paras, dr
     c.init(); c.train_mode()
     c.train_op(X, Y, epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
     assert getattr(c, "seen", False) and "_direct_buffers" not in c.__dict__
+
+
+@pytest.mark.parametrize("x6", ["0", "2"])
+def test_single_call_step_matches_the_three_calls_under_either_forward(x6, monkeypatch):
+    """ptr_train_step (ABI v5) with the fp32-MFMA forward (wimg = NULL) and with the bf16x6 forward (PTR_MLP_X6=2 forces it at any row
+    count): bit-identical parameters, optimiser state and loss to the three separate entry points, over several steps with dropout."""
+    import ptranking_amd as pa
+    monkeypatch.setenv("PTR_MLP_X6", x6)
+    sf = copy.deepcopy(SF)
+    sf["pointsf"].update(num_features=136, dropout=0.1)
+
+    def make(single):
+        torch.manual_seed(12)
+        r = pa.LambdaRank(sf_para_dict=copy.deepcopy(sf), model_para_dict=dict(sigma=1.0), gpu=True, device="cuda:0")
+        r.init(); r.point_sf.dropout = 0.1; r.train_mode()
+        r.single_call_step = single
+        return r
+
+    a, b = make(True), make(False)
+    X, Y = make_data(6, 33, 128, 136)
+    X, Y = X.cuda(), Y.cuda()
+    for step in range(3):
+        out = []
+        for r in (a, b):
+            torch.manual_seed(200 + step)
+            out.append(r.train_op(X, Y, epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel))
+        assert torch.equal(out[0][0], out[1][0]) and torch.equal(a.point_sf.flat, b.point_sf.flat), step
+    d = next(iter(a._direct_buffers.values()))["desc"]
+    assert (d.wimg is not None) == (x6 == "2")
+
+
+def test_train_step_descriptor_is_checked():
+    """ptr_train_step refuses a descriptor of another size / an unknown loss before any launch."""
+    import ctypes as C
+    from ptranking_amd import _lib
+    d = _lib.TrainStepDesc()
+    d.struct_bytes = C.sizeof(_lib.TrainStepDesc) - 8
+    with pytest.raises(RuntimeError, match="descriptor of"):
+        _lib.call("ptr_train_step", C.addressof(d), None)
+    d.struct_bytes = C.sizeof(_lib.TrainStepDesc)
+    d.B, d.L, d.loss_kind = 1, 8, 9
+    with pytest.raises(RuntimeError, match="unknown loss"):
+        _lib.call("ptr_train_step", C.addressof(d), None)
