@@ -21,9 +21,11 @@ KS = [1, 3, 5, 10, 20, 50]
 ITERS = 6
 # (label, kernel-name substring, list length, algorithmic bytes per query)
 CASES = [
-    ("ranknet L=32", "pairwise_bce_kernel", 32, lambda L: 12 * L + 4),
+    ("ranknet L=32", "pairwise_bce_kernel<32, 1, false>", 32, lambda L: 12 * L + 4),
     ("lambdarank L=128", "lambdarank_ring_kernel<2>", 128, lambda L: 12 * L + 4),
     ("lambdarank L=256", "lambdarank_ring_kernel<4>", 256, lambda L: 12 * L + 4),
+    ("lambdarank L=512", "lambdarank_ring_kernel<8>", 512, lambda L: 12 * L + 4),            # r6: the ring form up to 512 documents
+    ("lambdarank L=1024", "pairwise_bce_kernel<64, 16, true>", 1024, lambda L: 12 * L + 4),  # above: the LDS kernel (MSLR-WEB30K lists run to 1 251 documents)
     ("listnet L=256", "listnet_vec_kernel", 256, lambda L: 12 * L + 4),
     ("listmle L=256", "listmle_vec_kernel", 256, lambda L: 16 * L + 4),
     ("lambdaloss L=256 k=5", "lambdaloss_", 256, lambda L: 12 * L + 4),
@@ -34,6 +36,11 @@ CASES = [
 ]
 
 
+def queries_at(B, L):
+    """Queries per launch at list length L: B up to 256 documents, B / 2 up to 512, B / 4 above (the O(L^2) kernels)."""
+    return B if L <= 256 else B // 2 if L <= 512 else B // 4
+
+
 def run(B):
     import torch
     import ptranking_amd as pa
@@ -41,8 +48,8 @@ def run(B):
     torch.manual_seed(137)
     probs = torch.tensor([0.5147, 0.3250, 0.1339, 0.0183, 0.0081], device="cuda")
     data = {}
-    for L in (32, 128, 256, 512):
-        Bq = B if L <= 256 else B // 2
+    for L in (32, 128, 256, 512, 1024):
+        Bq = queries_at(B, L)
         preds = torch.randn(Bq, L, device="cuda")
         Y = torch.multinomial(probs.expand(Bq, -1), L, replacement=True).float()
         Y[:, 0].clamp_(min=1.0)
@@ -65,6 +72,8 @@ def run(B):
         F.metrics_at_ks(p, y, KS, presort=True)
         F.sort_desc(p)
         p, y = data[512]; lg(F.approxndcg_loss, p, y, alpha=10.0, presort=True)
+        lg(F.lambdarank_loss, p, y, sigma=1.0)
+        p, y = data[1024]; lg(F.lambdarank_loss, p, y, sigma=1.0)
     torch.cuda.synchronize()
 
 
@@ -100,7 +109,7 @@ def summarise(stats_csv, out_json, B, fetch_csv=None, write_csv=None, valu_csv=N
     slot_sum = [r for r in rows if "sum_f32_kernel" in r["Name"]]
     slot_sum_us = float(slot_sum[0]["AverageNs"]) / 1e3 if slot_sum else None      # the loss-slot sum every *_fwd_bwd entry point ends with
     for label, sub, L, bytes_per_q in CASES:
-        Bq = B if L <= 256 else B // 2
+        Bq = queries_at(B, L)
         match = [r for r in rows if sub in r["Name"] and "ptr::" in r["Name"]]
         if not match:
             continue

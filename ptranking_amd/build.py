@@ -15,10 +15,17 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 OBJ_DIR = os.path.join(PKG_DIR, "csrc", "build")
 LIB_PATH = os.path.join(PKG_DIR, "libptranking_amd.so")
 ARCH = "gfx950"
-SOURCES = ["abi.hip", "pairwise.hip", "lambdaloss.hip", "approxndcg.hip", "listwise.hip", "metrics.hip", "scorer.hip", "scorer_bwd.hip", "scorer_x6.hip", "scorer_bwd_x6.hip", "scorer_dw_x6.hip", "linear.hip", "linear_bw_x6.hip", "bnact.hip", "listsf.hip", "train_step.hip", "letor.cpp"]
-HEADERS = ["ptr_device.h", "ptr_dropout.h", "ptr_mlp.h", os.path.join("..", "..", "include", "ptranking_amd.h")]
+SOURCES = ["abi.hip", "pairwise.hip", "pairwise_ring.hip", "lambdaloss.hip", "approxndcg.hip", "listwise.hip", "metrics.hip", "scorer.hip", "scorer_bwd.hip", "scorer_x6.hip", "scorer_bwd_x6.hip", "scorer_dw_x6.hip", "linear.hip", "linear_bw_x6.hip", "bnact.hip", "listsf.hip", "train_step.hip", "letor.cpp"]
+HEADERS = ["ptr_device.h", "ptr_dropout.h", "ptr_mlp.h", "ptr_ring.h", os.path.join("..", "..", "include", "ptranking_amd.h")]
 CXXFLAGS = ["-O3", "-std=c++20", "-fPIC", "-fno-gpu-rdc", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
             "-ffp-contract=off"]
+
+
+# per-source flags.  r6 measured `-mllvm -amdgpu-sched-strategy=max-ilp` on the LambdaRank ring kernel (csrc/pairwise_ring.hip): the ILP strategy removes
+# the 59 s_nop wait states per ring step the default strategy leaves behind the transcendentals (562 -> 501 issue slots per 32 pair evaluations at 256
+# documents) but needs 208 instead of 150 registers — two waves per SIMD instead of three — and the kernel got SLOWER (92.9 -> 101.7 us at 4096 x 256);
+# capped at three waves per SIMD it emits 140 wait states.  Not used; the hook stays for the next such experiment.
+EXTRA_FLAGS = {}
 
 
 def _hipcc():
@@ -47,7 +54,7 @@ def build_variant(tag, defines, sources=("scorer_bwd.hip",), verbose=False):
         obj = os.path.join(OBJ_DIR, os.path.splitext(s)[0] + ".o")
         if s in sources:
             obj = os.path.join(vdir, os.path.splitext(s)[0] + ".o")
-            cmd = [hipcc] + CXXFLAGS + [d if d.startswith("-") else f"-D{d}" for d in defines] + ["-c", os.path.join(CSRC, s), "-o", obj]
+            cmd = [hipcc] + CXXFLAGS + EXTRA_FLAGS.get(s, []) + [d if d.startswith("-") else f"-D{d}" for d in defines] + ["-c", os.path.join(CSRC, s), "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
@@ -72,7 +79,7 @@ def build(force=False, verbose=False):
         if force or _stale(obj, [src] + hdrs):
             flags = CXXFLAGS if s.endswith(".hip") else [f for f in CXXFLAGS if not f.startswith("--offload-arch")
                                                               and f != "-fno-gpu-rdc"] + ["-pthread"]
-            jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + flags + EXTRA_FLAGS.get(s, []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

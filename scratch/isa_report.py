@@ -15,9 +15,13 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++20", "-fno-gpu-rdc", "--offload-arch=gfx950", "-ffp-contract=off", "-I" + CSRC, "-I" + os.path.join(ROOT, "include")]
 
 
+sys.path.insert(0, ROOT)
+from ptranking_amd.build import EXTRA_FLAGS       # per-source flags of the product build (e.g. the ring kernel's scheduling strategy)
+
+
 def asm(src):
     out = tempfile.NamedTemporaryFile(suffix=".s", delete=False).name
-    subprocess.run([HIPCC, *FLAGS, "-S", "--cuda-device-only", src, "-o", out], check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([HIPCC, *FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), "-S", "--cuda-device-only", src, "-o", out], check=True, stderr=subprocess.DEVNULL)
     text = open(out).read()
     os.unlink(out)
     return text
@@ -83,7 +87,7 @@ def blocks(f, pat):
 
 def regs(files):
     for f in files:
-        r = subprocess.run([HIPCC, *FLAGS, "-c", f, "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+        r = subprocess.run([HIPCC, *FLAGS, *EXTRA_FLAGS.get(os.path.basename(f), []), "-c", f, "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
         name, row = None, {}
         for l in r.stderr.splitlines():
             m = re.search(r"Function Name: (\S+)", l)

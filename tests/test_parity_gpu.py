@@ -209,7 +209,7 @@ def test_oracle_pairwise(F, B, L, use_lens):
         G.assert_close(grad, g, f"{name} grad")
 
 
-@pytest.mark.parametrize("L", [40, 128, 200, 256])
+@pytest.mark.parametrize("L", [40, 128, 200, 256, 300, 512])
 @pytest.mark.parametrize("case", ["huge", "tiny", "all_tied", "some_tied", "mixed_scale"])
 def test_ring_rank_count_fallback(F, L, case):
     """The ring kernel counts ranks with one packed fma-with-clamp per two compares (exact unless BIG*s overflows or a score
@@ -238,6 +238,30 @@ def test_ring_rank_count_fallback(F, L, case):
     lq, g = CO.lambdarank(preds, labels, sigma, lens=ln)
     G.assert_close(loss, lq.astype(np.float64).sum(), f"lambdarank loss {case}")
     G.assert_close(grad, g, f"lambdarank grad {case}")
+
+
+@pytest.mark.parametrize("L", [128, 256, 384, 512])
+def test_ring_kernel_equal_label_slot_skipping(F, L):
+    """The ring kernel skips the (own slot, travelling slot) blocks among the trailing 64-document slots whose documents all carry ONE label
+    (r3; r6: lists of up to 512 documents, Z rounded down to an even slot count there): every head length — from one relevant document to
+    none irrelevant — must give the oracle's loss and gradients, with and without padding."""
+    from oracle import c_oracle as CO
+    rng = np.random.default_rng(L)
+    heads = sorted(set([1, 2, 63, 64, 65, 127, 128, 129, L // 2, L - 65, L - 64, L - 1, L]) & set(range(1, L + 1)))
+    B = len(heads)
+    labels = np.zeros((B, L), np.float32)
+    for b, h in enumerate(heads):
+        labels[b, :h] = np.sort(rng.integers(1, 5, size=h))[::-1]
+    preds = rng.standard_normal((B, L)).astype(np.float32)
+    for ln in (None, np.array([max(1, L - 7 * (b % 5)) for b in range(B)], np.int32)):
+        loss, grad = loss_and_grad(F.lambdarank_loss, preds, dev(labels), sigma=1.0, lens=None if ln is None else dev(ln))
+        lq, g = CO.lambdarank(preds, labels, 1.0, lens=ln)
+        G.assert_close(loss, lq.astype(np.float64).sum(), "lambdarank loss")
+        G.assert_close(grad, g, "lambdarank grad")
+    # one grade everywhere (all slots pure): loss and gradients exactly 0
+    same = np.full((3, L), 2.0, np.float32)
+    loss, grad = loss_and_grad(F.lambdarank_loss, preds[:3], dev(same), sigma=1.0)
+    assert float(loss) == 0.0 and not np.any(grad)
 
 
 @pytest.mark.parametrize("B,L", [(5, 7), (16, 128), (9, 256), (4, 512), (2, 1030)])
