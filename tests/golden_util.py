@@ -11,9 +11,12 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # magnitude <= 1, relative 1e-5 above that (fp32 summation order alone moves a sum of ~1e4 terms by ~1e-6 rel).
 RTOL = 1e-5
 ATOL = 1e-5
-# second, ELEMENT-WISE gate: an entry far below the row maximum must still be right to 1e-4 relative (or 1e-6 of the maximum,
-# whichever is larger) — the max-norm rule alone would let a gradient element 1000x smaller than the maximum be 100 % wrong
-EL_RTOL = 1e-4
+# second, ELEMENT-WISE gate: an entry far below the row maximum must still be right to 1e-5 relative (or 1e-6 of the maximum, whichever is larger)
+# — the max-norm rule alone would let a gradient element 1000x smaller than the maximum be 100 % wrong.  r6: 1e-5, north_star's
+# figure (r5: 1e-4).  Measured on the GPU with this gate: every reference-generated golden family and every oracle comparison of the loss, metric,
+# sort, scorer and listsf suites passes; the ONE exception — 2 of 65 664 dQ entries of the fp32-MFMA attention core at 513 keys, off by 2.0e-5 and
+# 2.4e-5 relative (tests/test_listsf_gpu.py::test_oracle_mhsa_core[*-2-513-64-4]) — states its own el_rtol (profiles/r06_golden_el_rtol_1e-5.txt)
+EL_RTOL = float(os.environ.get("PTR_GOLDEN_EL_RTOL", "1e-5"))
 EL_FLOOR = 1e-6
 
 
@@ -22,7 +25,7 @@ def tol(ref):
     return ATOL + RTOL * (np.max(np.abs(ref)) if ref.size else 0.0)
 
 
-def assert_close(got, ref, what=""):
+def assert_close(got, ref, what="", el_rtol=None):
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     assert got.shape == ref.shape, f"{what}: shape {got.shape} vs {ref.shape}"
@@ -31,7 +34,7 @@ def assert_close(got, ref, what=""):
     err = np.max(np.abs(got - ref))
     assert err <= tol(ref), f"{what}: max|diff|={err:.3e} > tol={tol(ref):.3e} (scale {np.max(np.abs(ref)):.3e})"
     both_nan = np.isnan(got) & np.isnan(ref)
-    el_tol = EL_RTOL * np.abs(ref) + EL_FLOOR * max(1.0, float(np.nanmax(np.abs(ref))))
+    el_tol = (EL_RTOL if el_rtol is None else el_rtol) * np.abs(ref) + EL_FLOOR * max(1.0, float(np.nanmax(np.abs(ref))))
     bad = ~both_nan & ~(np.abs(got - ref) <= el_tol)
     if bad.any():
         i = int(np.argmax(np.where(bad, np.abs(got - ref) - el_tol, -np.inf)))

@@ -19,6 +19,12 @@ pytestmark = pytest.mark.gpu
 CPU_REFERENCE_MODULES = True      # tests/conftest.py: this module evaluates build_pointsf() module objects on the CPU as its reference (torch ops, not our kernels)
 
 
+# bench-scale passes against float64 (kink rows screened), max-norm per tensor.  r6: set from the measured worst case over the eleven shapes and both
+# forwards (profiles/r06_x6_error_ratios.txt: scores 8.7e-7, gradients 3.6e-6 of the tensor's max at 303 121 / 524 288 rows) — r5: 2e-5 / 5e-5
+PRED_TOL = 5e-6
+GRAD_TOL = 1e-5
+
+
 def close(a, b, tol, what):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     scale = max(1.0, float(b.abs().max()))
@@ -111,19 +117,23 @@ def test_scorer_train_forward_backward_at_bench_scale(F, NL, R, x6, monkeypatch)
     out = fused(X)
     monkeypatch.undo()
     exp = _masked_forward(ref, fused, Xc, seed, p, NL, torch.float64, masks=masks)
-    close(out.reshape(-1), exp.reshape(-1), 2e-5, "preds")
+    close(out.reshape(-1), exp.reshape(-1), PRED_TOL, "preds")
     w = torch.randn(R, 1, device="cuda")
     (out * w).sum().backward()
     (exp * w.cpu().double()).sum().backward()
     got = fused.views(grad=True)
+    worst = 0.0
     for name, prm in ref.named_parameters():
-        close(got[name], prm.grad, 5e-5, name)
+        e = float((got[name].detach().double().cpu() - prm.grad).abs().max()) / max(1.0, float(prm.grad.abs().max()))
+        worst = max(worst, e)
+        close(got[name], prm.grad, GRAD_TOL, name)
+    print(f"MEASURED bench-scale F={F} NL={NL} R={R} x6={x6}: preds err/scale {float((out.reshape(-1).detach().double().cpu() - exp.reshape(-1)).abs().max()) / max(1.0, float(exp.abs().max())):.3e}; worst gradient err/scale {worst:.3e}")
     # eval forward (no stored activations, other tile schedule) at the same scale
     fused.eval()
     with torch.no_grad():
         out_e = fused(X)
         exp_e = _masked_forward(ref, fused, X.cpu(), 0, 0.0, NL, torch.float64)
-    close(out_e.reshape(-1), exp_e.reshape(-1), 2e-5, "eval preds")
+    close(out_e.reshape(-1), exp_e.reshape(-1), PRED_TOL, "eval preds")
 
 
 def test_scorer_backward_is_run_to_run_bit_stable_at_bench_scale():
@@ -196,18 +206,14 @@ def test_direct_train_step_at_headline_batch_matches_cpu_reference(name, paras, 
         # pre-activations of this batch) rounding noise becomes a +-lr move on either side.  Nearly all coordinates agree to 2e-5; none
         # may be off by more than a tenth of the 3 * lr a coordinate can travel in three steps.
         d = (p1.detach().cpu() - p2.detach()).abs()
-        if x6 == "0":
-            assert float(d.max()) <= 0.1 * 3 * 1e-3, (n1, float(d.max()))
-            assert float((d > 2e-5 + 1e-4 * p2.detach().abs()).float().mean()) < 2e-3, (n1, float((d > 2e-5).float().mean()))
-        else:
-            # The bf16x6 forward is as accurate as the fp32-MFMA one (same error against float64, test_x6_gpu.py; identical gradient error
-            # once rows at a ReLU kink are screened, scratch/dbg_x6_grad64.py) but rounds DIFFERENTLY from the CPU's fp32 GEMM, so a handful of
-            # the 4 * 10^7 pre-activations of this batch (measured: 4, all below 2e-7) land on the other side of their kink.  A flipped gate
-            # changes one document's contribution to a whole weight row; Adam turns that into a full +-lr move wherever the coordinate's
-            # gradient is near 0 (measured: 1 / 4 / 20 of the 13 600 first-layer coordinates after 1 / 2 / 3 steps, all others within 1e-4).
-            assert float(d.max()) <= 2 * 3 * 1e-3, (n1, float(d.max()))
-            assert float((d > 1e-4 + 1e-4 * p2.detach().abs()).float().mean()) < 5e-3, (n1, float((d > 1e-4).float().mean()))
-            assert float((d > 2e-5 + 1e-4 * p2.detach().abs()).float().mean()) < 5e-2, (n1, float((d > 2e-5).float().mean()))
+        print(f"MEASURED regime {name} x6={x6} {n1}: max d {float(d.max()):.3e}; frac(d > 2e-5 + 1e-4|p|) {float((d > 2e-5 + 1e-4 * p2.detach().abs()).float().mean()):.3e} "
+              f"(count {int((d > 2e-5 + 1e-4 * p2.detach().abs()).sum())} of {d.numel()}); frac(d > 1e-4 + 1e-4|p|) {float((d > 1e-4 + 1e-4 * p2.detach().abs()).float().mean()):.3e}")
+        # r6: ONE gate for both forwards — r5 allowed the bf16x6 forward 5 % of the coordinates off by 2e-5 and 2 lr of travel,
+        # orders above what was ever measured (profiles/r06_x6_error_ratios.txt: max |d| 2.8e-5 / 1.1e-4, 0 / 3 of 13 600 coordinates beyond
+        # 2e-5 for x6 / fp32-MFMA on these batches; r5 saw up to 20 on another seed).  Gradient-level agreement BEFORE Adam, against float64 with the
+        # kink rows screened, is test_scorer_train_forward_backward_at_bench_scale's job (same file, R up to 524 288, both forwards).
+        assert float(d.max()) <= 0.1 * 3 * 1e-3, (n1, float(d.max()))
+        assert float((d > 2e-5 + 1e-4 * p2.detach().abs()).float().mean()) < 2e-3, (n1, float((d > 2e-5).float().mean()))
 
 
 # (d) the loss kernels at B = 4096 (launch geometry of the benchmark) against the C oracle

@@ -59,6 +59,18 @@ def _forward(fused, X, NL, train, seed, x6):
     return preds, acts
 
 
+# The gates on "bf16x6 is a numerical drop-in for the fp32-MFMA path" (r5 allowed 1.5x everywhere and 5e-5 absolute on weight
+# gradients).  r6 sets them from what the suite MEASURES (every test prints `MEASURED ...`; profiles/r06_x6_error_ratios.txt) plus a small margin:
+#   forward, error against float64, x6 / fp32-MFMA (max | median relative): N(0,1) data 0.72-0.93 | 0.91-0.92, wide exponents 0.80-1.19 | 0.97-1.04,
+#     all-positive data 0.87-1.12 | 0.83-1.26 — x6 is the BETTER path on ordinary data and within 26 % on the adversarial sets: 1.1x does not hold there
+#   backward: where a ReLU gate sits at rounding distance of its kink (both kernels read the same stored activations) the two errors agree to
+#     1.000-1.009; elsewhere both are rounding noise (x6 <= 1.15e-6 of the tensor's max, the kernels differ by <= 4.2e-6 of it at 524 288 rows)
+X6_FWD_RATIO = {"normal": (1.05, 1.05), "wide_exponent": (1.25, 1.1), "all_positive": (1.2, 1.3)}      # (max error, median relative error)
+X6_BWD_RATIO = 1.05          # x6 error <= 1.05 x the fp32-MFMA error + 2e-6 of the tensor's max (r5: max(5e-5 max, 1.5 x ...))
+X6_BWD_PAIR = 1e-5           # |x6 - fp32-MFMA| <= 1e-5 of the tensor's max (r5: 2e-5)
+X6_WIDE_RATIO, X6_WIDE_ABS, X6_WIDE_PAIR = 1.05, 0.0, 1e-5         # the first-layer dW of wide inputs: measured 1.000-1.001 at gate flips, x6 error <= 7.2e-7
+                                                                  # and |x6 - fp32| <= 1.3e-6 of the tensor's max elsewhere (r5: 1.5, 5e-5, 2e-5)
+
 # (F, NL, R): the benchmark width and its neighbours, one / many slices in layer 1 (F <= 32, F = 700), 2..5 hidden layers, tiles that end
 # inside a wave (R mod 32 != 0), inside a workgroup (R mod 256 != 0), one tile, more than one pass per workgroup (R > 65536)
 SHAPES = [(136, 3, 2085), (136, 3, 32), (136, 3, 31), (136, 3, 1), (132, 3, 777), (140, 5, 300), (700, 3, 1111), (24, 2, 100), (256, 3, 640),
@@ -115,9 +127,11 @@ def test_x6_error_not_above_the_fp32_mfma_path(kind, train):
         preds, acts = _forward(fused, X, NL, train, seed, x6)
         errs[x6] = float(((preds.double().cpu() - exp).abs() / exp.abs().clamp_min(1e-30)).median()), float((preds.double().cpu() - exp).abs().max())
     scale = float(exp.abs().max())
+    print(f"MEASURED x6-forward {kind} train={train}: max err x6 {errs[True][1]:.3e} fp32 {errs[False][1]:.3e} (ratio {errs[True][1] / max(errs[False][1], 1e-300):.3f}, "
+          f"scale {scale:.3e}); median rel err x6 {errs[True][0]:.3e} fp32 {errs[False][0]:.3e} (ratio {errs[True][0] / max(errs[False][0], 1e-300):.3f})")
     # max error: not above the fp32 path's by more than the noise between two roundings of the same sum; median relative error likewise
-    assert errs[True][1] <= 1.5 * errs[False][1] + 1e-7 * scale, (kind, errs)
-    assert errs[True][0] <= 1.5 * errs[False][0] + 1e-8, (kind, errs)
+    assert errs[True][1] <= X6_FWD_RATIO[kind][0] * errs[False][1] + 1e-7 * scale, (kind, errs)
+    assert errs[True][0] <= X6_FWD_RATIO[kind][1] * errs[False][0] + 1e-8, (kind, errs)
 
 
 def test_x6_range_and_argument_errors():
@@ -165,8 +179,9 @@ def test_x6_is_the_default_forward_at_bench_scale_and_deterministic(monkeypatch)
 
 
 # ---- the bf16x6 fused backward (csrc/scorer_bwd_x6.hip; r5: the default, PTR_BWD_X6=0 selects the fp32-MFMA kernel)
-@pytest.mark.parametrize("F,R", [(136, 2085), (136, 32), (136, 1), (132, 777), (140, 4101), (136, 65536 + 37)])
-@pytest.mark.parametrize("p", [0.1, 0.0])
+@pytest.mark.parametrize("F,R,p", [(136, 2085, 0.1), (136, 2085, 0.0), (136, 32, 0.1), (136, 32, 0.0), (136, 1, 0.1), (136, 1, 0.0), (132, 777, 0.1), (132, 777, 0.0),
+                                   (140, 4101, 0.1), (140, 4101, 0.0), (136, 65536 + 37, 0.1), (136, 65536 + 37, 0.0),
+                                   (136, 524288, 0.1)])        # r6: the benchmark's row count (64 slabs per workgroup), VERDICT r5 missing 5
 def test_x6_backward_matches_float64_modules_and_the_fp32_kernel(F, R, p, monkeypatch):
     """Gradients of sum(w * scores) through the stored activations of a training forward: the bf16x6 backward against float64 CPU modules
     (same dropout masks) with the tolerance of the fp32-MFMA backward's tests, and against the fp32-MFMA fused backward on identical inputs."""
@@ -215,10 +230,12 @@ def test_x6_backward_matches_float64_modules_and_the_fp32_kernel(F, R, p, monkey
         # Both kernels read the SAME stored activations, so a pre-activation at rounding distance of its ReLU kink (the float64 reference gates it
         # the other way: one document's contribution to a whole weight row) moves both by the same amount: the float64 bar of
         # tests/test_scorer_gpu.py (5e-5) applies where no gate flipped, "not worse than the fp32-MFMA backward" everywhere, and the two kernels
-        # agree with each other to fp32 rounding
-        assert e6 <= max(5e-5 * scale, 1.5 * e32 + 2e-6 * scale), (off, e6, e32, scale)
+        # agree with each other to fp32 rounding.  r6: no absolute 5e-5 branch any more — x6 must be within 5 % of the fp32-MFMA kernel's error
+        # (+ 2e-6 of the tensor's maximum: both errors are rounding noise of ~2e-7 where no gate flipped, and their ratio there is meaningless)
         d = float((grads["1"][off:off + n] - grads["0"][off:off + n]).abs().max())
-        assert d <= 2e-5 * scale, (off, d, scale)
+        print(f"MEASURED x6-backward F={F} R={R} p={p} param@{off}: err/scale x6 {e6 / scale:.3e} fp32 {e32 / scale:.3e} ratio {e6 / max(e32, 1e-300):.3f} x6-vs-fp32 {d / scale:.3e}")
+        assert e6 <= X6_BWD_RATIO * e32 + 2e-6 * scale, (off, e6, e32, scale)
+        assert d <= X6_BWD_PAIR * scale, (off, d, scale)
         off += n
 
 
@@ -305,8 +322,10 @@ def test_x6_wide_dw_matches_float64_modules_and_the_fp32_kernel(F, NL, R, p, mon
         e32 = float((grads["0"][off:off + n] - gref[off:off + n]).abs().max())
         for mode in ("2", "tail"):
             e6 = float((grads[mode][off:off + n] - gref[off:off + n]).abs().max())
-            assert e6 <= max(5e-5 * scale, 1.5 * e32 + 2e-6 * scale), (mode, i, e6, e32, scale)      # same bar as the fused x6 backward above
-            assert float((grads[mode][off:off + n] - grads["0"][off:off + n]).abs().max()) <= 2e-5 * scale, (mode, i)
+            dd = float((grads[mode][off:off + n] - grads["0"][off:off + n]).abs().max())
+            print(f"MEASURED x6-wide-dw F={F} NL={NL} R={R} p={p} {mode} param#{i}: err/scale x6 {e6 / scale:.3e} fp32 {e32 / scale:.3e} ratio {e6 / max(e32, 1e-300):.3f} x6-vs-fp32 {dd / scale:.3e}")
+            assert e6 <= max(X6_WIDE_ABS * scale, X6_WIDE_RATIO * e32 + 2e-6 * scale), (mode, i, e6, e32, scale)
+            assert dd <= X6_WIDE_PAIR * scale, (mode, i)
         if i >= 2:                                                                                # untouched kernels: the same bits
             assert torch.equal(grads["2"][off:off + n], grads["0"][off:off + n]), i
         off += n
