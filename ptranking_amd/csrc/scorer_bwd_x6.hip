@@ -365,6 +365,10 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
     uint32_t m2 = 0u, m1 = 0u;                         // gate bits (activation > 0) of this lane's 2 x 4 elements of layers 2 / 1, per slab
     auto staging = [&](uint32_t zdst, int dt0 = 0, int dt1 = 2) __attribute__((always_inline)) {        // zdst: LDS offset (from lds0) of the dZ buffer that receives dZ3; document tiles dt0 .. dt1 - 1
         if (dt0 == 0) { m2 = 0u; m1 = 0u; }
+#if defined(PTR_B6_ABL_NOSTAGE) || defined(PTR_B6_ABL_ST_NOMASK)     // (opaque gate bits: with a known 0 the compiler deletes the chain behind them)
+        m2 = 0xa5u; m1 = 0x5au;
+        asm volatile("" : "+v"(m2), "+v"(m1));
+#endif
 #ifdef PTR_B6_ABL_NOSTAGE    // timing-only ablation (wrong results): no staging pass at all
         if (false) {
 #else
@@ -375,23 +379,32 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
             for (int dt = dt0; dt < dt1; ++dt) {
                 // the staging area is a straight copy of two tile-major row tiles (ptr_mlp.h): feature tile W of row tile dt at dt * 7168 + W * 1024, lane (j, g) at j * 64 + 16 g
                 const uint32_t so = b6_opaque(lds0 + (uint32_t)(kB6_ST + 1024 * W)) + (uint32_t)(j * 64 + 16 * g) + (uint32_t)(dt * kActTile * 4);
+#ifdef PTR_B6_ABL_ST_NOREAD     // timing-only ablations of the staging pass (wrong results): no staging-area reads / no mask bits / no A1, A2 image stores
+                f32x4 a1 = wo4, a2 = wo4, a3 = wo4;
+                asm volatile("" : "+v"(a1), "+v"(a2), "+v"(a3));
+#else
                 const f32x4 a1 = *reinterpret_cast<lds_f32x4_b *>((uintptr_t)so);
                 const f32x4 a2 = *reinterpret_cast<lds_f32x4_b *>((uintptr_t)(so + kB6STG));
                 const f32x4 a3 = *reinterpret_cast<lds_f32x4_b *>((uintptr_t)(so + 2 * kB6STG));
+#endif
                 const float ds = dsv[dt];
                 f32x4 z3;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     z3[r] = a3[r] > 0.0f ? ds * wo4[r] : 0.0f;
                     awo[r] = fmaf(ds, a3[r], awo[r]);
+#ifndef PTR_B6_ABL_ST_NOMASK
                     m2 |= (a2[r] > 0.0f ? 1u : 0u) << (4 * dt + r);
                     m1 |= (a1[r] > 0.0f ? 1u : 0u) << (4 * dt + r);
+#endif
                 }
                 if (W == 0 && g == 0) abo += ds;
                 const uint32_t wo = wr_z + b6_opaque(lds0 + (uint32_t)(32 * W)) + (uint32_t)(16 * dt * kB6ZRS);
                 b6_write4(wo + b6_opaque(zdst), kB6ZPL, z3);
+#ifndef PTR_B6_ABL_ST_NOWRITE
                 b6_write4(wo + kB6_A2, kB6ZPL, a2);
                 b6_write4(wo + kB6_A1, kB6ZPL, a1);
+#endif
             }
         }
     };

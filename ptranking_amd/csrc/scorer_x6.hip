@@ -498,18 +498,36 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
             constexpr bool LAST = decltype(lastlayer_)::value;
             abase = slice_step(I0{}, abase, bp[0], nowork, KNone{}, Early{});
             abase = slice_step(I1{}, abase, bp[1], nowork, KNone{}, Early{});
-            if constexpr (LAST) {                    // the next tile's first two X slices, in front of this layer's store burst
+#ifndef PTR_X6_XLOAD_POS
+#define PTR_X6_XLOAD_POS 0          /* where the next tile's first X loads are issued: 0 behind the layer's second slice step (r4/r5), 1 behind its third, 2 inside its third (behind the SYNC) */
+#endif
+#ifndef PTR_X6_XQ_R0
+#define PTR_X6_XQ_R0 0              /* first tile region of the last step that converts a quarter of the next tile's slice 0 */
+#endif
+            auto xloads = [&]() __attribute__((always_inline)) {
 #pragma unroll
                 for (int q = 0; q < 2 * DT; ++q) { load_xq(raw[0], t32n, 0, q); load_xq(raw[1], t32n, n1 > 1 ? 1 : 0, q); }      // (past the end: zeros, never used)
+            };
+            if constexpr (LAST && PTR_X6_XLOAD_POS == 0) {       // the next tile's first two X slices, in front of this layer's store burst
+                xloads();
                 X6_SB();
             }
-            abase = slice_step(I0{}, abase, bp[2], nowork, KNone{}, Early{});
+            if constexpr (LAST && PTR_X6_XLOAD_POS == 2) {
+                abase = slice_step(I0{}, abase, bp[2], [&](auto r_) __attribute__((always_inline)) { if constexpr (decltype(r_)::value == 4) xloads(); }, KNone{}, Early{});
+            } else {
+                abase = slice_step(I0{}, abase, bp[2], nowork, KNone{}, Early{});
+            }
+            if constexpr (LAST && PTR_X6_XLOAD_POS == 1) {
+                xloads();
+                X6_SB();
+            }
             if constexpr (LAST) {
                 abase = slice_step(I1{}, abase, bp[3], [&](auto r_) __attribute__((always_inline)) {
                     constexpr int r = decltype(r_)::value;
                     // the third slice right behind the quarter it replaces: in front of all but the first few stores of the burst
                     auto quarter = [&](int q) __attribute__((always_inline)) { make_bq(raw[0], t32n, 0, bfx[0], q); load_xq(raw[0], t32n, n1 > 2 ? 2 : 0, q); };
-                    if constexpr (r < 4) { if constexpr (DT == 2) quarter(r); else { quarter(2 * r); quarter(2 * r + 1); } }
+                    if constexpr (DT == 2) { if constexpr (r >= PTR_X6_XQ_R0 && r < PTR_X6_XQ_R0 + 4) quarter(r - PTR_X6_XQ_R0); }
+                    else if constexpr (r < 4) { quarter(2 * r); quarter(2 * r + 1); }
                     if constexpr (r > 0) epilogue_out(std::integral_constant<int, r - 1>{});
                 }, X6K<KX, KX + 1, KX + 1, KX + 1, 1, 1, 1>{}, std::bool_constant<TRAIN && PTR_X6_LATE == 2>{});
                 epilogue_out(std::integral_constant<int, kMT - 1>{});
