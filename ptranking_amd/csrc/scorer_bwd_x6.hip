@@ -144,6 +144,14 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
     const int F = a.F, R = a.R;
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, W = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lds0 = b6_lds_addr(smem_b6);
+#ifdef PTR_B6_TRACE_EDGE      // experiment builds: shader-clock stamps of the kernel's prologue / epilogue (workgroup 0, every wave), behind the phase stamps' area
+    unsigned long long *etrace = reinterpret_cast<unsigned long long *>(ws + (size_t)gridDim.x * np_stride) + 8 * 256 + W * 16;
+    int nedge = 0;
+#define B6_EDGE() do { if (blockIdx.x == 0 && lane == 0 && nedge < 16) etrace[nedge++] = clock64(); } while (0)
+#else
+#define B6_EDGE() do { } while (0)
+#endif
+    B6_EDGE();                                                       // E0 entry
     const int nslabs = (R + kB6S - 1) / kB6S;
     const uint32_t thr = a.p_drop > 0.0f ? drop_thr(a.p_drop) : 0u;
     const float scale = a.p_drop > 0.0f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
@@ -151,6 +159,7 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
     // every image starts as zeros (rows of documents past R in the last slab are read before anything was written there: 0 x NaN = NaN)
     for (int i = tid; i < kB6Lds / 16; i += 512) reinterpret_cast<u32x4 *>(smem_b6)[i] = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();                       // before the first DMA lands in the staging area
+    B6_EDGE();                                                       // E1 LDS zeroed
 
     // ---- persistent registers: ONE array of 42 x 4, used by role (a single instruction stream allocates the maximum over the waves anyway —
     // separate arrays for the chain fragments and the accumulators would add up: 296 spills in the first build):
@@ -199,6 +208,7 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
             }
         }
     }
+    B6_EDGE();                                                       // E2 W^T fragments loaded and split
     if (tid < kHP) reinterpret_cast<float *>(smem_b6 + kB6_WO)[tid] = tid < kH ? P[off_wout(NL, F) + tid] : 0.0f;
     float awo[4] = {0.0f, 0.0f, 0.0f, 0.0f}, abo = 0.0f;
 
@@ -412,6 +422,7 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
     prefetch(slab0 < nslabs ? slab0 : nslabs - 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                       // zero fill + first staging visible to every wave
+    B6_EDGE();                                                       // E3 first slab's activations landed (r6: gathering W^T BEHIND the first DMA instead of in front of it was measured — 12.5 K against 11.7 K cycles to this point: not kept)
 
 #ifdef PTR_B6_TRACE       // experiment builds: shader-clock stamps of workgroup 0 behind its partial gradient (ws is sized for 2 partials per CU)
     unsigned long long *trace = reinterpret_cast<unsigned long long *>(ws + (size_t)gridDim.x * np_stride) + W * 256;
@@ -652,6 +663,7 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
         const uint32_t tz = zi; zi = zo; zo = tz;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the run-ahead DMA must not outlive the workgroup's LDS allocation
+    B6_EDGE();                                                       // E4 slab loop done
 
     // ---- this workgroup's partial gradient, flat parameter layout (every element written exactly once)
     float *out = ws + (size_t)blockIdx.x * np_stride;
@@ -696,6 +708,10 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
             if constexpr (!TAIL) store_tile(st[28 + mo], 0, mo, 8);
         }
     }
+#ifdef PTR_B6_TRACE_EDGE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    B6_EDGE();                                                       // E5 partial gradient stored
+#endif
 }
 
 // PTR_BWD_X6 (read per call): "0" selects the fp32-MFMA fused backward (scorer_bwd.hip) instead.  r5: this kernel is the DEFAULT wherever it
