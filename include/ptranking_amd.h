@@ -224,6 +224,8 @@ int ptr_mlp_forward_x6(const float *X, const float *params, int R, int F, int NL
  *   scratch        preds [B*L], acts (ptr_mlp_acts_floats), loss_q [B], dpreds [B*L], ws (ptr_mlp_backward_ws_floats), dz
  *                  (ptr_mlp_backward_dz_floats, NULL when 0), wimg (ptr_mlp_x6_ws_bytes; NULL selects the fp32-MFMA forward)
  *   loss_out [1]   sum of the per-query losses (written by the backward's reduction launch)
+ *   wimg_current   with the bf16x6 forward the step is FOUR launches: the optimiser launch also writes the updated weights' bf16 planes into `wimg`
+ *                  (bit-identical to what the prep launch of ptr_mlp_forward_x6 would build), so the next step needs no prep launch
  * Errors: the first failing stage's code; ptr_last_error() names the stage's entry point. */
 #define PTR_LOSS_RANKNET 1
 #define PTR_LOSS_LAMBDARANK 2
@@ -244,6 +246,14 @@ typedef struct ptr_train_step_desc {
     float *preds, *acts, *loss_q, *dpreds, *dz, *ws;
     void *wimg;
     float *loss_out;
+    void *events[4];                      /* optional hipEvent_t handles (NULL: none) recorded on `stream` in front of the forward, between the stages
+                                             and behind the backward: events[0..1] bracket the forward, [1..2] the loss kernel, [2..3] the backward + step
+                                             (bench.py times the stages of the product path with them) */
+    int32_t wimg_current;                 /* != 0: `wimg` already holds the bf16 planes of `params` (left there by the previous ptr_train_step on these
+                                             buffers): the forward skips its prep launch.  The call ALWAYS leaves the image current for the updated
+                                             parameters — the optimiser launch rewrites it element by element.  0 when in doubt (first call, parameters or
+                                             image touched by anything else in between) */
+    int32_t reserved;
 } ptr_train_step_desc;
 int ptr_train_step(const ptr_train_step_desc *d, void *stream);
 /* Test helper: the dropout keep-mask (1.0 / 0.0) of dropout site `site` for an [R][n_feat] activation. */

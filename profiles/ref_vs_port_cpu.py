@@ -2,7 +2,7 @@
 """The reference ITSELF (wildltr/ptranking imported read-only from /root/reference) timed beside the oracle's torch-CPU port of its
 train step, same process, same synthetic MSLR-shaped batches, same thread count — run in the BUILD container (the reference cannot
 travel to the GPU box).  Shows that bench.py's `cpu_baseline` (kind "port") is timing-faithful to the reference's train_op
-(ptranking/base/ranker.py:589-603 followed by loss.item(), :579-584).  Writes profiles/r02_reference_vs_port_cpu.json.
+(ptranking/base/ranker.py:589-603 followed by loss.item(), :579-584).  Writes profiles/r06_reference_vs_port_cpu.json.
 
     PYTHONDONTWRITEBYTECODE=1 python profiles/ref_vs_port_cpu.py
 """
@@ -79,7 +79,7 @@ def main():
                    "(the `cpu_baseline` port of bench.py), same batches (MSLR-shaped synthetic, 128 docs x 136 feats), same process, build container",
            "host": {"threads": threads, "nproc": os.cpu_count(), "torch": torch.__version__},
            "rows": rows}
-    with open(os.path.join(ROOT, "profiles", "r02_reference_vs_port_cpu.json"), "w") as f:
+    with open(os.path.join(ROOT, "profiles", "r06_reference_vs_port_cpu.json"), "w") as f:
         json.dump(doc, f, indent=1)
 
 

@@ -91,7 +91,7 @@ class TrainStepDesc(C.Structure):
                 ("X", C.c_void_p), ("labels", C.c_void_p), ("lens", C.c_void_p),
                 ("params", C.c_void_p), ("grad", C.c_void_p), ("state1", C.c_void_p), ("state2", C.c_void_p),
                 ("preds", C.c_void_p), ("acts", C.c_void_p), ("loss_q", C.c_void_p), ("dpreds", C.c_void_p), ("dz", C.c_void_p), ("ws", C.c_void_p),
-                ("wimg", C.c_void_p), ("loss_out", C.c_void_p)]
+                ("wimg", C.c_void_p), ("loss_out", C.c_void_p), ("events", C.c_void_p * 4), ("wimg_current", C.c_int32), ("reserved", C.c_int32)]
 
 
 class NativeLibraryError(RuntimeError):

@@ -41,6 +41,50 @@ struct MlpArgs {
 
 int mlp_num_cus();
 
+// ---- the bf16x6 forward's pre-split weight image (scorer_x6.hip): one slice = [3 planes][7 tiles][lane group g][16 out-features][8 k-slots] bf16
+constexpr int kX6Rows = kHP;                       // 112 A rows per slice
+constexpr int kX6PlaneBytes = kX6Rows * 32 * 2;    // 7168
+constexpr int kX6SliceBytes = 3 * kX6PlaneBytes;   // 21504 = 21 DMA pieces of 1 KB
+__host__ __device__ inline int x6_n1(int F) { return (F + 31) / 32; }
+__host__ __device__ inline int x6_nslices(int F, int NL) { return x6_n1(F) + 4 * (NL - 1); }
+#if defined(__HIPCC__)
+// r6: ONE parameter's three bf16 planes written into the image at the place x6_prep_kernel puts them — the optimiser step of the fused train step
+// (reduce_partials_kernel) refreshes the image element by element, so the next step's forward needs no prep launch.  Same split as scorer_x6.hip
+// split_pack2 (round to nearest, v_cvt_pk_bf16_f32), element for element: the image is bit-identical to a fresh x6_prep_kernel run.
+// i = index into the flat parameter vector; b_1, w_out and b_out are not part of the image (they live in LDS / registers of the forward).
+__device__ __forceinline__ void x6_img_put(uint8_t *__restrict__ img, int F, int NL, size_t i, float x) {
+    using bf2 = __attribute__((ext_vector_type(2))) __bf16;
+    using f2 = __attribute__((ext_vector_type(2))) float;
+    const size_t w1 = (size_t)kH * F;
+    int sl, row, g, e;
+    if (i < w1) {                                                    // W1[row][k]: slice k / 32, slot (g, e) <-> feature 32 s + 8 g + e
+        row = (int)(i / F);
+        const int k = (int)(i - (size_t)row * F), kk = k & 31;
+        sl = k >> 5; g = kk >> 3; e = kk & 7;
+    } else {
+        if (i < w1 + kH) return;                                     // b_1
+        const size_t jv = i - (w1 + kH);
+        const int l = 1 + (int)(jv / (kH * kH + kH));
+        if (l > NL - 1) return;                                      // w_out, b_out
+        const int jj = (int)(jv - (size_t)(l - 1) * (kH * kH + kH));
+        int k;
+        if (jj < kH * kH) { row = jj / kH; k = jj - row * kH; } else { row = jj - kH * kH; k = kH; }      // the bias rides on the ones slot (feature 100)
+        const int kk = k & 31;
+        sl = x6_n1(F) + 4 * (l - 1) + (k >> 5);
+        g = (kk & 15) >> 2; e = 4 * (kk >> 4) + (kk & 3);           // hidden layers: slot (g, e) <-> feature 32 s + 16 (e >> 2) + 4 g + (e & 3)
+    }
+    const uint16_t p1 = (uint16_t)(__builtin_bit_cast(uint32_t, __builtin_convertvector(f2{x, 0.0f}, bf2)) & 0xffffu);
+    const float r = x - __uint_as_float((uint32_t)p1 << 16);
+    const uint16_t p2 = (uint16_t)(__builtin_bit_cast(uint32_t, __builtin_convertvector(f2{r, 0.0f}, bf2)) & 0xffffu);
+    const float t = r - __uint_as_float((uint32_t)p2 << 16);
+    const uint16_t p3 = (uint16_t)(__builtin_bit_cast(uint32_t, __builtin_convertvector(f2{t, 0.0f}, bf2)) & 0xffffu);
+    uint8_t *at = img + (size_t)sl * kX6SliceBytes + (size_t)(row >> 4) * 1024 + g * 256 + (row & 15) * 16 + e * 2;
+    *reinterpret_cast<uint16_t *>(at) = p1;
+    *reinterpret_cast<uint16_t *>(at + kX6PlaneBytes) = p2;
+    *reinterpret_cast<uint16_t *>(at + 2 * kX6PlaneBytes) = p3;
+}
+#endif
+
 // ---- compile-time loop with a constexpr index: f(std::integral_constant<int, I>{}) for I = 0..N-1
 template <int N, class Fn> __device__ __forceinline__ void static_for(Fn &&f) {
     [&]<int... I>(std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, N>{});
@@ -72,5 +116,14 @@ int launch_bwd_x6_tail(const float *params, const float *acts, const float *dpre
 bool dw_x6_supported(int R, int K, int lda, const void *A);
 int launch_dw_x6(const float *A, int lda, const float *dZ, int K, int nt_base, const MlpArgs &a, float *ws, size_t np_stride, size_t w_off, size_t b_off,
                  int nblk, hipStream_t st, const char *who);
+
+// ---- internals the one-call train step (train_step.hip) chains: the extern "C" entry points with the image hand-over of r6
+//   mlp_forward_x6_impl: ptr_mlp_forward_x6 with prep = false when `wimg` already holds the planes of `params`
+//   mlp_backward_step_impl: ptr_mlp_backward_step whose optimiser step also refreshes `wimg` (NULL: plain ptr_mlp_backward_step)
+int mlp_forward_x6_impl(const float *X, const float *params, int R, int F, int NL, int train, float p_drop, uint64_t seed, float *preds, float *acts,
+                        void *wimg, bool prep, void *stream);
+int mlp_backward_step_impl(const float *X, float *params, const float *acts, const float *dpreds, int R, int F, int NL, float p_drop, uint64_t seed, float *dz,
+                           float *ws, float *grad, int opt_kind, float lr, float hyper1, float hyper2, float eps, float weight_decay, int step, float *state1,
+                           float *state2, const float *loss_q, int nq, float *loss_out, void *wimg, void *stream);
 
 }  // namespace ptr

@@ -999,6 +999,7 @@ struct OptStep {
     float lr, h1, h2, eps, wd, bc1, bc2_sqrt;
     float *param, *s1, *s2;
     const float *loss_q; int nq; float *loss_out;
+    uint8_t *wimg; int F, NL;      // r6: the bf16x6 forward's weight image, refreshed element by element behind the step (NULL: none)
 };
 __global__ void __launch_bounds__(1024)
 reduce_partials_kernel(const float *__restrict__ ws, int nblk, int nblk_tail, size_t tail_begin, size_t stride, size_t n,
@@ -1040,19 +1041,25 @@ reduce_partials_kernel(const float *__restrict__ ws, int nblk, int nblk_tail, si
             const float vi = o.h2 * o.s2[i] + (1.0f - o.h2) * gi * gi;
             o.s1[i] = mi; o.s2[i] = vi;
             const float denom = sqrtf(vi) / o.bc2_sqrt + o.eps;
-            o.param[i] = pi - (o.lr / o.bc1) * (mi / denom);
+            const float pn = pi - (o.lr / o.bc1) * (mi / denom);
+            o.param[i] = pn;
+            if (o.wimg) x6_img_put(o.wimg, o.F, o.NL, i, pn);
         } else if (o.kind == PTR_OPT_ADAGRAD) {
             const float pi = o.param[i];
             const float gi = s + o.wd * pi;
             const float si = o.s1[i] + gi * gi;
             o.s1[i] = si;
-            o.param[i] = pi - o.lr * (gi / (sqrtf(si) + o.eps));          // o.lr = the decayed clr
+            const float pn = pi - o.lr * (gi / (sqrtf(si) + o.eps));     // o.lr = the decayed clr
+            o.param[i] = pn;
+            if (o.wimg) x6_img_put(o.wimg, o.F, o.NL, i, pn);
         } else if (o.kind == PTR_OPT_RMSPROP) {
             const float pi = o.param[i];
             const float gi = s + o.wd * pi;
             const float si = o.h1 * o.s1[i] + (1.0f - o.h1) * gi * gi;
             o.s1[i] = si;
-            o.param[i] = pi - o.lr * (gi / (sqrtf(si) + o.eps));
+            const float pn = pi - o.lr * (gi / (sqrtf(si) + o.eps));
+            o.param[i] = pn;
+            if (o.wimg) x6_img_put(o.wimg, o.F, o.NL, i, pn);
         }
     }
 }
@@ -1204,6 +1211,13 @@ extern "C" int ptr_mlp_backward_step(const float *X, float *params, const float 
                                      uint64_t seed, float *dz, float *ws, float *grad, int opt_kind, float lr, float hyper1, float hyper2,
                                      float eps, float weight_decay, int step, float *state1, float *state2, const float *loss_q, int nq,
                                      float *loss_out, void *stream) {
+    return ptr::mlp_backward_step_impl(X, params, acts, dpreds, R, F, NL, p_drop, seed, dz, ws, grad, opt_kind, lr, hyper1, hyper2, eps, weight_decay, step, state1,
+                                       state2, loss_q, nq, loss_out, nullptr, stream);
+}
+
+int ptr::mlp_backward_step_impl(const float *X, float *params, const float *acts, const float *dpreds, int R, int F, int NL, float p_drop, uint64_t seed,
+                                float *dz, float *ws, float *grad, int opt_kind, float lr, float hyper1, float hyper2, float eps, float weight_decay, int step,
+                                float *state1, float *state2, const float *loss_q, int nq, float *loss_out, void *wimg, void *stream) {
     using namespace ptr;
     const char *who = "ptr_mlp_backward_step";
     if (opt_kind < PTR_OPT_ADAM || opt_kind > PTR_OPT_RMSPROP) { set_error("%s: unknown optimiser %d", who, opt_kind); return PTR_ERR_INVALID_ARG; }
@@ -1214,6 +1228,7 @@ extern "C" int ptr_mlp_backward_step(const float *X, float *params, const float 
     OptStep o{};
     o.kind = opt_kind; o.h1 = hyper1; o.h2 = hyper2; o.eps = eps; o.wd = weight_decay;
     o.param = params; o.s1 = state1; o.s2 = state2; o.loss_q = loss_q; o.nq = nq; o.loss_out = loss_out;
+    o.wimg = reinterpret_cast<uint8_t *>(wimg); o.F = F; o.NL = NL;
     if (opt_kind == PTR_OPT_ADAM) {                                  // as ptr_adam_step
         o.lr = lr; o.bc1 = 1.0f - powf(hyper1, (float)step); o.bc2_sqrt = sqrtf(1.0f - powf(hyper2, (float)step));
     } else if (opt_kind == PTR_OPT_ADAGRAD) {                        // as ptr_adagrad_step: hyper1 = lr_decay

@@ -27,14 +27,10 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 union Frag { bf16x8 v; u32x4 q; uint32_t u[4]; };
 
-constexpr int kX6Rows = kHP;                       // 112 A rows per slice
-constexpr int kX6PlaneBytes = kX6Rows * 32 * 2;    // 7168
-constexpr int kX6SliceBytes = 3 * kX6PlaneBytes;   // 21504 = 21 DMA pieces of 1 KB
+// (kX6Rows / kX6PlaneBytes / kX6SliceBytes / x6_n1 / x6_nslices: ptr_mlp.h — the optimiser step of the fused train step writes the image too)
 constexpr int kX6Pieces = kX6SliceBytes / 1024;
 constexpr int kX6Ring = 6;                         // slices resident in LDS
 
-__host__ __device__ inline int x6_n1(int F) { return (F + 31) / 32; }
-__host__ __device__ inline int x6_nslices(int F, int NL) { return x6_n1(F) + 4 * (NL - 1); }
 __host__ __device__ inline size_t x6_lds_bytes(int NL) { return (size_t)kX6Ring * kX6SliceBytes + ((size_t)NL * kHP + kHP + 16) * sizeof(float); }
 
 // Split by ROUNDING (v_cvt_pk_bf16_f32, round to nearest even): a = p1 + p2 + p3 exactly (|p2| <= 2^-9 |a|, |p3| <= 2^-18 |a|), and the
@@ -563,6 +559,11 @@ extern "C" size_t ptr_mlp_x6_ws_bytes(int F, int NL) {
 
 extern "C" int ptr_mlp_forward_x6(const float *X, const float *params, int R, int F, int NL, int train, float p_drop, uint64_t seed,
                                   float *preds, float *acts, void *wimg, void *stream) {
+    return ptr::mlp_forward_x6_impl(X, params, R, F, NL, train, p_drop, seed, preds, acts, wimg, true, stream);
+}
+
+int ptr::mlp_forward_x6_impl(const float *X, const float *params, int R, int F, int NL, int train, float p_drop, uint64_t seed, float *preds, float *acts,
+                             void *wimg, bool prep, void *stream) {
     using namespace ptr;
     const char *who = "ptr_mlp_forward_x6";
     if (R < 0 || F <= 0 || NL < 1 || NL > kMaxLayers) { set_error("%s: bad shape R=%d F=%d NL=%d", who, R, F, NL); return PTR_ERR_INVALID_ARG; }
@@ -583,9 +584,11 @@ extern "C" int ptr_mlp_forward_x6(const float *X, const float *params, int R, in
     }
     MlpArgs a{R, F, NL, train ? p_drop : 0.0f, (uint32_t)seed, (uint32_t)(seed >> 32)};
     hipStream_t st = as_stream(stream);
-    const int nthreads = x6_nslices(F, NL) * kX6Rows * 4;
-    hipLaunchKernelGGL(x6_prep_kernel, dim3((nthreads + 255) / 256), dim3(256), 0, st, params, F, NL, reinterpret_cast<uint8_t *>(wimg));
-    if (int e = check_hip(hipGetLastError(), who)) return e;
+    if (prep) {                       // (prep = false: the previous train step's optimiser launch left the image current, ptr_train_step)
+        const int nthreads = x6_nslices(F, NL) * kX6Rows * 4;
+        hipLaunchKernelGGL(x6_prep_kernel, dim3((nthreads + 255) / 256), dim3(256), 0, st, params, F, NL, reinterpret_cast<uint8_t *>(wimg));
+        if (int e = check_hip(hipGetLastError(), who)) return e;
+    }
     const size_t lds = x6_lds_bytes(NL);
     constexpr int dt = 2, nw = 16 / dt, rpt = 16 * dt;
     const int ntiles = (R + rpt - 1) / rpt, nblk = (ntiles + nw - 1) / nw;

@@ -6,7 +6,7 @@
 // (ptranking_amd/rankers.py `_direct_train_op`, r2-r5): identical launches with identical arguments, so the results are bit-identical —
 // what goes away is the host work between them.  r5 measured the five-launch step at 80 us for 64 queries (GPU work: ~25 us) and 23 %
 // above a quarter of the 4096-query step at 1024 queries: three ctypes calls with ~60 marshalled arguments per step.
-#include "ptr_device.h"
+#include "ptr_mlp.h"
 
 extern "C" int ptr_train_step(const ptr_train_step_desc *d, void *stream) {
     using namespace ptr;
@@ -20,9 +20,13 @@ extern "C" int ptr_train_step(const ptr_train_step_desc *d, void *stream) {
     if (d->loss_kind < PTR_LOSS_RANKNET || d->loss_kind > PTR_LOSS_LISTNET) { set_error("%s: unknown loss %d", who, d->loss_kind); return PTR_ERR_INVALID_ARG; }
     if (!d->loss_q || !d->dpreds || !d->preds) { set_error("%s: NULL scratch pointer", who); return PTR_ERR_INVALID_ARG; }
     const int R = d->B * d->L;
-    // 1. forward (training mode: the activations the backward reads are stored)
-    if (int rc = d->wimg ? ptr_mlp_forward_x6(d->X, d->params, R, d->F, d->NL, 1, d->p_drop, d->seed, d->preds, d->acts, d->wimg, stream)
+    hipStream_t st = as_stream(stream);
+    auto mark = [&](int k) -> int { return d->events[k] ? check_hip(hipEventRecord(reinterpret_cast<hipEvent_t>(d->events[k]), st), who) : 0; };
+    if (int rc = mark(0)) return rc;
+    // 1. forward (training mode: the activations the backward reads are stored).  bf16x6 forward: no prep launch when the image is current
+    if (int rc = d->wimg ? mlp_forward_x6_impl(d->X, d->params, R, d->F, d->NL, 1, d->p_drop, d->seed, d->preds, d->acts, d->wimg, d->wimg_current == 0, stream)
                          : ptr_mlp_forward(d->X, d->params, R, d->F, d->NL, 1, d->p_drop, d->seed, d->preds, d->acts, stream)) return rc;
+    if (int rc = mark(1)) return rc;
     // 2. loss + dLoss/dscore.  loss_out = NULL: the per-query slots are summed by the backward's reduction launch (3)
     int rc = 0;
     switch (d->loss_kind) {
@@ -35,7 +39,9 @@ extern "C" int ptr_train_step(const ptr_train_step_desc *d, void *stream) {
     default: rc = ptr_listnet_fwd_bwd(d->preds, d->labels, d->lens, d->B, d->L, nullptr, d->loss_q, d->dpreds, stream); break;
     }
     if (rc) return rc;
-    // 3. backward -> flat gradient; the partial reduction applies the optimiser step and sums the loss slots
-    return ptr_mlp_backward_step(d->X, d->params, d->acts, d->dpreds, R, d->F, d->NL, d->p_drop, d->seed, d->dz, d->ws, d->grad, d->opt_kind, d->lr, d->hyper1,
-                                 d->hyper2, d->eps, d->weight_decay, d->step, d->state1, d->state2, d->loss_q, d->B, d->loss_out, stream);
+    if (int rc2 = mark(2)) return rc2;
+    // 3. backward -> flat gradient; the partial reduction applies the optimiser step, sums the loss slots and (bf16x6 forward) refreshes the weight image
+    if (int rc3 = mlp_backward_step_impl(d->X, d->params, d->acts, d->dpreds, R, d->F, d->NL, d->p_drop, d->seed, d->dz, d->ws, d->grad, d->opt_kind, d->lr, d->hyper1,
+                                         d->hyper2, d->eps, d->weight_decay, d->step, d->state1, d->state2, d->loss_q, d->B, d->loss_out, d->wimg, stream)) return rc3;
+    return mark(3);
 }

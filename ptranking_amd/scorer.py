@@ -93,6 +93,19 @@ def x6_serves(X2d, R, F, NL, train):
 
 
 _X6_WS = {}
+# r6: whose parameters an image buffer currently holds.  ptr_train_step leaves the image current for the UPDATED parameters (its optimiser launch
+# rewrites it), so the next step's forward can skip the prep launch — but only when NOTHING touched the parameters or the shared image in between.
+# The tag is (parameter storage address, torch's in-place version counter, optimiser step count): every torch-level write bumps the version
+# (load_state_dict, no_grad updates), every optimiser step of ours bumps the count, every other forward through a shared image drops the tag.
+_X6_IMG_TAG = {}
+
+
+def x6_image_tag(dev, F, NL):
+    return _X6_IMG_TAG.get((torch.device(dev), F, NL))
+
+
+def x6_set_image_tag(dev, F, NL, tag):
+    _X6_IMG_TAG[(torch.device(dev), F, NL)] = tag
 
 
 def x6_workspace(dev, F, NL):
@@ -100,7 +113,7 @@ def x6_workspace(dev, F, NL):
     n = _lib.query("ptr_mlp_x6_ws_bytes", F, NL)
     if n == 0:
         return None
-    key = (dev, F, NL)
+    key = (torch.device(dev), F, NL)
     ws = _X6_WS.get(key)
     if ws is None:
         ws = _X6_WS[key] = torch.empty(n, device=dev, dtype=torch.uint8)
@@ -121,6 +134,7 @@ def mlp_forward(X2d, flat, R, F, NL, train, p, seed, preds, acts, dev):
     """Scorer forward through the C ABI: the bf16x6 entry point when it serves (F, NL), the fp32-MFMA one otherwise."""
     ws = x6_wimg_for(X2d, R, F, NL, train, dev)
     if ws is not None:
+        x6_set_image_tag(dev, F, NL, None)       # this call's prep launch rebuilds the (shared) image for `flat` as it is NOW: no train step's tag survives it
         _lib.call("ptr_mlp_forward_x6", _lib.ptr(X2d), _lib.ptr(flat), R, F, NL, int(train), C.c_float(p), C.c_uint64(seed),
                   _lib.ptr(preds), _lib.ptr(acts), _lib.ptr(ws), _lib.current_stream(dev))
     else:

@@ -121,9 +121,9 @@ def test_train_step_descriptor_layout_and_validation_without_a_gpu():
     lib = _lib.load()
     hdr = open(HEADER).read()
     body = re.search(r"typedef struct ptr_train_step_desc \{(.*?)\} ptr_train_step_desc;", hdr, flags=re.S).group(1)
-    names = re.findall(r"[\s\*,]([A-Za-z_0-9]+)(?:\[4\])?\s*(?=[,;])", re.sub(r"/\*.*?\*/", "", body))
+    names = re.findall(r"[\s\*,]([A-Za-z_0-9]+)(?:\[4\])?\s*(?=[,;])", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
     assert names == [f[0] for f in _lib.TrainStepDesc._fields_], names          # same fields, same order
-    assert ctypes.sizeof(_lib.TrainStepDesc) == 216
+    assert ctypes.sizeof(_lib.TrainStepDesc) == 256
     d = _lib.TrainStepDesc()
     assert lib.ptr_train_step(None, None) == 1001
     d.struct_bytes = 8

@@ -274,6 +274,78 @@ def test_single_call_step_matches_the_three_calls_under_either_forward(x6, monke
     assert (d.wimg is not None) == (x6 == "2")
 
 
+def test_weight_image_hand_over_between_train_steps(monkeypatch):
+    """r6: with the bf16x6 forward, ptr_train_step's optimiser launch rewrites the forward's weight image element by element and the next step skips
+    the prep launch (`wimg_current`).  The image must be trusted exactly when nothing touched the parameters or the (shared) image in between:
+    a run that keeps handing the image over, a run that always rebuilds it (`reuse_weight_image = False`) and the three-call path must produce the
+    same bits through: plain steps, an evaluation forward in between, an in-place edit of the parameters by torch, a second ranker stepping through
+    the same image buffer, and a step on the three-call path."""
+    import ptranking_amd as pa
+    monkeypatch.setenv("PTR_MLP_X6", "2")
+    sf = copy.deepcopy(SF)
+    sf["pointsf"].update(num_features=136, dropout=0.1)
+
+    def make(seed, reuse=True, single=True):
+        torch.manual_seed(seed)
+        r = pa.LambdaRank(sf_para_dict=copy.deepcopy(sf), model_para_dict=dict(sigma=1.0), gpu=True, device="cuda:0")
+        r.init(); r.point_sf.dropout = 0.1; r.train_mode()
+        r.reuse_weight_image, r.single_call_step = reuse, single
+        return r
+
+    a, b, c = make(12), make(12, reuse=False), make(12, single=False)
+    other = make(99)                                              # same (device, F, NL): shares the image buffer with a / b / c
+    X, Y = make_data(6, 33, 128, 136)
+    X, Y = X.cuda(), Y.cuda()
+    kw = dict(epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
+    seen = []
+
+    def step(i, rankers=None):
+        outs = []
+        for r in (rankers or (a, b, c)):
+            torch.manual_seed(300 + i)
+            outs.append(r.train_op(X, Y, **kw)[0])
+            if r is a:
+                seen.append(int(next(iter(a._direct_buffers.values()))["desc"].wimg_current))
+        return outs
+
+    def same(i):
+        assert torch.equal(a.point_sf.flat, b.point_sf.flat) and torch.equal(a.point_sf.flat, c.point_sf.flat), i
+
+    for i in range(3):                                            # a alone hands its image over only when it steps back to back
+        o = step(i, (a,)); step(i, (b,)); step(i, (c,)); same(i)
+    # every ranker shares ONE image buffer, so b's / c's steps in between invalidate a's tag: a rebuilt the image each time so far
+    assert seen == [0, 0, 0], seen
+    for i in range(3, 6):                                         # back-to-back steps of a: the hand-over happens
+        step(i, (a,))
+    assert seen[3:] == [0, 1, 1], seen
+    for i in range(3, 6):
+        step(i, (b,)); step(i, (c,))
+    same(6)
+    a.eval_mode(); _ = a.predict(X); a.train_mode()               # an evaluation forward rebuilds the image through the other entry point
+    for r in (b, c):
+        r.eval_mode(); _ = r.predict(X); r.train_mode()
+    n0 = len(seen); step(7, (a,)); step(8, (a,))
+    assert seen[n0:] == [0, 1], seen
+    step(7, (b,)); step(8, (b,)); step(7, (c,)); step(8, (c,)); same(8)
+    with torch.no_grad():                                         # torch edits the parameters in place: version counter moves
+        for r in (a, b, c):
+            r.point_sf.flat.mul_(0.999)
+    n0 = len(seen); step(9, (a,)); step(10, (a,))
+    assert seen[n0:] == [0, 1], seen
+    step(9, (b,)); step(10, (b,)); step(9, (c,)); step(10, (c,)); same(10)
+    torch.manual_seed(5); other.train_op(X, Y, **kw)              # another ranker steps through the shared image
+    n0 = len(seen); step(11, (a,))
+    assert seen[n0:] == [0], seen
+    a.single_call_step = False; step(12, (a,)); a.single_call_step = True      # a three-call step moves the parameters without refreshing the image
+    n0 = len(seen); step(13, (a,)); step(14, (a,))
+    assert seen[n0:] == [0, 1], seen
+    for i in (11, 12, 13, 14):
+        step(i, (b,)); step(i, (c,))
+    same(14)
+    sa, sb = a.optimizer.state[a.point_sf.flat], b.optimizer.state[b.point_sf.flat]
+    assert sa["step"] == sb["step"] and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
+
+
 def test_train_step_descriptor_is_checked():
     """ptr_train_step refuses a descriptor of another size / an unknown loss before any launch."""
     import ctypes as C
