@@ -12,7 +12,7 @@ Rank 0 prints ONE JSON line (contract in the task statement).  `value` is measur
 queries per GPU (1024 is the survey's headline batch) measured the same way with fewer steps.  Extra objects:
   roofline      the dominant kernel of the step by time (the fused single-pass scorer backward, fp32 MFMA): algorithmic flops per
                 launch / its average launch duration measured with HIP events on the launch stream during the timed region (every 4th step), vs
-                the 157.3 TFLOP/s fp32 MFMA peak; `traffic` = PMC HBM bytes (profiles/r05_pmc_traffic.json, trusted only when its kernel-source hash matches the built sources), `algorithmic_bytes_*`
+                the 157.3 TFLOP/s fp32 MFMA peak; `traffic` = PMC HBM bytes (profiles/r06_pmc_traffic.json, trusted only when its kernel-source hash matches the built sources), `algorithmic_bytes_*`
                 = SURVEY 8(d)'s definition (features + scores), `design_bytes_*` = what the design additionally moves (stored
                 activations, partial gradients)
   kernels       the other kernels of the step: scorer forward (MFMA roofline), the north-star LambdaRank loss kernel against the
@@ -210,7 +210,7 @@ def metric_path(ranker, B, L, F, device, rank, ks=(1, 3, 5, 10, 20, 50), cpu_sec
                          "sample": f"{done} queries in {cel:.1f} s: torch-CPU scorer forward + sort + gather + nDCG@ks + AP@10 on batches of 64 queries"}}
 
 
-PMC_FILE = os.path.join("profiles", "r05_pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r06_pmc_traffic.json")
 
 
 def kernel_source_hash():
@@ -271,7 +271,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="queries per GPU per step (weak scaling)")
     ap.add_argument("--global-batch", type=int, default=0, help="strong scaling: total queries per step, split evenly over the GPUs")
     ap.add_argument("--sweep", default="64,256,1024,4096", help="SURVEY 8(d) per-GPU batch sweep reported in by_batch ('' = off)")
-    ap.add_argument("--sweep-steps", type=int, default=30)
+    ap.add_argument("--sweep-steps", type=int, default=100)
     ap.add_argument("--list-len", type=int, default=128)
     ap.add_argument("--features", type=int, default=136)
     ap.add_argument("--nbatches", type=int, default=4, help="distinct HBM-resident batches cycled through (> L3 capacity)")
@@ -425,6 +425,7 @@ def main():
 
     ranker = build_ranker()
     elapsed, timing, ar_timing, final_loss = measure(ranker, B, args.steps, args.warmup, 5)
+    single_call = bool(getattr(ranker, "single_call_step", False)) and "desc" in next(iter(ranker.__dict__.get("_direct_buffers", {"": {}}).values()))
     # The contract's window is the one above (`steps`, `ms_per_step`, `value`).  It is tens of ms long, so its spread is reported too:
     # args.windows - 1 further windows of the same K steps, each bracketed the same way
     # Every window gets the pre-warm of the first (with ONE warm-up step in front of freshly synthesised batches the
@@ -441,7 +442,10 @@ def main():
                 by_batch[str(bq)] = {"queries_per_s_per_gpu": B * args.steps / elapsed, "ms_per_step": 1e3 * elapsed / args.steps,
                                      "steps": args.steps, "is_value": True}
                 continue
-            el, _, _, _ = measure(ranker, bq, args.sweep_steps, args.warmup, 1)
+            # r6: the sweep sizes get the headline's pre-warm (5 rounds of 20 steps).  r5 gave them one round: at 1024 queries that is 5 ms of GPU work behind
+            # the host-side batch synthesis — the clocks had not come back up, and `value_at_1024` read 0.251 ms where a dedicated --batch 1024 run of the
+            # same build measured 0.232 (profiles/r05_bench_B1024.json)
+            el, _, _, _ = measure(ranker, bq, args.sweep_steps, args.warmup, 5)
             by_batch[str(bq)] = {"queries_per_s_per_gpu": bq * args.sweep_steps / el, "ms_per_step": 1e3 * el / args.sweep_steps,
                                  "steps": args.sweep_steps, "is_value": False}
 
@@ -701,6 +705,11 @@ def main():
             "step_hbm_roofline": {"algorithmic_bytes_per_step": step_alg_bytes, "achieved_GBps": step_alg_bytes / (step_ms * 1e-3) / 1e9,
                                   "frac_of_hbm_peak": step_alg_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                   "note": "SURVEY 8(d) end-to-end definition: 2*4*L*F + 12L + 4 bytes per query"},
+            "step_entry": ("ptr_train_step: ONE C-ABI call per step enqueues scorer forward -> fused loss + gradient kernel -> scorer backward + optimiser "
+                           "step + loss-slot sum (ABI v5, csrc/train_step.hip); with the bf16x6 forward the optimiser launch also refreshes the forward's "
+                           "weight image, so a step is FOUR kernel launches; the per-stage times below come from HIP events the call records between its "
+                           "stages on every 4th step" if single_call
+                           else "entry points chained from Python (autograd or data-parallel path)"),
             "roofline": roofline,
             "kernels": kernels,
             "by_batch": by_batch,

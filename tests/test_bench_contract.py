@@ -143,7 +143,7 @@ def test_self_launch_refuses_more_ranks_than_gpus():
 
 def test_committed_kernel_profiles_hold_no_fraction_above_one():
     """a roofline fraction above 1 means the "peak" was not a bound.  Every `frac` / `frac_of_hbm_peak` in the committed
-    round-5 stand-alone kernel profile and bench lines is a fraction."""
+    round-5 / round-6 stand-alone kernel profiles and bench lines is a fraction."""
     import glob
 
     def fracs(o, path=""):
@@ -153,8 +153,8 @@ def test_committed_kernel_profiles_hold_no_fraction_above_one():
                     yield path + "/" + k, v
                 else:
                     yield from fracs(v, path + "/" + k)
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_kernels_B65536.json")) + glob.glob(os.path.join(ROOT, "profiles", "r05_bench_*.json")))
-    assert files, "the round-5 profiles are committed"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[56]_kernels_B65536.json")) + glob.glob(os.path.join(ROOT, "profiles", "r0[56]_bench_*.json")))
+    assert files, "the round-5 / round-6 profiles are committed"
     for f in files:
         text = open(f).read().strip()
         try:
