@@ -116,6 +116,9 @@ constexpr uint32_t kX6Oob = 0xFFFFC000u;       // an offset no buffer of ours re
                                                // (6 x 1 KB feature tiles of a row tile: 0xFFFFF000 + 4096 wrapped to offset 0 and wrote row 0, r5)
 constexpr uint64_t kX6BufLimit = 0xFFFFC000ull;
 
+#ifndef PTR_X6_KTAIL
+#define PTR_X6_KTAIL 1            /* r6: the last slice of a hidden layer as a 16-deep slice (0: the r4/r5 32-deep form, A/B measurements) */
+#endif
 #define X6_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16((A).v, (B).v, (C), 0, 0, 0)
 
 // =================================================================================================== forward
@@ -267,15 +270,31 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) acc[mt][dt] = X6_MFMA(buf[kA[q]], bf[dt][kB[q]], acc[mt][dt]);
     };
+    // r6: the LAST slice of a hidden layer holds only features 96..111 (100 real + the ones feature): its k slots (g, e >= 4) <-> features 112.. are zeros
+    // in both operands, so the slice is 16 deep — one v_mfma_f32_16x16x16_bf16 on the first 8 bytes of each fragment (k slot (g, e < 4) <-> feature
+    // 96 + 4 g + e) at HALF the matrix-pipe time of the 32-deep instruction that multiplied 16 zeros per lane.  Hidden layers: 3.5 instead of 4 slices.
+    auto mma_tile_tail = [&](const Frag (&buf)[3], auto mt_, const Frag (&bf)[DT][3]) __attribute__((always_inline)) {
+        constexpr int mt = decltype(mt_)::value;
+        constexpr int kA[6] = {0, 1, 2, 0, 1, 0}, kB[6] = {2, 1, 0, 1, 0, 0};
+        using i16x4 = __attribute__((ext_vector_type(4))) short;
+        using u32x2_ = __attribute__((ext_vector_type(2))) uint32_t;
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                acc[mt][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(i16x4, u32x2_{buf[kA[q]].u[0], buf[kA[q]].u[1]}),
+                                                                         __builtin_bit_cast(i16x4, u32x2_{bf[dt][kB[q]].u[0], bf[dt][kB[q]].u[1]}), acc[mt][dt], 0, 0, 0);
+    };
     // one slice step (see the schedule above).  In: af[AP] = tile 0 of this slice; out: af[AP ^ 1] = tile 0 of the next slice (its base
     // returned).  work(r): the VALU work beside the MFMAs of tile r; Ks: VALU instructions per MFMA of the interleave hint (0 = none)
     // LATE (the epilogue-carrying steps of the training kernel): the next tile's A fragments are read BEHIND the work of the current tile instead
     // of one tile ahead, so the read-ahead set is not live beside the epilogue's temporaries — the 12 registers that decide between spilling and
     // not spilling there (r5: a scratch reload waits with vmcnt for the activation stores in flight; the exposed LDS latency is hidden by the
     // partner wave, a drained store queue is not)
-    auto slice_step = [&](auto ap_, uint32_t abase, const Frag (&bf)[DT][3], auto &&work, auto ks_, auto late_) __attribute__((always_inline)) -> uint32_t {
+    auto slice_step = [&](auto ap_, uint32_t abase, const Frag (&bf)[DT][3], auto &&work, auto ks_, auto late_, auto tail_) __attribute__((always_inline)) -> uint32_t {
         constexpr int AP = decltype(ap_)::value;
         constexpr bool LATE = decltype(late_)::value;
+        constexpr bool TAIL16 = decltype(tail_)::value;            // a 16-deep slice (the last one of a hidden layer)
         uint32_t nb = 0;
         static_for<kMT>([&](auto r_) __attribute__((always_inline)) {
             constexpr int r = decltype(r_)::value;
@@ -286,7 +305,7 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
                 else read_a(af[AP ^ 1], nb, 0);
                 X6_SB();
             }
-            mma_tile(af[AP ^ (r & 1)], r_, bf);
+            if constexpr (TAIL16) mma_tile_tail(af[AP ^ (r & 1)], r_, bf); else mma_tile(af[AP ^ (r & 1)], r_, bf);
             work(r_);
             if constexpr (K > 0) X6_MIX(6 * DT, K);
             X6_SB();
@@ -302,6 +321,8 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
 #define PTR_X6_LATE 2
 #endif
     using Early = std::false_type;
+    using Full = std::false_type;
+    using Tail16 = std::bool_constant<PTR_X6_KTAIL != 0>;
     using LateE = std::bool_constant<TRAIN && PTR_X6_LATE != 0>;      // steps whose work is an epilogue
     using KNone = X6K<0, 0, 0, 0, 0, 0, 0>;
     auto nowork = [](auto) __attribute__((always_inline)) {};
@@ -423,8 +444,10 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
                 if constexpr (TRAIN) X6_SB();
 #endif
                 if (mt == kMT - 1) {
+#if !PTR_X6_KTAIL       /* (the 16-deep tail slice never reads the second half of these fragments) */
 #pragma unroll
                     for (int p = 0; p < 3; ++p) { bp[3][dt][p].u[2] = 0u; bp[3][dt][p].u[3] = 0u; }
+#endif
                     // feature 100 (lane group 1, element 0; its activation is exactly 0) = 1.0: the slot the weight image keeps the bias in
                     bp[3][dt][0].u[0] |= g == 1 ? 0x3F80u : 0u;
                 }
@@ -468,7 +491,7 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
                 } else {                            // eight quarters: two beside tile 0, one beside each other tile
                     if constexpr (r == 0) { quarter(0); quarter(1); } else quarter(r + 1);
                 }
-            }, std::conditional_t<DT == 2, X6K<KX, KX, 0, KX, KX, 0, 0>, X6K<KX, KX / 2, KX / 2, KX / 2, KX / 2, KX / 2, KX / 2>>{}, Early{});
+            }, std::conditional_t<DT == 2, X6K<KX, KX, 0, KX, KX, 0, 0>, X6K<KX, KX / 2, KX / 2, KX / 2, KX / 2, KX / 2, KX / 2>>{}, Early{}, Full{});
         };
         // the last slice of layer 1: the epilogue of a tile rides beside the MFMAs of the next one
         auto l1_last = [&](auto par_) __attribute__((always_inline)) {
@@ -476,7 +499,7 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
             abase = slice_step(par_, abase, bfx[PAR], [&](auto r_) __attribute__((always_inline)) {
                 constexpr int r = decltype(r_)::value;
                 if constexpr (r > 0) epilogue(std::integral_constant<int, r - 1>{}, 1);
-            }, X6K<0, KE, KE, KE, KE, KE, KE>{}, LateE{});
+            }, X6K<0, KE, KE, KE, KE, KE, KE>{}, LateE{}, Full{});
             epilogue(std::integral_constant<int, kMT - 1>{}, 1);
             if constexpr (PAR == 0) {               // an odd number of layer-1 slices: the hidden layers expect the next A fragment in set 0
 #pragma unroll
@@ -492,8 +515,8 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
         // ---- hidden layers 2 .. NL: B fragments = the registers the previous epilogue left
         auto hidden = [&](auto lastlayer_, int l) __attribute__((always_inline)) {
             constexpr bool LAST = decltype(lastlayer_)::value;
-            abase = slice_step(I0{}, abase, bp[0], nowork, KNone{}, Early{});
-            abase = slice_step(I1{}, abase, bp[1], nowork, KNone{}, Early{});
+            abase = slice_step(I0{}, abase, bp[0], nowork, KNone{}, Early{}, Full{});
+            abase = slice_step(I1{}, abase, bp[1], nowork, KNone{}, Early{}, Full{});
 #ifndef PTR_X6_XLOAD_POS
 #define PTR_X6_XLOAD_POS 0          /* where the next tile's first X loads are issued: 0 behind the layer's second slice step (r4/r5), 1 behind its third, 2 inside its third (behind the SYNC) */
 #endif
@@ -509,9 +532,9 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
                 X6_SB();
             }
             if constexpr (LAST && PTR_X6_XLOAD_POS == 2) {
-                abase = slice_step(I0{}, abase, bp[2], [&](auto r_) __attribute__((always_inline)) { if constexpr (decltype(r_)::value == 4) xloads(); }, KNone{}, Early{});
+                abase = slice_step(I0{}, abase, bp[2], [&](auto r_) __attribute__((always_inline)) { if constexpr (decltype(r_)::value == 4) xloads(); }, KNone{}, Early{}, Full{});
             } else {
-                abase = slice_step(I0{}, abase, bp[2], nowork, KNone{}, Early{});
+                abase = slice_step(I0{}, abase, bp[2], nowork, KNone{}, Early{}, Full{});
             }
             if constexpr (LAST && PTR_X6_XLOAD_POS == 1) {
                 xloads();
@@ -525,13 +548,13 @@ mlp_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
                     if constexpr (DT == 2) { if constexpr (r >= PTR_X6_XQ_R0 && r < PTR_X6_XQ_R0 + 4) quarter(r - PTR_X6_XQ_R0); }
                     else if constexpr (r < 4) { quarter(2 * r); quarter(2 * r + 1); }
                     if constexpr (r > 0) epilogue_out(std::integral_constant<int, r - 1>{});
-                }, X6K<KX, KX + 1, KX + 1, KX + 1, 1, 1, 1>{}, std::bool_constant<TRAIN && PTR_X6_LATE == 2>{});
+                }, X6K<KX, KX + 1, KX + 1, KX + 1, 1, 1, 1>{}, std::bool_constant<TRAIN && PTR_X6_LATE == 2>{}, Tail16{});
                 epilogue_out(std::integral_constant<int, kMT - 1>{});
             } else {
                 abase = slice_step(I1{}, abase, bp[3], [&](auto r_) __attribute__((always_inline)) {
                     constexpr int r = decltype(r_)::value;
                     if constexpr (r > 0) epilogue(std::integral_constant<int, r - 1>{}, l + 1);
-                }, X6K<0, KE, KE, KE, KE, KE, KE>{}, LateE{});
+                }, X6K<0, KE, KE, KE, KE, KE, KE>{}, LateE{}, Tail16{});
                 epilogue(std::integral_constant<int, kMT - 1>{}, l + 1);
             }
         };
