@@ -385,6 +385,20 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
         if (chain) {
 #endif
             const f32x4 wo4 = *reinterpret_cast<lds_f32x4_b *>((uintptr_t)(b6_opaque(lds0 + (uint32_t)(kB6_WO + 64 * W)) + (uint32_t)(16 * g)));
+#ifndef PTR_B6_STAGE_PRELOAD
+#define PTR_B6_STAGE_PRELOAD 0        /* experiment: both document tiles' staging-area reads issued up front (r5 / default: tile by tile — the second tile's reads wait behind the first tile's stores) */
+#endif
+#if PTR_B6_STAGE_PRELOAD
+            f32x4 pre[2][3];
+            {
+                const uint32_t so0 = b6_opaque(lds0 + (uint32_t)(kB6_ST + 1024 * W)) + (uint32_t)(j * 64 + 16 * g);
+#pragma unroll
+                for (int dt = dt0; dt < dt1; ++dt)
+#pragma unroll
+                    for (int l = 0; l < 3; ++l) pre[dt][l] = *reinterpret_cast<lds_f32x4_b *>((uintptr_t)(so0 + (uint32_t)(dt * kActTile * 4 + l * kB6STG)));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
 #pragma unroll
             for (int dt = dt0; dt < dt1; ++dt) {
                 // the staging area is a straight copy of two tile-major row tiles (ptr_mlp.h): feature tile W of row tile dt at dt * 7168 + W * 1024, lane (j, g) at j * 64 + 16 g
@@ -392,6 +406,9 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
 #ifdef PTR_B6_ABL_ST_NOREAD     // timing-only ablations of the staging pass (wrong results): no staging-area reads / no mask bits / no A1, A2 image stores
                 f32x4 a1 = wo4, a2 = wo4, a3 = wo4;
                 asm volatile("" : "+v"(a1), "+v"(a2), "+v"(a3));
+#elif PTR_B6_STAGE_PRELOAD
+                const f32x4 a1 = pre[dt][0], a2 = pre[dt][1], a3 = pre[dt][2];
+                (void)so;
 #else
                 const f32x4 a1 = *reinterpret_cast<lds_f32x4_b *>((uintptr_t)so);
                 const f32x4 a2 = *reinterpret_cast<lds_f32x4_b *>((uintptr_t)(so + kB6STG));

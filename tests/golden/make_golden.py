@@ -482,8 +482,26 @@ def gen_metrics():
     print(f"metrics.npz: {len(store)} arrays")
 
 
+def gen_long():
+    """r6: reference outputs of LambdaRank on LONG lists — 3x384 and 2x512 (the ring kernel's one-wave-per-SIMD form, lambdarank_ring_kernel<8>),
+    2x700 and 1x1251 (the LDS kernel; 1 251 documents is MSLR-WEB30K's longest list, data_utils.py:118-123) — on the MSLR label mix, whose
+    grade-0 tail fills whole 64-document slots (the blocks the ring kernel skips).  A file of its own: the older files stay byte-identical."""
+    store = {}
+    rng = np.random.default_rng(SEED + 23)
+    torch.manual_seed(SEED + 23)
+    for tag, (B, L) in (("L_3x384", (3, 384)), ("L_2x512", (2, 512)), ("L_2x700", (2, 700)), ("L_1x1251", (1, 1251))):
+        preds, labels = synth(rng, B, L)
+        loss, grad = run_loss(LambdaRank(sf_para_dict=SF, model_para_dict={"sigma": 1.0}, device="cpu"), preds, labels)
+        add(store, f"lambdarank/{tag}", preds=preds, labels=labels, sigma=np.float32(1.0), loss=loss, grad=grad,
+            sort_idx=pred_sort_idx(preds))
+    np.savez_compressed(os.path.join(HERE, "losses_long.npz"), **store)
+    print(f"losses_long.npz: {len(store)} arrays")
+
+
 if __name__ == "__main__":
-    if "--only-big" in sys.argv:
+    if "--only-long" in sys.argv:
+        gen_long()
+    elif "--only-big" in sys.argv:
         gen_big()
     elif "--only-knife" in sys.argv:
         gen_knife()
@@ -495,4 +513,5 @@ if __name__ == "__main__":
         gen_siblings()
         gen_big()
         gen_knife()
+        gen_long()
     print("torch", torch.__version__, "numpy", np.__version__)

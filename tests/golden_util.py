@@ -55,11 +55,11 @@ _CACHE = {}
 
 
 def losses():
-    """losses.npz (edge cases, small shapes) merged with losses_big.npz (reference outputs at BASELINE.json's config shapes) and
-    losses_knife.npz (the sigmoid-saturation band, reference outputs)."""
+    """losses.npz (edge cases, small shapes) merged with losses_big.npz (reference outputs at BASELINE.json's config shapes),
+    losses_knife.npz (the sigmoid-saturation band, reference outputs) and losses_long.npz (r6: LambdaRank on lists of 384 .. 1 251 documents)."""
     if "l" not in _CACHE:
         d = _load("losses.npz")
-        for extra in ("losses_big.npz", "losses_knife.npz"):       # reference outputs at BASELINE's shapes; the sigmoid-saturation knife edge
+        for extra in ("losses_big.npz", "losses_knife.npz", "losses_long.npz"):       # reference outputs at BASELINE's shapes; the sigmoid-saturation knife edge
             if os.path.exists(os.path.join(GOLDEN_DIR, extra)):
                 for fam, cases in _load(extra).items():
                     d.setdefault(fam, {}).update(cases)
