@@ -73,6 +73,26 @@ def metrics():
     return _CACHE["m"]
 
 
+def steps():
+    """step.npz (r6): the reference's own rankers run for three whole train steps (tests/golden/make_golden_step.py): {case: {field: array}} with
+    nested keys 'sd0/<param>', 'sd3/<param>', 'X', 'Y', 'losses'."""
+    if "st" not in _CACHE:
+        z = np.load(os.path.join(GOLDEN_DIR, "step.npz"), allow_pickle=False)
+        d = defaultdict(dict)
+        for key in z.files:
+            case, field = key.split("/", 1)
+            d[case][field] = z[key]
+        _CACHE["st"] = dict(d)
+    return _CACHE["st"]
+
+
+STEP_CASES = {"lambdarank_6x40": ("LambdaRank", dict(sigma=1.0), "lambdarank_loss", dict(sigma=1.0)),
+              "lambdarank_4x128": ("LambdaRank", dict(sigma=1.0), "lambdarank_loss", dict(sigma=1.0)),
+              "ranknet_8x32": ("RankNet", dict(sigma=1.0), "ranknet_loss", dict(sigma=1.0)),
+              "listnet_4x256": ("ListNet", None, "listnet_loss", {}),
+              "lambdaloss_4x64": ("LambdaLoss", dict(k=5, sigma=1.0, mu=5.0, loss_type="NDCG_Loss2"), "lambdaloss_loss", dict(k=5, sigma=1.0, mu=5.0, loss_type=1))}
+
+
 def siblings():
     if "s" not in _CACHE:
         _CACHE["s"] = _load("siblings.npz")

@@ -267,3 +267,22 @@ def test_mdprank_oracles(name):
     G.assert_close(loss.numpy(), c["loss"], "torch loss"); G.assert_close(grad.numpy(), c["grad"], "torch grad")
     lq, g = CO.mdprank(c["preds"], c["labels"], c["perm"], top_k=tk, gamma=float(c["gamma"]))
     G.assert_close(lq.astype(np.float64).sum(), c["loss"], "C loss"); G.assert_close(g, c["grad"], "C grad")
+
+
+@pytest.mark.parametrize("name", sorted(G.STEP_CASES))
+def test_train_step_restatement_reproduces_the_reference_itself(name):
+    """r6: oracle/torch_ref.py's restatement of the WHOLE train step (scorer forward -> loss -> zero_grad / backward / Adam step) against three steps of
+    the reference's own ranker objects (tests/golden/step.npz: NeuralRanker.init + train_op, ranker.py:512-525,589-603, run by make_golden_step.py)."""
+    c = G.steps()[name]
+    _, _, loss_fn, okw = G.STEP_CASES[name]
+    X, Y = torch.from_numpy(c["X"]), torch.from_numpy(c["Y"])
+    net = T.build_pointsf(X.shape[2], dropout=0.0)
+    net.load_state_dict({k[len("sd0/"):]: torch.from_numpy(v) for k, v in c.items() if k.startswith("sd0/")})
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-3)
+    for step in range(3):
+        got = T.cpu_train_step(net, opt, X, Y, getattr(T, loss_fn), **okw)
+        G.assert_close(got, c["losses"][step], f"loss of step {step}")
+    for k, v in net.state_dict().items():
+        if k == "ff_5.bias":
+            continue        # every loss here is shift-invariant: this gradient is identically 0 and Adam turns rounding noise into +-lr moves
+        assert np.allclose(v.numpy(), c[f"sd3/{k}"], rtol=1e-4, atol=2e-5), k

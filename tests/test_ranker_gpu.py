@@ -358,3 +358,68 @@ def test_train_step_descriptor_is_checked():
     d.B, d.L, d.loss_kind = 1, 8, 9
     with pytest.raises(RuntimeError, match="unknown loss"):
         _lib.call("ptr_train_step", C.addressof(d), None)
+
+
+@pytest.mark.parametrize("opt", ["Adagrad", "RMS"])
+def test_weight_image_hand_over_with_the_other_flat_optimisers(opt, monkeypatch):
+    """The optimiser launch refreshes the bf16x6 weight image behind an Adagrad / RMSprop step as it does behind Adam's (ptranking/base/ranker.py:516-521
+    `opt` choices): four back-to-back steps of the one-call path (image handed over from the second step on) against the three-call path, bit for bit."""
+    import ptranking_amd as pa
+    monkeypatch.setenv("PTR_MLP_X6", "2")
+    sf = copy.deepcopy(SF)
+    sf["opt"] = opt
+    sf["pointsf"].update(num_features=136, dropout=0.1)
+
+    def make(single):
+        torch.manual_seed(21)
+        r = pa.LambdaRank(sf_para_dict=copy.deepcopy(sf), model_para_dict=dict(sigma=1.0), gpu=True, device="cuda:0")
+        r.init(); r.point_sf.dropout = 0.1; r.train_mode()
+        r.single_call_step = single
+        return r
+
+    X, Y = make_data(8, 17, 128, 136)
+    X, Y = X.cuda(), Y.cuda()
+    kw = dict(epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
+    a = make(True)
+    cur, la = [], []
+    for i in range(4):                                            # a's steps back to back: nothing else touches the shared image in between
+        torch.manual_seed(400 + i)
+        la.append(a.train_op(X, Y, **kw)[0].clone())
+        cur.append(int(next(iter(a._direct_buffers.values()))["desc"].wimg_current))
+    assert cur == [0, 1, 1, 1], cur
+    c = make(False)
+    for i in range(4):
+        torch.manual_seed(400 + i)
+        lc = c.train_op(X, Y, **kw)[0]
+        assert torch.equal(la[i], lc), (opt, i)
+    assert type(a.optimizer).__name__ == {"Adagrad": "FlatAdagrad", "RMS": "FlatRMSprop"}[opt]
+    assert torch.equal(a.point_sf.flat, c.point_sf.flat)
+
+
+@pytest.mark.parametrize("name", sorted(G.STEP_CASES))
+def test_train_steps_match_the_reference_itself(name):
+    """r6: three whole train steps of the product path — fused scorer kernels, fused loss + gradient kernel, fused backward / Adam, enqueued by
+    ptr_train_step — against the REFERENCE's own ranker objects run for three steps on the same weights and batch (tests/golden/step.npz, produced by
+    tests/golden/make_golden_step.py: NeuralRanker.init + train_op, ranker.py:512-525,589-603; dropout 0).  Losses within the golden gates; the
+    parameters after three Adam steps within 1e-4 relative / 2e-5 absolute (Adam divides by sqrt(v): rounding noise on near-zero gradients moves a
+    coordinate by up to lr)."""
+    import ptranking_amd as pa
+    c = G.steps()[name]
+    cls_name, paras, _, _ = G.STEP_CASES[name]
+    X, Y = torch.from_numpy(c["X"]).cuda(), torch.from_numpy(c["Y"]).cuda()
+    sf = copy.deepcopy(SF)
+    sf["pointsf"].update(num_features=int(X.shape[2]), dropout=0.0)
+    cls = getattr(pa, cls_name)
+    r = cls(sf_para_dict=sf, gpu=True, device="cuda:0") if paras is None else cls(sf_para_dict=sf, model_para_dict=dict(paras), gpu=True, device="cuda:0")
+    r.init()
+    r.point_sf.load_state_dict({k[len("sd0/"):]: torch.from_numpy(v).cuda() for k, v in c.items() if k.startswith("sd0/")})
+    r.train_mode()
+    for step in range(3):
+        loss, stop = r.train_op(X, Y, epoch_k=1, presort=True, label_type=pa.LABEL_TYPE.MultiLabel)
+        assert stop is False
+        G.assert_close(loss.item(), c["losses"][step], f"loss of step {step}")
+    assert "desc" in next(iter(r._direct_buffers.values())), "the one-call step must be the path taken"
+    for k, v in r.point_sf.state_dict().items():
+        if k == "ff_5.bias":
+            continue
+        assert np.allclose(v.detach().cpu().numpy(), c[f"sd3/{k}"], rtol=1e-4, atol=2e-5), k
