@@ -119,6 +119,12 @@ __device__ __forceinline__ uint32_t b6_opaque(uint32_t x) { asm volatile("" : "+
 #ifndef PTR_B6_CHAIN_ORDER
 #define PTR_B6_CHAIN_ORDER 0
 #endif
+#ifndef PTR_B6_EPI_MIX
+#define PTR_B6_EPI_MIX 0              /* r6 experiment: the chain's epilogue (gating, split, image stores) issued BETWEEN the dW row's MFMAs (2-3 VALU per MFMA) instead of in front of them */
+#endif
+#ifndef PTR_B6_EPI_K
+#define PTR_B6_EPI_K 3
+#endif
 #ifndef PTR_B6_W7_ILV
 #define PTR_B6_W7_ILV 0               /* experiment: wave 7's two tiles of a row as one interleaved stream (no back-to-back MFMAs on one accumulator) */
 #endif
@@ -516,6 +522,41 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
                 }
                 B6_STAMP2();                                      // chain MFMAs issued
                 const uint32_t m = c == 0 ? m2 : m1;
+#if PTR_B6_EPI_MIX
+                if (!(TAIL && c == 1)) {
+                    // the epilogue rides between the MFMAs of the dW row: tile n's six MFMAs carry chunk n — gating of document tile 0 | its split + image
+                    // stores | gating of tile 1 | its split + stores | (nothing)
+                    BFrag za[3], ab[2][3];
+                    f32x4 dz = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const bool pipe = c != PTR_B6_X_PHASE;          // (compile-time after unrolling) the phase with X in flight has no registers for a fragment ahead
+                    read_tr(za, zin + tr_z + (uint32_t)(32 * W), kB6ZPL, kB6ZRS, 0);
+                    if (pipe) read_tr(ab[0], aim + tr_z, kB6ZPL, kB6ZRS, 0);
+#pragma unroll
+                    for (int n = 0; n < 5; ++n) {
+                        if (pipe) { if (n + 1 < 5) read_tr(ab[(n + 1) & 1], aim + tr_z, kB6ZPL, kB6ZRS, n + 1); }
+                        else read_tr(ab[0], aim + tr_z, kB6ZPL, kB6ZRS, n);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mma6(st[5 * c + n], za, ab[pipe ? (n & 1) : 0]);
+                        if (n < 4) {
+                            const int dt = n >> 1;
+                            if ((n & 1) == 0) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) dz[r] = (m >> (4 * dt + r)) & 1u ? cc[dt][r] * scale : 0.0f;
+                            } else {
+                                b6_write4(zout + wr_z + (uint32_t)(16 * dt * kB6ZRS), kB6ZPL, dz);
+                            }
+#pragma unroll
+                            for (int i_ = 0; i_ < 6; ++i_) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x002, PTR_B6_EPI_K, 0);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    B6_STAMP2();
+                    return;
+                }
+#endif
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
                     f32x4 dz;
@@ -532,6 +573,9 @@ mlp_bwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ P, cons
               };
               // dW of the layer whose dZ is the chain's INPUT: row w, in-tiles 0..4 of the activations below it
               auto dw_part = [&]() __attribute__((always_inline)) {
+#if PTR_B6_EPI_MIX
+                if (!(TAIL && c == 1)) return;                   // (done inside chain_part, interleaved with the epilogue)
+#endif
                 if (c == 0) dw_row(std::integral_constant<int, 5>{}, std::bool_constant<PTR_B6_X_PHASE != 0 || PTR_B6_PIPE_C2 != 0>{}, 0, zin, W, aim + tr_z, kB6ZPL, kB6ZRS, 0);
                 else dw_row(std::integral_constant<int, 5>{}, std::bool_constant<PTR_B6_X_PHASE != 1 || PTR_B6_PIPE_C2 != 0>{}, 5, zin, W, aim + tr_z, kB6ZPL, kB6ZRS, 0);
               };
