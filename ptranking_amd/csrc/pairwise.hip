@@ -244,7 +244,7 @@ static int launch_pairwise(const float *preds, const float *labels, const int32_
         const int dpt = L <= 64 ? 1 : L <= 128 ? 2 : L <= 256 ? 4 : 8;
         int QPB = ring_waves();
         if (!QPB) { QPB = kRingBlock / kWave; while (QPB > 1 && B < QPB * ring_num_cus()) QPB >>= 1; }
-        if (dpt >= 4 && QPB > 8) QPB = 8;
+        if (dpt >= 4 && QPB > PTR_RING4_WAVES) QPB = PTR_RING4_WAVES;
         if (dpt >= 8 && QPB > 4) QPB = 4;
         if (dpt < 8) {                            // pairwise_ring.hip
             if (int e = launch_lambdarank_ring_small(dpt, QPB, preds, labels, lens, B, L, sigma, loss_q, grad, st)) return check_hip((hipError_t)e, who);

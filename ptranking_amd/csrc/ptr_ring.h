@@ -138,7 +138,10 @@ __device__ __forceinline__ void ring_pairs(const float (&si)[DPT], const float (
 // 128-register cap of a 16-wave block it spilled 25 of them to scratch (PMC: 348 MB of HBM traffic per 65 536 queries against 202 MB
 // algorithmic); 3 waves per SIMD without spills run as fast as 4 with them.
 constexpr int kRingBlock = 1024;
-template <int DPT> constexpr int ring_block() { return DPT >= 8 ? 256 : DPT >= 4 ? 512 : kRingBlock; }      // DPT = 8: one wave per SIMD — 128 record registers + the temporaries of 64 blocks per step need more than the 256 of an 8-wave block (163 spills there)
+#ifndef PTR_RING4_WAVES
+#define PTR_RING4_WAVES 8          // waves per workgroup of the DPT = 4 kernel (experiment: 16 = the 128-register cap)
+#endif
+template <int DPT> constexpr int ring_block() { return DPT >= 8 ? 256 : DPT >= 4 ? 64 * PTR_RING4_WAVES : kRingBlock; }      // DPT = 8: one wave per SIMD — 128 record registers + the temporaries of 64 blocks per step need more than the 256 of an 8-wave block (163 spills there)
 template <int DPT>
 __global__ void __launch_bounds__(ring_block<DPT>())
 lambdarank_ring_kernel(const float *__restrict__ preds, const float *__restrict__ labels, const int32_t *__restrict__ lens,
