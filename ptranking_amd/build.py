@@ -15,8 +15,8 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 OBJ_DIR = os.path.join(PKG_DIR, "csrc", "build")
 LIB_PATH = os.path.join(PKG_DIR, "libptranking_amd.so")
 ARCH = "gfx950"
-SOURCES = ["abi.hip", "pairwise.hip", "pairwise_ring.hip", "lambdaloss.hip", "approxndcg.hip", "listwise.hip", "metrics.hip", "scorer.hip", "scorer_bwd.hip", "scorer_x6.hip", "scorer_bwd_x6.hip", "scorer_dw_x6.hip", "linear.hip", "linear_bw_x6.hip", "bnact.hip", "listsf.hip", "train_step.hip", "letor.cpp"]
-HEADERS = ["ptr_device.h", "ptr_dropout.h", "ptr_mlp.h", "ptr_ring.h", os.path.join("..", "..", "include", "ptranking_amd.h")]
+SOURCES = ["abi.hip", "pairwise.hip", "pairwise_ring.hip", "lambdaloss.hip", "approxndcg.hip", "listwise.hip", "metrics.hip", "scorer.hip", "scorer_bwd.hip", "scorer_x6.hip", "scorer_bwd_x6.hip", "scorer_dw_x6.hip", "linear.hip", "linear_x6.hip", "linear_bw_x6.hip", "bnact.hip", "listsf.hip", "train_step.hip", "letor.cpp"]
+HEADERS = ["ptr_device.h", "ptr_dropout.h", "ptr_mlp.h", "ptr_ring.h", "ptr_linear.h", os.path.join("..", "..", "include", "ptranking_amd.h")]
 CXXFLAGS = ["-O3", "-std=c++20", "-fPIC", "-fno-gpu-rdc", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
             "-ffp-contract=off"]
 

@@ -370,6 +370,18 @@ static int bn_blocks(int R) {
     int b = (R + 255) / 256;
     return b < 1 ? 1 : (b > 512 ? 512 : b);
 }
+// chunks of the BACKWARD sums (colsum2_kernel<1>): the pass evaluates AF'(y) (erf + exp for GELU) and the dropout hash per element, so it wants
+// more resident waves than the forward statistics (r6; PTR_BN_BWD_BLOCKS overrides the cap for measurements)
+static int bn_blocks_bwd_cap() {
+    static int cap = 0;
+    if (!cap) { const char *e = getenv("PTR_BN_BWD_BLOCKS"); cap = e ? atoi(e) : 0; if (cap < 1 || cap > 4096) cap = 512; }
+    return cap;
+}
+static int bn_blocks_bwd(int R) {
+    int b = (R + 63) / 64;
+    const int cap = bn_blocks_bwd_cap();
+    return b < 1 ? 1 : (b > cap ? cap : b);
+}
 
 static int check_bnact(const char *who, int R, int N, int ld, int af, float p) {
     if (R < 0 || N <= 0 || ld < N) { set_error("%s: bad shape R=%d N=%d ld=%d", who, R, N, ld); return PTR_ERR_INVALID_ARG; }
@@ -383,7 +395,7 @@ static int check_bnact(const char *who, int R, int N, int ld, int af, float p) {
 // group_rows: 0 = statistics over all R rows (LTRBatchNorm); L > 0 = per group of L consecutive rows (per query, LTRBatchNorm2; R % L == 0)
 // layout: [blocks][2][N] partials | [2][N] totals (backward) | [blocks] real rows per chunk | [4] total real rows (padded batches)
 extern "C" size_t ptr_bn_ws_floats(int R, int N, int group_rows) {
-    const size_t blocks = group_rows > 0 ? (size_t)(R / group_rows) : (size_t)ptr::bn_blocks(R);
+    const size_t blocks = group_rows > 0 ? (size_t)(R / group_rows) : (size_t)std::max(ptr::bn_blocks(R), ptr::bn_blocks_bwd(R));
     return blocks * 2 * (size_t)N + 2 * (size_t)N + blocks + 4;
 }
 
@@ -466,7 +478,7 @@ extern "C" int ptr_bnact_backward(const float *z, const float *da, int ld, int R
     const bool v4 = vec4_ok(N, ld, z, da, dz, ws, mean, rstd, gamma, beta, dgamma, dbeta);
     float *total_real = nullptr;
     if (mean) {
-        const int nb = a.group > 0 ? R / a.group : bn_blocks(R);
+        const int nb = a.group > 0 ? R / a.group : bn_blocks_bwd(R);
         // totals over all rows: straight into dbeta / dgamma when the caller wants them
         float *tot_dy = dbeta ? dbeta : ws + (size_t)nb * 2 * N, *tot_dyx = dgamma ? dgamma : ws + (size_t)nb * 2 * N + N;
         float *counts = (lens && a.group == 0) ? ws + (size_t)nb * 2 * N + 2 * (size_t)N : nullptr;

@@ -22,18 +22,10 @@
 
 #include "ptr_device.h"
 #include "ptr_dropout.h"
+#include "ptr_linear.h"
 
 namespace ptr {
 
-
-struct LinArgs {
-    int R, K, N;
-    int ldx, ldy, ldg;           // leading dimensions (floats) of X, Y and the gate
-    int act;                     // PTR_LINEAR_* epilogue
-    float p_drop;
-    uint32_t seed_lo, seed_hi;
-    int site;
-};
 
 __host__ __device__ inline int lin_ldk(int K) { return (K + 3) / 4 * 4 + 4; }
 
@@ -483,6 +475,11 @@ static int launch_linear(const float *X, int ldx, const float *W, const float *b
     if (!X || !W || !Y || (act == PTR_LINEAR_GATE && !gate)) { set_error("%s: NULL pointer", who); return PTR_ERR_INVALID_ARG; }
     if (!(p_drop >= 0.0f && p_drop < 1.0f)) { set_error("%s: dropout p=%g out of [0,1)", who, (double)p_drop); return PTR_ERR_INVALID_ARG; }
     if (R == 0) return 0;
+    {   // r6: the bf16x6 form of the same product (linear_x6.hip) where it serves the shape
+        const LinArgs ax{R, K, N, ldx, ldy, ldg, act, p_drop, (uint32_t)seed, (uint32_t)(seed >> 32), site};
+        const int rc = launch_linear_x6(TRANS, X, W, bias, gate, ax, Y, lin_num_cus(), st, who);
+        if (rc >= 0) return rc;
+    }
     // 16 waves x 16-row tiles (4 waves per SIMD; <= 128 VGPRs) or, PTR_LIN_WIDE=0, the round-2 form 8 waves x 32-row tiles
     static const int wide = [] { const char *e = getenv("PTR_LIN_WIDE"); return e ? atoi(e) != 0 : 1; }();
     int MT, nby;

@@ -251,3 +251,99 @@ def test_weight_gradient_bf16x6_reads_strided_rows(K, N, monkeypatch):
     ref_w = dy.double().cpu().t() @ x.double().cpu()
     close(dw, ref_w, tol=2e-5, what="dw")
     close(db, dy.double().cpu().sum(0), tol=2e-5, what="db")
+
+
+# ---- r6: forward / backward-input on the bf16 instructions (csrc/linear_x6.hip; default for K <= 256 in 16-byte rows from 1024 rows on; PTR_LIN_X6=0 selects
+# the fp32-MFMA kernel, =2 the general form where the default takes the whole-tile form)
+X6_LIN_RATIO = 1.1      # bf16x6 error against float64 may be this much above the fp32-MFMA kernel's ... (measured 0.9-1.05, printed below)
+X6_LIN_FLOOR = 2e-6     # ... plus this much of the tensor's maximum
+
+
+def _x6_lin_err(out, ref):
+    return float((out.double().cpu() - ref).abs().max())
+
+
+@pytest.mark.parametrize("R,K,N", [(4133, 136, 136), (2049, 136, 408), (1024, 100, 100), (70003, 100, 100), (3000, 128, 256), (1500, 136, 128), (5000, 112, 112),
+                                   (2500, 144, 144), (1777, 64, 100), (1200, 200, 136), (3001, 256, 96), (66000, 36, 200), (1030, 16, 64), (2000, 132, 120)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_linear_forward_bf16x6_matches_float64_and_the_fp32_kernel(R, K, N, act, monkeypatch):
+    """Y = epi(X W^T + b) through `ptr_linear_forward`: the bf16x6 kernels (whole-tile form: K16 in {112, 128, 144} with 7-9 output tiles; general form: the
+    rest, incl. 1-3 blocks of outputs, a 16-deep tail or none, a ragged last tile) against float64 and against the fp32-MFMA kernel — same dropout mask
+    (counter-based: a function of (seed, site, row, column)), every entry written, error not above the fp32 kernel's."""
+    from ptranking_amd.linear import _fwd
+    torch.manual_seed(R + K + N + act)
+    x = torch.randn(R, K, device="cuda")
+    w = torch.randn(N, K, device="cuda") / K ** 0.5
+    b = torch.randn(N, device="cuda")
+    z = x.double().cpu() @ w.double().cpu().t() + b.double().cpu()
+    p = 0.25 if act == 2 else 0.0
+    out = {}
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("PTR_LIN_X6", mode)
+        y = _fwd(x, K, w, b, act=act, p=p, seed=1234, site=3)
+        torch.cuda.synchronize()
+        assert torch.isfinite(y).all(), mode
+        out[mode] = y
+    if act == 0:
+        ref = z
+    else:
+        ref = z.clamp(min=0.0)
+        if act == 2:   # the kernel's own mask: kept entries are scaled by 1 / (1 - p), and the three forms must drop the same ones
+            kept = out["0"].cpu() != 0
+            for mode in ("1", "2"):
+                flips = (out[mode].cpu() != 0) != kept
+                assert float(ref[flips].abs().max() if flips.any() else 0.0) < 1e-5, "the forms drop different entries"
+            ref = torch.where(kept, ref / (1.0 - p), torch.zeros_like(ref))
+    s = max(1.0, float(ref.abs().max()))
+    e32 = _x6_lin_err(out["0"], ref)
+    for mode in ("1", "2"):
+        e6 = _x6_lin_err(out[mode], ref)
+        print(f"MEASURED linear fwd x6 R={R} K={K} N={N} act={act} mode={mode}: err {e6:.3e} fp32 {e32:.3e} ratio {e6 / max(e32, 1e-12):.2f}")
+        assert e6 <= X6_LIN_RATIO * e32 + X6_LIN_FLOOR * s, (mode, e6, e32, s)
+
+
+@pytest.mark.parametrize("R,K,N", [(4133, 136, 136), (1500, 128, 136), (1024, 100, 100), (70003, 100, 100), (3000, 256, 128), (2049, 136, 408), (1777, 100, 64),
+                                   (2500, 144, 144), (1200, 136, 200)])
+@pytest.mark.parametrize("gated", [False, True])
+def test_linear_backward_input_bf16x6_matches_float64_and_the_fp32_kernel(R, K, N, gated, monkeypatch):
+    """dX = (dY W) * [gate > 0] / (1 - p) through `ptr_linear_backward_input` (the same kernels on W^T; the gate read through a buffer resource): layer
+    K inputs -> N outputs, so the product contracts over N (<= 256 for the bf16x6 forms; 408 stays on the fp32 kernel in every mode)."""
+    from ptranking_amd.linear import _bwd_input
+    torch.manual_seed(R + K + N)
+    dy = torch.randn(R, N, device="cuda")
+    w = torch.randn(N, K, device="cuda") / K ** 0.5
+    gate = torch.randn(R, K, device="cuda") if gated else None
+    p = 0.1 if gated else 0.0
+    ref = dy.double().cpu() @ w.double().cpu()
+    if gated:
+        ref = ref * (gate.cpu() > 0).double() / (1.0 - p)
+    out = {}
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("PTR_LIN_X6", mode)
+        dx = _bwd_input(dy, w, gate=gate, p=p)
+        torch.cuda.synchronize()
+        assert torch.isfinite(dx).all(), mode
+        out[mode] = dx
+    s = max(1.0, float(ref.abs().max()))
+    e32 = _x6_lin_err(out["0"], ref)
+    for mode in ("1", "2"):
+        e6 = _x6_lin_err(out[mode], ref)
+        print(f"MEASURED linear bwd-input x6 R={R} K={K} N={N} gated={gated} mode={mode}: err {e6:.3e} fp32 {e32:.3e} ratio {e6 / max(e32, 1e-12):.2f}")
+        assert e6 <= X6_LIN_RATIO * e32 + X6_LIN_FLOOR * s, (mode, e6, e32, s)
+
+
+def test_linear_bf16x6_reads_strided_rows_and_is_bit_stable():
+    """X as a column slice of a wider matrix (ldx > K, 16-byte aligned), Y into a freshly allocated tensor; two launches give identical bits (the tile loop's
+    hand-counted loads: a miscounted wait would read a fragment before it arrives, and not the same way twice)."""
+    from ptranking_amd.linear import _fwd
+    torch.manual_seed(3)
+    big = torch.randn(9000, 200, device="cuda")
+    x = big[:, 32:168]                                    # 136 columns at a 128-byte offset, ldx = 200
+    w = torch.randn(136, 136, device="cuda") / 136 ** 0.5
+    b = torch.randn(136, device="cuda")
+    y1 = _fwd(x, 200, w, b)
+    y2 = _fwd(x, 200, w, b)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2)
+    ref = x.double().cpu() @ w.double().cpu().t() + b.double().cpu()
+    close(y1, ref, tol=5e-6, what="strided x6")
