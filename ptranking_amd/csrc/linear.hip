@@ -518,7 +518,7 @@ static int launch_linear(const float *X, int ldx, const float *W, const float *b
 // 27 TFLOP/s measured); N = 136 is 9 output tiles -> two blocks of MTO = 5.  MTO * NTW <= 24 accumulator tiles (96 registers) per wave.
 // linear_bw_x6.hip: the weight gradient on the bf16 instructions when one side of the product is narrow (plan 0 = not served)
 int lin_bw_x6_plan(int R, int K, int N, int ldx, int ldy, const void *X, const void *dY);
-int lin_bw_x6_chunks(int R);
+int lin_bw_x6_chunks(int R, int K, int N, int plan);
 int launch_lin_bw_x6(int plan, const float *X, int ldx, const float *dY, int ldy, int R, int K, int N, float *ws, int chunks, hipStream_t st, const char *who);
 
 static void bw_tiling(int K, int N, int &MTO, int &NTW) {
@@ -560,8 +560,8 @@ extern "C" int ptr_linear_backward_input(const float *dY, int ldy, const float *
 }
 
 extern "C" size_t ptr_linear_backward_weight_ws_floats(int R, int K, int N) {
-    // the larger of the two kernels' needs (the bf16x6 form, linear_bw_x6.hip, runs one row chunk per CU)
-    const int c32 = ptr::bw_chunks(R, K, N), c6 = (K <= 140 || N <= 144) ? ptr::lin_bw_x6_chunks(R) : 0;
+    // the larger of the two kernels' needs (the bf16x6 form, linear_bw_x6.hip, runs one or two row chunks per CU)
+    const int c32 = ptr::bw_chunks(R, K, N), c6 = (K <= 140 || N <= 144) ? ptr::lin_bw_x6_chunks(R, K, N, 0) : 0;
     return (size_t)(c32 > c6 ? c32 : c6) * ((size_t)N * K + N);
 }
 
@@ -579,7 +579,7 @@ extern "C" int ptr_linear_backward_weight(const float *X, int ldx, const float *
         return db ? check_hip(hipMemsetAsync(db, 0, N * sizeof(float), st), who) : 0;
     }
     if (const int plan = lin_bw_x6_plan(R, K, N, ldx, ldy, X, dY)) {
-        const int chunks6 = lin_bw_x6_chunks(R);
+        const int chunks6 = lin_bw_x6_chunks(R, K, N, plan);
         if (int e = launch_lin_bw_x6(plan, X, ldx, dY, ldy, R, K, N, ws, chunks6, st, who)) return e;
         hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, ws, chunks6, n, n, dW, nw, db);
         return check_hip(hipGetLastError(), who);

@@ -28,10 +28,12 @@ using lds_u32x2_l = __attribute__((address_space(3))) u32x2;
 using lds_i16x4_l = __attribute__((address_space(3))) i16x4;
 
 constexpr int kL6S = 32;                         // rows per slab
-constexpr int kL6CT = 24;                        // wide tiles per pass (384 columns)
-constexpr int kL6WRS = 800, kL6WPL = kL6S * kL6WRS;      // wide image: 768 B per row padded to 800 (= 32 mod 256: conflict-free transpose reads)
+constexpr int kL6CT = 24;                        // wide tiles per pass (384 columns); r6: CT = 8 (128 columns) for the products whose wide side is that small
+// wide image: 768 B per row padded to 800, or 256 padded to 288 (both = 32 mod 256: conflict-free transpose reads)
+__host__ __device__ constexpr int l6_wrs(int CT) { return CT == 24 ? 800 : 288; }
 __host__ __device__ constexpr int l6_nrs(int MT) { return MT == 9 ? 288 : 224; }             // narrow image row stride (bytes): 144 / 112 bf16, both = +-32 mod 256
-__host__ __device__ constexpr int l6_lds(int MT) { return 3 * kL6WPL + 3 * kL6S * l6_nrs(MT) + kL6S * 16 * MT * 4; }
+// CT = 8: the column-sum scratch of the epilogue lies over the wide image (dead by then) — 49 / 55 KB per workgroup, two workgroups per CU
+__host__ __device__ constexpr int l6_lds(int MT, int CT) { return 3 * kL6S * l6_wrs(CT) + 3 * kL6S * l6_nrs(MT) + (CT == 24 ? kL6S * 16 * MT * 4 : 0); }
 
 __device__ __forceinline__ uint32_t l6_cvt_pk(float x0, float x1) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{x0, x1}, bf16x2)); }
 __device__ __forceinline__ void l6_split2(float x0, float x1, uint32_t &p1, uint32_t &p2, uint32_t &p3) {      // round-to-nearest split, scorer_x6.hip
@@ -53,17 +55,21 @@ __device__ __forceinline__ void l6_write4(uint32_t addr, int plane_bytes, const 
 // Zn: the narrow operand [R][ldn], NN columns (+ a column of ones at index NN when `ones`); Aw: the wide operand [R][ldw], KW columns, this launch
 // covers its tiles tile0 .. tile0 + 23.  Element (o, k) of the product -> part[o * s_n + k * s_w] for o < NN, the ones row -> part[bias_off + k];
 // colsum != 0 (narrow = dY, first pass): the column sums of the narrow slab -> part[bias_off + o].
-template <int MT>
-__global__ void __launch_bounds__(512, 1)
+// r6, CT = 8: ONE wide tile per wave, <= 128 registers, two workgroups per CU.  The slab loop is stage (VALU split) -> barrier -> MFMAs -> barrier with the next
+// slab's loads in flight behind the first barrier; with one wide tile per wave the MFMA phase is 42-54 instructions and a slab took 3.2 us of which the matrix
+// pipe worked 0.3: a second workgroup per CU runs its stage while the first multiplies (default pointsf's 100 x 100 layers: 51 -> 3x us per call).
+template <int MT, int CT>
+__global__ void __launch_bounds__(512, CT == 24 ? 1 : 2)
 linear_bw_x6_kernel(const float *__restrict__ Zn, int ldn, int NN, int ones, const float *__restrict__ Aw, int ldw, int KW, int tile0, int ntp, int R,
                     float *__restrict__ ws, size_t ws_stride, size_t s_n, size_t s_w, size_t bias_off, int colsum) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_l6[];
     constexpr int NRS = l6_nrs(MT), NPL = kL6S * NRS;
-    constexpr int WW4 = kL6CT * 4;                         // float4 per wide-slice row (96)
-    constexpr int SW = kL6S * WW4 / 512;                   // wide load slots per thread (6)
+    constexpr int kL6WRS = l6_wrs(CT), kL6WPL = kL6S * kL6WRS, NWT = CT / 8;      // NWT: wide tiles per wave (W, W + 8, ..)
+    constexpr int WW4 = CT * 4;                            // float4 per wide-slice row (96 / 32)
+    constexpr int SW = kL6S * WW4 / 512;                   // wide load slots per thread (6 / 2)
     constexpr int ZW4 = 4 * MT;                            // float4 per narrow row (28 / 36)
     constexpr int SZ = (kL6S * ZW4 + 511) / 512;           // narrow load slots per thread (2 / 3)
-    constexpr int kW_ = 0, kZ_ = 3 * kL6WPL, kB_ = kZ_ + 3 * NPL;
+    constexpr int kW_ = 0, kZ_ = 3 * kL6WPL, kB_ = CT == 24 ? kZ_ + 3 * NPL : 0;
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, W = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int chunk = ((R + gridDim.x - 1) / gridDim.x + kL6S - 1) / kL6S * kL6S;
     const int r_begin = blockIdx.x * chunk, r_end = min(R, r_begin + chunk);
@@ -144,9 +150,9 @@ linear_bw_x6_kernel(const float *__restrict__ Zn, int ldn, int NN, int ones, con
     const uint32_t tr_w = lds0 + (uint32_t)(kW_ + (4 * g + (j >> 2)) * kL6WRS + 8 * (j & 3));
     const uint32_t tr_z = lds0 + (uint32_t)(kZ_ + (4 * g + (j >> 2)) * NRS + 8 * (j & 3));
 
-    f32x4 acc[3][MT];
+    f32x4 acc[NWT][MT];
 #pragma unroll
-    for (int n = 0; n < 3; ++n)
+    for (int n = 0; n < NWT; ++n)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[n][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -155,9 +161,9 @@ linear_bw_x6_kernel(const float *__restrict__ Zn, int ldn, int NN, int ones, con
         stage(r0);
         __syncthreads();
         if (r0 + kL6S < r_end) gload(r0 + kL6S);
-        LFrag xb[3][3];
+        LFrag xb[NWT][3];
 #pragma unroll
-        for (int n = 0; n < 3; ++n)
+        for (int n = 0; n < NWT; ++n)
             if (W + 8 * n < ntp) read_tr(xb[n], tr_w, kL6WPL, kL6WRS, W + 8 * n);        // wave-uniform: a wave multiplies only the tiles the pass holds
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -165,7 +171,7 @@ linear_bw_x6_kernel(const float *__restrict__ Zn, int ldn, int NN, int ones, con
             LFrag za[3];
             read_tr(za, tr_z, NPL, NRS, mt);
 #pragma unroll
-            for (int n = 0; n < 3; ++n) {
+            for (int n = 0; n < NWT; ++n) {
                 if (W + 8 * n >= ntp) continue;
                 f32x4 c = acc[n][mt];
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[0].v, xb[n][2].v, c, 0, 0, 0);
@@ -181,7 +187,7 @@ linear_bw_x6_kernel(const float *__restrict__ Zn, int ldn, int NN, int ones, con
     }
     float *part = ws + (size_t)blockIdx.x * ws_stride;
 #pragma unroll
-    for (int n = 0; n < 3; ++n) {
+    for (int n = 0; n < NWT; ++n) {
         const int k = col0 + 16 * (W + 8 * n) + j;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -222,19 +228,32 @@ int lin_bw_x6_plan(int R, int K, int N, int ldx, int ldy, const void *X, const v
     if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(dY)) & 15) return 0;
     const bool a_ok = N <= 144, b_ok = K <= 140;
     if (!a_ok && !b_ok) return 0;
-    if (a_ok && b_ok) {                                   // both narrow: hold the SMALLER one's companion as the wide stream (one pass either way up to 384)
+    if (a_ok && b_ok) {
+        // both narrow: r6 — the orientation whose WIDE side fits 128 columns runs the one-tile-per-wave form (two workgroups per CU); otherwise hold
+        // the SMALLER one's companion as the wide stream (one pass either way up to 384 columns)
+        if (K <= 128 && N <= K) return 1;
+        if (N <= 128 && K < N) return 2;
+        if (K <= 128) return 1;
+        if (N <= 128) return 2;
         return N <= K ? 1 : 2;
     }
     return a_ok ? 1 : 2;
 }
-int lin_bw_x6_chunks(int R) {
-    static const int ncu = [] {                          // one row chunk per CU (queried once: hipGetDeviceProperties is not a per-call cost)
+static int l6_num_cus() {
+    static const int ncu = [] {                          // queried once: hipGetDeviceProperties is not a per-call cost
         int dev = 0;
         hipDeviceProp_t pr;
         return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
     }();
-    const int maxc = (R + 255) / 256;
-    return maxc < ncu ? (maxc < 1 ? 1 : maxc) : ncu;
+    return ncu;
+}
+// the one-tile-per-wave form serves a product whose wide side (plan 1: X, plan 2: dY) has at most 128 columns
+static bool l6_small(int plan, int K, int N) { return (plan == 1 ? K : N) <= 128; }
+// row chunks (= partials): one per CU, two for the one-tile-per-wave form (two workgroups per CU); at least 256 rows each.  plan 0: the largest count any plan uses
+int lin_bw_x6_chunks(int R, int K, int N, int plan) {
+    const int per_cu = (plan == 0 || l6_small(plan, K, N)) ? 2 : 1;
+    const int maxc = (R + 255) / 256, want = per_cu * l6_num_cus();
+    return maxc < want ? (maxc < 1 ? 1 : maxc) : want;
 }
 
 int launch_lin_bw_x6(int plan, const float *X, int ldx, const float *dY, int ldy, int R, int K, int N, float *ws, int chunks, hipStream_t st, const char *who) {
@@ -244,11 +263,21 @@ int launch_lin_bw_x6(int plan, const float *X, int ldx, const float *dY, int ldy
     const int ones = plan == 2 ? 1 : 0;
     const size_t s_n = plan == 1 ? (size_t)K : 1, s_w = plan == 1 ? 1 : (size_t)K;
     const int mt = (NN + ones) <= 112 ? 7 : 9;
+    const int T = (KW + 15) / 16;
+    if (l6_small(plan, K, N)) {                           // one pass, one wide tile per wave
+        auto go8 = [&](auto kern, int MT) -> int {
+            const size_t lds = (size_t)l6_lds(MT, 8);
+            if (int e = allow_lds(kern, lds)) return e;
+            hipLaunchKernelGGL(kern, dim3(chunks), dim3(512), lds, st, Zn, ldn, NN, ones, Aw, ldw, KW, 0, T, R, ws, n, s_n, s_w, (size_t)N * K, plan == 1 ? 1 : 0);
+            return check_hip(hipGetLastError(), who);
+        };
+        return mt == 7 ? go8(linear_bw_x6_kernel<7, 8>, 7) : go8(linear_bw_x6_kernel<9, 8>, 9);
+    }
     auto go = [&](auto kern, int MT) -> int {
-        const size_t lds = (size_t)l6_lds(MT);
+        const size_t lds = (size_t)l6_lds(MT, kL6CT);
         if (int e = allow_lds(kern, lds)) return e;
         // balanced passes: ceil(T / 24) of them, each ceil(T / passes) tiles wide (26 tiles: 13 + 13, not 24 + 2)
-        const int T = (KW + 15) / 16, passes = (T + kL6CT - 1) / kL6CT, tpp = (T + passes - 1) / passes;
+        const int passes = (T + kL6CT - 1) / kL6CT, tpp = (T + passes - 1) / passes;
         for (int t0 = 0; t0 < T; t0 += tpp) {
             hipLaunchKernelGGL(kern, dim3(chunks), dim3(512), lds, st, Zn, ldn, NN, ones, Aw, ldw, KW, t0, T - t0 < tpp ? T - t0 : tpp, R, ws, n, s_n, s_w,
                                (size_t)N * K, (plan == 1 && t0 == 0) ? 1 : 0);
@@ -256,7 +285,7 @@ int launch_lin_bw_x6(int plan, const float *X, int ldx, const float *dY, int ldy
         }
         return 0;
     };
-    return mt == 7 ? go(linear_bw_x6_kernel<7>, 7) : go(linear_bw_x6_kernel<9>, 9);
+    return mt == 7 ? go(linear_bw_x6_kernel<7, kL6CT>, 7) : go(linear_bw_x6_kernel<9, kL6CT>, 9);
 }
 
 }  // namespace ptr
