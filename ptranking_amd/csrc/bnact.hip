@@ -69,6 +69,10 @@ __device__ __forceinline__ float af_bwd(int af, float y) {
     }
 }
 
+#ifndef PTR_BN_BWD_ROWS
+#define PTR_BN_BWD_ROWS 2
+#endif
+
 struct BnActArgs {
     int group;                   // rows per statistics group: 0 = one group (LTRBatchNorm, the whole batch), L = per query (LTRBatchNorm2)
     int R, N, ld;                // z / a / da are [R][N] with leading dimension ld
@@ -172,15 +176,19 @@ colsum2_kernel(const float *__restrict__ z, const float *__restrict__ da, const 
                 }
             };
             int r = r_begin + rl;
-            for (; r + 3 * rsub < r_end; r += 4 * rsub) {          // four independent rows in flight
-                vec zv[4], dv[4];
+            // independent rows in flight: four for the statistics; TWO for the backward sums (r6) — with four, AF'(y) and the dropout hash of four float4 pairs need
+            // 130 registers = three waves per SIMD, and a wave issues one instruction per ~5 cycles whatever its instruction-level parallelism (scratch/valu_rate):
+            // 66 registers = seven waves per SIMD hide the loads AND issue faster
+            constexpr int UR = MODE == 1 ? PTR_BN_BWD_ROWS : 4;
+            for (; r + (UR - 1) * rsub < r_end; r += UR * rsub) {
+                vec zv[UR], dv[UR];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < UR; ++u) {
                     zv[u] = ldv(z + (size_t)(r + u * rsub) * a.ld + c);
                     if constexpr (MODE == 1) dv[u] = ldv(da + (size_t)(r + u * rsub) * a.ld + c); else dv[u] = zv[u];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc(r + u * rsub, zv[u], dv[u]);
+                for (int u = 0; u < UR; ++u) acc(r + u * rsub, zv[u], dv[u]);
             }
             for (; r < r_end; r += rsub) {
                 const vec zv = ldv(z + (size_t)r * a.ld + c);
@@ -398,8 +406,8 @@ static int bn_blocks(int R) {
     int b = (R + 255) / 256;
     return b < 1 ? 1 : (b > 512 ? 512 : b);
 }
-// chunks of the BACKWARD sums (colsum2_kernel<1>): the pass evaluates AF'(y) (erf + exp for GELU) and the dropout hash per element, so it wants
-// more resident waves than the forward statistics (r6; PTR_BN_BWD_BLOCKS overrides the cap for measurements)
+// chunks of the BACKWARD sums (colsum2_kernel<1>; PTR_BN_BWD_BLOCKS overrides the cap for measurements).  r6 measured 512 / 2048 chunks with two / four rows in flight
+// at 131 072 x 100: 1.267 / 1.277 / 1.272 / 1.324 ms per default-pointsf step — more chunks cost the fixed-order reduction more than they give the sums
 static int bn_blocks_bwd_cap() {
     static int cap = 0;
     if (!cap) { const char *e = getenv("PTR_BN_BWD_BLOCKS"); cap = e ? atoi(e) : 0; if (cap < 1 || cap > 4096) cap = 512; }
