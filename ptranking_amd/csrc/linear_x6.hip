@@ -1,8 +1,8 @@
 // bf16x6 forward / backward-input of the tall-skinny linear layers (r6): Y[R][N] = epi(X[R][K] Wm^T + bias) with every fp32 product as six
 // v_mfma_f32_16x16x32_bf16 products on exactly split operands (fp32 accumulation, fp32 results — the arithmetic of scorer_x6.hip) instead of
 // v_mfma_f32_16x16x4_f32: the matrix time of a layer drops by 2.6x and the 136 / 100 / 128-wide layers of the listsf encoder and of the
-// layer-wise pointsf stack become bound by their X and Y streams.  Serves K <= 256 with 16-byte aligned rows; everything else stays on
-// linear.hip's fp32-MFMA kernel (launch_linear_x6 returns < 0).
+// layer-wise pointsf stack become bound by their X and Y streams.  Serves 16-byte aligned rows of any K (whole-K weight image in LDS up to 256 inputs, K in
+// chunks of 128 beyond); narrow outputs and small batches stay on linear.hip's fp32-MFMA kernel (launch_linear_x6 returns < 0).
 //
 // Reference: the nn.Linear modules of ptranking/base/utils.py:288-356 (`get_stacked_FFNet`) and ptranking/base/list_ranker.py:176-254,303-350
 // (encoder projections, head / tail feed-forward stacks) and their autograd backward w.r.t. the input.
@@ -72,8 +72,9 @@ constexpr int kLxA[6] = {0, 1, 2, 0, 1, 0}, kLxB[6] = {2, 1, 0, 1, 0, 0};
 // 8..15) — any assignment works as long as both operands use it, and with this one a wave's X load covers 64 contiguous bytes per document.
 // Element (row r, k): s SL + p PL + (r / 16) 1024 + ((k % 16) / 4) 256 + (r % 16) 16 + ((k % 32) / 16) 8 + 2 (k % 4); in the 16-deep tail step lane (j, g) owns
 // k = 4 g .. 4 g + 3: nfull SL + p PL + (r / 16) 1024 + ((k % 32) / 4) 128 + (r % 16) 8 + 2 (k % 4).
+// c0 (chunked form): the image holds the k-steps from k = 4 c0 on; nfull / nsteps count the steps of the image.
 template <int MT, bool TRANS>
-__device__ __forceinline__ void lx_stage(const float *__restrict__ W, const float *__restrict__ bias, int K, int N, int n0, int nfull, int nsteps, uint8_t *smem) {
+__device__ __forceinline__ void lx_stage(const float *__restrict__ W, int K, int N, int n0, int nfull, int nsteps, uint8_t *smem, int c0 = 0) {
     constexpr int PL = MT * 1024, SL = 3 * PL;
     const int rows = min(16 * MT, N - n0), tid = threadIdx.x;
     const int k4 = nsteps * 8, n4 = 16 * MT * k4;            // 16-byte groups of four k per row (the tail step: only its first four hold data)
@@ -86,12 +87,13 @@ __device__ __forceinline__ void lx_stage(const float *__restrict__ W, const floa
             const int idx = min(base + u * kLxNT, n4 - 1);
             if constexpr (!TRANS) { r[u] = idx / k4; c[u] = idx - r[u] * k4; }            // W [N][K]: a thread reads 16 bytes of one row (K % 4 == 0)
             else { c[u] = idx / (16 * MT); r[u] = idx - c[u] * (16 * MT); }               // W [K][N]: lanes along the out-features (coalesced), four k per thread
-            const bool in = r[u] < rows && 4 * c[u] < K;
+            const int kc = 4 * (c0 + c[u]);                                               // first of the four k of this group
+            const bool in = r[u] < rows && kc < K;
             if constexpr (!TRANS) {
-                v[u] = *reinterpret_cast<const f32x4 *>(W + (size_t)(n0 + (in ? r[u] : 0)) * K + (in ? 4 * c[u] : 0));
+                v[u] = *reinterpret_cast<const f32x4 *>(W + (size_t)(n0 + (in ? r[u] : 0)) * K + (in ? kc : 0));
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[u][i] = W[(size_t)(in ? 4 * c[u] + i : 0) * N + n0 + (in ? r[u] : 0)];
+                for (int i = 0; i < 4; ++i) v[u][i] = W[(size_t)(in ? kc + i : 0) * N + n0 + (in ? r[u] : 0)];
             }
             if (!in) v[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
@@ -104,8 +106,10 @@ __device__ __forceinline__ void lx_stage(const float *__restrict__ W, const floa
             else if (cc < 4) lx_put4(smem + (size_t)s_ * SL + tl * 1024 + cc * 128 + rj * 8, PL, v[u]);
         }
     }
-    float *Bs = reinterpret_cast<float *>(smem + (size_t)nsteps * SL);
-    for (int i = tid; i < 16 * MT; i += kLxNT) Bs[i] = (bias && n0 + i < N) ? bias[n0 + i] : 0.0f;
+}
+template <int MT>
+__device__ __forceinline__ void lx_stage_bias(const float *__restrict__ bias, int N, int n0, float *Bs) {
+    for (int i = threadIdx.x; i < 16 * MT; i += kLxNT) Bs[i] = (bias && n0 + i < N) ? bias[n0 + i] : 0.0f;
 }
 
 // ---- one 32-deep k-step of a wave: X fragments (already masked) split into planes, weight fragments one tile ahead through two named buffers.  The
@@ -230,7 +234,8 @@ linear_fwd_x6t_kernel(const float *__restrict__ X, const float *__restrict__ W, 
     constexpr int PL = MT * 1024, SL = 3 * PL;
     const int K = a.K, R = a.R;
     const int n0 = blockIdx.y * 16 * MT;
-    lx_stage<MT, TRANS>(W, bias, K, a.N, n0, NFULL, NS, smem_lx);
+    lx_stage<MT, TRANS>(W, K, a.N, n0, NFULL, NS, smem_lx);
+    lx_stage_bias<MT>(bias, a.N, n0, reinterpret_cast<float *>(smem_lx + (size_t)NS * SL));
     __syncthreads();
     const float *Bs = reinterpret_cast<const float *>(smem_lx + (size_t)NS * SL);
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6;
@@ -326,7 +331,8 @@ linear_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ W, c
     const bool tail = (K16 & 31) != 0;                        // one 16-deep k-step behind the nfull 32-deep ones
     const int nsteps = nfull + (tail ? 1 : 0);
     const int n0 = blockIdx.y * 16 * MT;
-    lx_stage<MT, TRANS>(W, bias, K, a.N, n0, nfull, nsteps, smem_lx);
+    lx_stage<MT, TRANS>(W, K, a.N, n0, nfull, nsteps, smem_lx);
+    lx_stage_bias<MT>(bias, a.N, n0, reinterpret_cast<float *>(smem_lx + (size_t)nsteps * SL));
     __syncthreads();
     const float *Bs = reinterpret_cast<const float *>(smem_lx + (size_t)nsteps * SL);
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6;
@@ -420,6 +426,94 @@ linear_fwd_x6_kernel(const float *__restrict__ X, const float *__restrict__ W, c
     }
 }
 
+
+// =====================================================================================================================================================
+// The chunked form (any K, r6): the LDS image holds kLxKC k-steps of the weights at a time; per ROUND (one tile per wave) the workgroup walks the chunks —
+// barrier, re-split the chunk (36 weights per thread), barrier, multiply — with the accumulators of the tile in registers across the chunks.  Serves the layers
+// whose whole-K image does not fit (512 -> 136, the backward-input of the Q|K|V projection over 408) and 256 -> 512 (8 output tiles x 4 blocks instead of 6 x 6).
+// The X fragments of a chunk (kLxKC x 16 registers) are requested in front of the staging and consumed behind it.
+constexpr int kLxKC = 4;
+template <int MT, bool TRANS, bool GATE>
+__global__ void __launch_bounds__(kLxNT)
+linear_fwd_x6c_kernel(const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, const float *__restrict__ gate, LinArgs a,
+                      float *__restrict__ Y) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_lx[];
+    constexpr int RT = kLxRT, KC = kLxKC;
+    constexpr int PL = MT * 1024, SL = 3 * PL;
+    const int K = a.K, R = a.R;
+    const int K16 = (K + 15) & ~15, nfull = K16 >> 5;
+    const bool tail = (K16 & 31) != 0;
+    const int nsteps = nfull + (tail ? 1 : 0), nchunks = (nsteps + KC - 1) / KC;
+    const int n0 = blockIdx.y * 16 * MT;
+    float *Bs = reinterpret_cast<float *>(smem_lx + (size_t)KC * SL);
+    lx_stage_bias<MT>(bias, a.N, n0, Bs);
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, wave = tid >> 6;
+    const int ntiles = (R + 16 * RT - 1) / (16 * RT);
+    const LxEpi epi = lx_epi(a, gate, Y, n0);
+    const uint32_t afrag = lx_lds_addr(smem_lx) + g * 256 + j * 16;
+    const uint32_t afrag_t = lx_lds_addr(smem_lx) + g * 128 + j * 8;               // + (local step) SL
+    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int tiles_per_round = gridDim.x * kLxNW;
+    const int nrounds = (ntiles + tiles_per_round - 1) / tiles_per_round;          // every wave walks every round: the chunk loop holds workgroup barriers
+    for (int round = 0; round < nrounds; ++round) {
+        const int tile = round * tiles_per_round + blockIdx.x * kLxNW + wave;
+        int row[RT];
+        const float *xrow[RT];
+        bool rok[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            row[rt] = tile * 16 * RT + 16 * rt + j;                                 // a wave without a tile: rows past R, nothing loaded for real, nothing stored
+            rok[rt] = tile < ntiles && row[rt] < R;
+            xrow[rt] = X + (size_t)(rok[rt] ? row[rt] : R - 1) * a.ldx;
+        }
+        f32x4 acc[MT][RT];
+        for (int c = 0; c < nchunks; ++c) {
+            // ---- this chunk's X fragments (clamped addresses, selected below), in front of the staging
+            f32x4 xs[KC][RT][2];
+#pragma unroll
+            for (int s = 0; s < KC; ++s) {
+                const int S = KC * c + s;
+                const bool full = S < nfull, last = tail && S == nfull;
+                const int k0 = (full ? 32 * S : 32 * nfull) + 4 * g;
+                const int ka = ((full || last) && k0 < K) ? k0 : 0, kb = (full && k0 + 16 < K) ? k0 + 16 : 0;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    xs[s][rt][0] = *reinterpret_cast<const f32x4 *>(xrow[rt] + ka);
+                    xs[s][rt][1] = *reinterpret_cast<const f32x4 *>(xrow[rt] + kb);
+                }
+            }
+            __syncthreads();                                                        // every wave is done with the previous chunk's image
+            const int steps_here = min(KC, nsteps - KC * c), full_here = min(max(nfull - KC * c, 0), KC);
+            lx_stage<MT, TRANS>(W, K, a.N, n0, full_here, steps_here, smem_lx, 8 * KC * c);
+            __syncthreads();
+            if (c == 0) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(Bs + 16 * mt + 4 * g);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) acc[mt][rt] = b4;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < KC; ++s) {
+                const int S = KC * c + s;
+                if (S >= nsteps) break;                                             // uniform
+                const bool full = S < nfull;
+                const int k0 = (full ? 32 * S : 32 * nfull) + 4 * g;
+                f32x4 x[RT][2];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    x[rt][0] = (rok[rt] && k0 < K) ? xs[s][rt][0] : zero4;
+                    x[rt][1] = (rok[rt] && full && k0 + 16 < K) ? xs[s][rt][1] : zero4;
+                }
+                if (full) lx_kstep<MT>(afrag + s * SL, x, acc);
+                else lx_ktail<MT>(afrag_t + s * SL, x, acc);
+            }
+        }
+        lx_store<MT, GATE>(epi, acc, row, rok, g);
+    }
+}
+
 }  // namespace
 
 int launch_linear_x6(bool trans, const float *X, const float *W, const float *bias, const float *gate, const LinArgs &a, float *Y, int num_cus,
@@ -429,7 +523,7 @@ int launch_linear_x6(bool trans, const float *X, const float *W, const float *bi
     if (!on) return -1;
     const int K = a.K, N = a.N, R = a.R;
     // served: K <= 256 in 16-byte rows (the fp32 X fragments are 16-byte loads), weights readable as 16-byte rows in the forward orientation
-    if (K > 256 || (K & 3) || (a.ldx & 3) || (reinterpret_cast<uintptr_t>(X) & 15)) return -1;
+    if ((K & 3) || (a.ldx & 3) || (reinterpret_cast<uintptr_t>(X) & 15)) return -1;
     if (!trans && (reinterpret_cast<uintptr_t>(W) & 15)) return -1;
     if (R < 1024) return -1;                                  // small batches: the fp32 kernel's 16-row tiles fill the machine better
     // outputs (and the gate) as 16-byte pieces through 32-bit buffer offsets: aligned, N % 4 == 0, below 2 GB
@@ -437,13 +531,23 @@ int launch_linear_x6(bool trans, const float *X, const float *W, const float *bi
     const bool gated = a.act == PTR_LINEAR_GATE;
     if (gated && (!trans || (a.ldg & 3) || (reinterpret_cast<uintptr_t>(gate) & 15) || (size_t)R * a.ldg * 4 >= 0x80000000ull)) return -1;
     const int n16 = (N + 15) / 16;
-    const int per_tile = lx_steps(K) * 3 * 1024;              // LDS bytes of one 16-row tile of the weight image
+    if (n16 < 4) return -1;                                   // narrow outputs stay with the fp32 kernel
+    int per_tile = lx_steps(K) * 3 * 1024;                    // LDS bytes of one 16-row tile of the whole-K weight image
     int mt_max = (150 * 1024) / (per_tile + 64);
     if (mt_max > 9) mt_max = 9;
-    if (mt_max < 4) return -1;
-    const int nby = (n16 + mt_max - 1) / mt_max;
+    int nby = mt_max >= 4 ? (n16 + mt_max - 1) / mt_max : 99;
+    bool chunked = false;
+    // X streams once per block of outputs: up to 3 blocks with the whole-K image, 4 when it still holds >= 8 tiles (136 -> 512: chunking a K of 4.5 k-steps
+    // re-splits the weights twice per round for half a k-step of work — measured slower than the fp32 kernel); otherwise chunk K
+    if (mt_max < 4 || nby > (mt_max >= 8 ? 4 : 3)) {
+        chunked = true;
+        per_tile = kLxKC * 3 * 1024;
+        mt_max = n16 <= 9 ? 9 : 8;                            // 9 x 12 KB = 108 KB; wider outputs in blocks of 8 tiles
+        nby = (n16 + mt_max - 1) / mt_max;
+        if (nby > 4 || K <= 64) return -1;
+    }
     const int MT = (n16 + nby - 1) / nby;
-    if (MT < 4 || nby > 3) return -1;                         // narrow outputs stay with the fp32 kernel; X streams once per block of outputs
+    if (MT < 4) return -1;
     const size_t lds = (size_t)MT * per_tile + (size_t)64 * MT;
     const int ntiles = (R + 16 * kLxRT - 1) / (16 * kLxRT);
     int gx = num_cus / nby;
@@ -455,6 +559,14 @@ int launch_linear_x6(bool trans, const float *X, const float *W, const float *bi
         return check_hip(hipGetLastError(), who);
     };
     const int K16 = (K + 15) & ~15, nfull = K16 >> 5, tail = (K16 & 31) != 0;
+    if (chunked) {
+#define LXC_CASE(M)                                                                                                                             \
+    case M:                                                                                                                                      \
+        return !trans ? go(linear_fwd_x6c_kernel<M, false, false>) : (gated ? go(linear_fwd_x6c_kernel<M, true, true>) : go(linear_fwd_x6c_kernel<M, true, false>));
+        switch (MT) { LXC_CASE(4) LXC_CASE(5) LXC_CASE(6) LXC_CASE(7) LXC_CASE(8) LXC_CASE(9) }
+#undef LXC_CASE
+        return -1;
+    }
     // instantiated: forward (no gate), backward-input without and with the gate
     if (on != 2 && MT >= 7) {                                 // the whole-tile form: 97..144 inputs (K16 = 112, 128, 144), 7..9 output tiles
 #define LXT_CASE(M, NF, TL)                                                                                                                     \

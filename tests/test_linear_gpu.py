@@ -264,7 +264,9 @@ def _x6_lin_err(out, ref):
 
 
 @pytest.mark.parametrize("R,K,N", [(4133, 136, 136), (2049, 136, 408), (1024, 100, 100), (70003, 100, 100), (3000, 128, 256), (1500, 136, 128), (5000, 112, 112),
-                                   (2500, 144, 144), (1777, 64, 100), (1200, 200, 136), (3001, 256, 96), (66000, 36, 200), (1030, 16, 64), (2000, 132, 120)])
+                                   (2500, 144, 144), (1777, 64, 100), (1200, 200, 136), (3001, 256, 96), (66000, 36, 200), (1030, 16, 64), (2000, 132, 120),
+                                   # the chunked form (K in chunks of 128): whole-K image too large, or too few output tiles per block with it
+                                   (2000, 512, 136), (1500, 256, 512), (1100, 300, 200), (1024, 408, 136), (40000, 512, 136), (1300, 700, 100)])
 @pytest.mark.parametrize("act", [0, 1, 2])
 def test_linear_forward_bf16x6_matches_float64_and_the_fp32_kernel(R, K, N, act, monkeypatch):
     """Y = epi(X W^T + b) through `ptr_linear_forward`: the bf16x6 kernels (whole-tile form: K16 in {112, 128, 144} with 7-9 output tiles; general form: the
@@ -303,11 +305,11 @@ def test_linear_forward_bf16x6_matches_float64_and_the_fp32_kernel(R, K, N, act,
 
 
 @pytest.mark.parametrize("R,K,N", [(4133, 136, 136), (1500, 128, 136), (1024, 100, 100), (70003, 100, 100), (3000, 256, 128), (2049, 136, 408), (1777, 100, 64),
-                                   (2500, 144, 144), (1200, 136, 200)])
+                                   (2500, 144, 144), (1200, 136, 200), (1500, 136, 512), (1200, 200, 300), (40000, 136, 408)])
 @pytest.mark.parametrize("gated", [False, True])
 def test_linear_backward_input_bf16x6_matches_float64_and_the_fp32_kernel(R, K, N, gated, monkeypatch):
     """dX = (dY W) * [gate > 0] / (1 - p) through `ptr_linear_backward_input` (the same kernels on W^T; the gate read through a buffer resource): layer
-    K inputs -> N outputs, so the product contracts over N (<= 256 for the bf16x6 forms; 408 stays on the fp32 kernel in every mode)."""
+    K inputs -> N outputs, so the product contracts over N (whole-N weight image up to 256, the chunked form beyond: 408, 512, 300)."""
     from ptranking_amd.linear import _bwd_input
     torch.manual_seed(R + K + N)
     dy = torch.randn(R, N, device="cuda")
