@@ -29,8 +29,8 @@ using lds_i16x4_l = __attribute__((address_space(3))) i16x4;
 
 constexpr int kL6S = 32;                         // rows per slab
 constexpr int kL6CT = 24;                        // wide tiles per pass (384 columns); r6: CT = 8 (128 columns) for the products whose wide side is that small
-// wide image: 768 B per row padded to 800, or 256 padded to 288 (both = 32 mod 256: conflict-free transpose reads)
-__host__ __device__ constexpr int l6_wrs(int CT) { return CT == 24 ? 800 : 288; }
+// wide image: 768 B per row padded to 800, 512 to 544, or 256 to 288 (all = 32 mod 256: conflict-free transpose reads)
+__host__ __device__ constexpr int l6_wrs(int CT) { return CT == 24 ? 800 : CT == 16 ? 544 : 288; }      // 768 / 512 / 256 B of tiles + 32
 __host__ __device__ constexpr int l6_nrs(int MT) { return MT == 9 ? 288 : 224; }             // narrow image row stride (bytes): 144 / 112 bf16, both = +-32 mod 256
 // CT = 8: the column-sum scratch of the epilogue lies over the wide image (dead by then) — 49 / 55 KB per workgroup, two workgroups per CU
 __host__ __device__ constexpr int l6_lds(int MT, int CT) { return 3 * kL6S * l6_wrs(CT) + 3 * kL6S * l6_nrs(MT) + (CT == 24 ? kL6S * 16 * MT * 4 : 0); }
@@ -58,19 +58,23 @@ __device__ __forceinline__ void l6_write4(uint32_t addr, int plane_bytes, const 
 // r6, CT = 8: ONE wide tile per wave, <= 128 registers, two workgroups per CU.  The slab loop is stage (VALU split) -> barrier -> MFMAs -> barrier with the next
 // slab's loads in flight behind the first barrier; with one wide tile per wave the MFMA phase is 42-54 instructions and a slab took 3.2 us of which the matrix
 // pipe worked 0.3: a second workgroup per CU runs its stage while the first multiplies (default pointsf's 100 x 100 layers: 51 -> 3x us per call).
-template <int MT, int CT>
-__global__ void __launch_bounds__(512, CT == 24 ? 1 : 2)
+// r6, CT = 16 with NW = 16 waves: the waves 0-7 / 8-15 split the narrow tiles (even / odd), a wave holds 2 wide x 5 narrow accumulators (<= 128 registers, four
+// waves per SIMD): the staging pass is issued by twice the waves and the MFMA phase is half as long per wave — for products with 9..16 wide tiles per pass.
+template <int MT, int CT, int NW>
+__global__ void __launch_bounds__(NW * 64, CT == 8 ? 2 : 1)
 linear_bw_x6_kernel(const float *__restrict__ Zn, int ldn, int NN, int ones, const float *__restrict__ Aw, int ldw, int KW, int tile0, int ntp, int R,
                     float *__restrict__ ws, size_t ws_stride, size_t s_n, size_t s_w, size_t bias_off, int colsum) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_l6[];
     constexpr int NRS = l6_nrs(MT), NPL = kL6S * NRS;
     constexpr int kL6WRS = l6_wrs(CT), kL6WPL = kL6S * kL6WRS, NWT = CT / 8;      // NWT: wide tiles per wave (W, W + 8, ..)
     constexpr int WW4 = CT * 4;                            // float4 per wide-slice row (96 / 32)
-    constexpr int SW = kL6S * WW4 / 512;                   // wide load slots per thread (6 / 2)
+    constexpr int NT = NW * 64, HALVES = NW / 8, MTL = (MT + HALVES - 1) / HALVES;      // HALVES: groups of 8 waves sharing the wide tiles, each with every HALVES-th narrow tile
+    constexpr int SW = (kL6S * WW4 + NT - 1) / NT;         // wide load slots per thread (6 / 2)
     constexpr int ZW4 = 4 * MT;                            // float4 per narrow row (28 / 36)
-    constexpr int SZ = (kL6S * ZW4 + 511) / 512;           // narrow load slots per thread (2 / 3)
-    constexpr int kW_ = 0, kZ_ = 3 * kL6WPL, kB_ = CT == 24 ? kZ_ + 3 * NPL : 0;
-    const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, W = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int SZ = (kL6S * ZW4 + NT - 1) / NT;         // narrow load slots per thread (2 / 3)
+    constexpr int kW_ = 0, kZ_ = 3 * kL6WPL, kB_ = CT == 24 ? kZ_ + 3 * NPL : 0;      // CT = 8 / 16: the column-sum scratch lies over the (dead) wide image
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, Wall = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W = Wall & 7, half = Wall >> 3;               // wide tiles W, W + 8, ..; narrow tiles half, half + HALVES, ..
     const int chunk = ((R + gridDim.x - 1) / gridDim.x + kL6S - 1) / kL6S * kL6S;
     const int r_begin = blockIdx.x * chunk, r_end = min(R, r_begin + chunk);
     const int col0 = 16 * tile0, colE = min(KW, col0 + 16 * ntp);        // this pass: wide columns [col0, colE), ntp <= 24 tiles
@@ -78,11 +82,11 @@ linear_bw_x6_kernel(const float *__restrict__ Zn, int ldn, int NN, int ones, con
 
     // slot geometry recomputed at each use from an opaque thread index (hoisted it costs the registers the accumulators need)
     auto wgeo = [&](int s, int t_, int &row, int &col, bool &ok) __attribute__((always_inline)) {
-        const int idx = s * 512 + t_;
-        row = idx / WW4; col = col0 + 4 * (idx % WW4); ok = col < colE;
+        const int idx = s * NT + t_;
+        row = idx / WW4; col = col0 + 4 * (idx % WW4); ok = col < colE && idx < kL6S * WW4;
     };
     auto zgeo = [&](int s, int t_, int &row, int &col, bool &in, bool &ok) __attribute__((always_inline)) {
-        const int idx = s * 512 + t_;
+        const int idx = s * NT + t_;
         in = idx < kL6S * ZW4; row = in ? idx / ZW4 : 0; col = in ? 4 * (idx % ZW4) : 0; ok = col < NN;
     };
     f32x4 rw[SW], rz[SZ], zsum[SZ];
@@ -150,11 +154,11 @@ linear_bw_x6_kernel(const float *__restrict__ Zn, int ldn, int NN, int ones, con
     const uint32_t tr_w = lds0 + (uint32_t)(kW_ + (4 * g + (j >> 2)) * kL6WRS + 8 * (j & 3));
     const uint32_t tr_z = lds0 + (uint32_t)(kZ_ + (4 * g + (j >> 2)) * NRS + 8 * (j & 3));
 
-    f32x4 acc[NWT][MT];
+    f32x4 acc[NWT][MTL];
 #pragma unroll
     for (int n = 0; n < NWT; ++n)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[n][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ml = 0; ml < MTL; ++ml) acc[n][ml] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if (r_begin < r_end) gload(r_begin);
     for (int r0 = r_begin; r0 < r_end; r0 += kL6S) {
@@ -166,21 +170,22 @@ linear_bw_x6_kernel(const float *__restrict__ Zn, int ldn, int NN, int ones, con
         for (int n = 0; n < NWT; ++n)
             if (W + 8 * n < ntp) read_tr(xb[n], tr_w, kL6WPL, kL6WRS, W + 8 * n);        // wave-uniform: a wave multiplies only the tiles the pass holds
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            if (W >= ntp) break;
+        for (int ml = 0; ml < MTL; ++ml) {
+            const int mt = ml * HALVES + half;
+            if (W >= ntp || mt >= MT) break;
             LFrag za[3];
             read_tr(za, tr_z, NPL, NRS, mt);
 #pragma unroll
             for (int n = 0; n < NWT; ++n) {
                 if (W + 8 * n >= ntp) continue;
-                f32x4 c = acc[n][mt];
+                f32x4 c = acc[n][ml];
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[0].v, xb[n][2].v, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[1].v, xb[n][1].v, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[2].v, xb[n][0].v, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[0].v, xb[n][1].v, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[1].v, xb[n][0].v, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[0].v, xb[n][0].v, c, 0, 0, 0);
-                acc[n][mt] = c;
+                acc[n][ml] = c;
             }
         }
         __syncthreads();
@@ -190,13 +195,14 @@ linear_bw_x6_kernel(const float *__restrict__ Zn, int ldn, int NN, int ones, con
     for (int n = 0; n < NWT; ++n) {
         const int k = col0 + 16 * (W + 8 * n) + j;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int ml = 0; ml < MTL; ++ml)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
+                const int mt = ml * HALVES + half;
                 const int o = 16 * mt + 4 * g + c;
-                if (k < colE && W + 8 * n < ntp) {
-                    if (o < NN) part[(size_t)o * s_n + (size_t)k * s_w] = acc[n][mt][c];
-                    else if (ones && o == NN) part[bias_off + k] = acc[n][mt][c];
+                if (k < colE && W + 8 * n < ntp && mt < MT) {
+                    if (o < NN) part[(size_t)o * s_n + (size_t)k * s_w] = acc[n][ml][c];
+                    else if (ones && o == NN) part[bias_off + k] = acc[n][ml][c];
                 }
             }
     }
@@ -271,21 +277,25 @@ int launch_lin_bw_x6(int plan, const float *X, int ldx, const float *dY, int ldy
             hipLaunchKernelGGL(kern, dim3(chunks), dim3(512), lds, st, Zn, ldn, NN, ones, Aw, ldw, KW, 0, T, R, ws, n, s_n, s_w, (size_t)N * K, plan == 1 ? 1 : 0);
             return check_hip(hipGetLastError(), who);
         };
-        return mt == 7 ? go8(linear_bw_x6_kernel<7, 8>, 7) : go8(linear_bw_x6_kernel<9, 8>, 9);
+        return mt == 7 ? go8(linear_bw_x6_kernel<7, 8, 8>, 7) : go8(linear_bw_x6_kernel<9, 8, 8>, 9);
     }
-    auto go = [&](auto kern, int MT) -> int {
-        const size_t lds = (size_t)l6_lds(MT, kL6CT);
+    // 9+ wide tiles: passes of <= 16 tiles on the 16-wave form (PTR_LIN_BW_FORM=24: the 8-wave / 24-tile form, A/B measurements)
+    const char *fe = getenv("PTR_LIN_BW_FORM");
+    const int ct = (fe && atoi(fe) == 24) ? 24 : 16;
+    auto go = [&](auto kern, int MT, int CT, int threads) -> int {
+        const size_t lds = (size_t)l6_lds(MT, CT);
         if (int e = allow_lds(kern, lds)) return e;
-        // balanced passes: ceil(T / 24) of them, each ceil(T / passes) tiles wide (26 tiles: 13 + 13, not 24 + 2)
-        const int passes = (T + kL6CT - 1) / kL6CT, tpp = (T + passes - 1) / passes;
+        // balanced passes: ceil(T / CT) of them, each ceil(T / passes) tiles wide (26 tiles: 13 + 13, not 24 + 2)
+        const int passes = (T + CT - 1) / CT, tpp = (T + passes - 1) / passes;
         for (int t0 = 0; t0 < T; t0 += tpp) {
-            hipLaunchKernelGGL(kern, dim3(chunks), dim3(512), lds, st, Zn, ldn, NN, ones, Aw, ldw, KW, t0, T - t0 < tpp ? T - t0 : tpp, R, ws, n, s_n, s_w,
+            hipLaunchKernelGGL(kern, dim3(chunks), dim3(threads), lds, st, Zn, ldn, NN, ones, Aw, ldw, KW, t0, T - t0 < tpp ? T - t0 : tpp, R, ws, n, s_n, s_w,
                                (size_t)N * K, (plan == 1 && t0 == 0) ? 1 : 0);
             if (int e = check_hip(hipGetLastError(), who)) return e;
         }
         return 0;
     };
-    return mt == 7 ? go(linear_bw_x6_kernel<7, kL6CT>, 7) : go(linear_bw_x6_kernel<9, kL6CT>, 9);
+    if (ct == 16) return mt == 7 ? go(linear_bw_x6_kernel<7, 16, 16>, 7, 16, 1024) : go(linear_bw_x6_kernel<9, 16, 16>, 9, 16, 1024);
+    return mt == 7 ? go(linear_bw_x6_kernel<7, kL6CT, 8>, 7, kL6CT, 512) : go(linear_bw_x6_kernel<9, kL6CT, 8>, 9, kL6CT, 512);
 }
 
 }  // namespace ptr
