@@ -349,3 +349,34 @@ def test_linear_bf16x6_reads_strided_rows_and_is_bit_stable():
     assert torch.equal(y1, y2)
     ref = x.double().cpu() @ w.double().cpu().t() + b.double().cpu()
     close(y1, ref, tol=5e-6, what="strided x6")
+
+
+@pytest.mark.parametrize("R,K,N", [(4133, 136, 136), (2050, 512, 136), (3000, 128, 256), (1500, 200, 96)])
+def test_linear_bf16x6_writes_strided_outputs_in_place(R, K, N, monkeypatch):
+    """Y (forward) and dX (backward-input, with a strided gate) as column slices of wider buffers through the raw C ABI: only the slice is written (the buffer
+    stores of linear_x6.hip drop a lane by an out-of-range offset — a wrong leading dimension there would scribble over the neighbours), whole-tile, general
+    and chunked forms."""
+    import ctypes as C
+    from ptranking_amd import _lib
+    torch.manual_seed(R + K)
+    x = torch.randn(R, K, device="cuda"); w = torch.randn(N, K, device="cuda") / K ** 0.5; b = torch.randn(N, device="cuda")
+    ldy = N + 8
+    for mode in ("1", "2", "0"):
+        monkeypatch.setenv("PTR_LIN_X6", mode)
+        ybuf = torch.full((R, ldy), 7.25, device="cuda")
+        y = ybuf[:, 4:4 + N]
+        _lib.call("ptr_linear_forward", _lib.ptr(x), K, _lib.ptr(w), _lib.ptr(b), R, K, N, 0, C.c_float(0.0), C.c_uint64(0), 0, _lib.ptr(y), ldy,
+                  _lib.current_stream(x.device))
+        torch.cuda.synchronize()
+        assert bool((ybuf[:, :4] == 7.25).all()) and bool((ybuf[:, 4 + N:] == 7.25).all()), mode
+        close(y, x.double().cpu() @ w.double().cpu().t() + b.double().cpu(), tol=5e-6, what=f"strided y mode {mode}")
+        # backward-input: dX[R][K] = dY[R][N] W, gated by a strided gate, into a strided dX
+        dy = torch.randn(R, N, device="cuda")
+        gbuf = torch.randn(R, K + 4, device="cuda"); gate = gbuf[:, 4:]
+        dbuf = torch.full((R, K + 12), -3.5, device="cuda"); dx = dbuf[:, 8:8 + K]
+        _lib.call("ptr_linear_backward_input", _lib.ptr(dy), N, _lib.ptr(w), R, K, N, _lib.ptr(gate), K + 4, C.c_float(0.2), _lib.ptr(dx), K + 12,
+                  _lib.current_stream(x.device))
+        torch.cuda.synchronize()
+        assert bool((dbuf[:, :8] == -3.5).all()) and bool((dbuf[:, 8 + K:] == -3.5).all()), mode
+        ref = (dy.double().cpu() @ w.double().cpu()) * (gate.cpu() > 0).double() / 0.8
+        close(dx, ref, tol=5e-6, what=f"strided dx mode {mode}")
