@@ -114,7 +114,7 @@ int launch_bwd_x6_tail(const float *params, const float *acts, const float *dpre
 
 // ---- bf16x6 row contraction dW of the first layer for wide inputs (scorer_dw_x6.hip); interface of mlp_bwd_dw_lds_kernel
 bool dw_x6_supported(int R, int K, int lda, const void *A);
-int launch_dw_x6(const float *A, int lda, const float *dZ, int K, int nt_base, const MlpArgs &a, float *ws, size_t np_stride, size_t w_off, size_t b_off,
+int launch_dw_x6(const float *A, int lda, const float *dZ, int K, int ntk, const MlpArgs &a, float *ws, size_t np_stride, size_t w_off, size_t b_off,
                  int nblk, hipStream_t st, const char *who);
 
 // ---- internals the one-call train step (train_step.hip) chains: the extern "C" entry points with the image hand-over of r6

@@ -1334,7 +1334,7 @@ int ptr::mlp_backward_impl(const char *who, const float *X, const float *params,
             if (aligned) {
                 if (ntk <= 12) e = dw_rb() == 32 ? go_lds(mlp_bwd_dw_lds_kernel<3, true, 32>, 3, 32, 0) : go_lds(mlp_bwd_dw_lds_kernel<3, true, 16>, 3, 16, 0);
                 else if (dw_x6_supported(R, K, lda, A))   // wide inputs: the bf16x6 row contraction (scorer_dw_x6.hip), same partial layout
-                    for (int base = 0; base < ntk && !e; base += 24) e = launch_dw_x6(A, lda, dZ, K, base, a, ws, NP, off_W(l, F), off_b(l, F), nblk, st, who);
+                    e = launch_dw_x6(A, lda, dZ, K, ntk, a, ws, NP, off_W(l, F), off_b(l, F), nblk, st, who);
                 else for (int base = 0; base < ntk && !e; base += 24) e = go_lds(mlp_bwd_dw_lds_kernel<6, true, 16>, 6, 16, base);
             } else if (ntk <= 12) e = go(mlp_bwd_dw_kernel<3, true, 4>, 0);
             else if (ntk <= 24) e = go(mlp_bwd_dw_kernel<6, true, 4>, 0);

@@ -35,12 +35,13 @@ using lds_u32x2_d = __attribute__((address_space(3))) u32x2;
 using lds_i16x4_d = __attribute__((address_space(3))) i16x4;
 
 constexpr int kD6S = 32;                         // rows per slab
-constexpr int kD6CT = 24;                        // column tiles per pass (384 columns)
-constexpr int kD6XRS = 800, kD6XPL = kD6S * kD6XRS;      // X image: 384 bf16 = 768 B per row, padded to 800 (= 32 mod 256)
+// column tiles per pass: 24 (384 columns, eight waves x three tiles: r4 / r5) or — r6, where it costs no extra pass — 16 (sixteen waves: waves 0-7 / 8-15 share the column tiles
+// W, W + 8 and split the seven dZ tiles even / odd; 2 x 4 accumulators per wave, <= 128 registers, four waves per SIMD: the staging pass is issued by twice the
+// waves and a wave's MFMA phase is 2 x 4 instead of 3 x 7 tile products — linear_bw_x6.hip's 16-wave form, measured there)
+__host__ __device__ constexpr int d6_xrs(int CT) { return CT == 24 ? 800 : 544; }      // X image: 768 / 512 B per row, padded by 32 (= 32 mod 256)
 constexpr int kD6ZRS = 224, kD6ZPL = kD6S * kD6ZRS;      // dZ image: 112 bf16 per row
-constexpr int kD6_X = 0, kD6_Z = 3 * kD6XPL, kD6_B = kD6_Z + 3 * kD6ZPL;         // bias scratch: 32 x 112 floats
-constexpr int kD6Lds = kD6_B + kD6S * kAL * 4;
-static_assert(kD6Lds <= 160 * 1024, "LDS budget");
+__host__ __device__ constexpr int d6_lds(int CT) { return 3 * kD6S * d6_xrs(CT) + 3 * kD6ZPL + kD6S * kAL * 4; }      // + bias scratch: 32 x 112 floats
+static_assert(d6_lds(24) <= 160 * 1024 && d6_lds(16) <= 160 * 1024, "LDS budget");
 
 __device__ __forceinline__ uint32_t d6_cvt_pk(float x0, float x1) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{x0, x1}, bf16x2)); }
 __device__ __forceinline__ void d6_split2(float x0, float x1, uint32_t &p1, uint32_t &p2, uint32_t &p3) {
@@ -59,17 +60,21 @@ __device__ __forceinline__ void d6_write4(uint32_t addr, int plane_bytes, const 
     for (int p = 0; p < 3; ++p) *reinterpret_cast<lds_u32x2_d *>((uintptr_t)(addr + (uint32_t)(p * plane_bytes))) = u32x2{a[p], b[p]};
 }
 
-template <bool SITE0>
-__global__ void __launch_bounds__(512, 1)
+template <bool SITE0, int CT, int NW>
+__global__ void __launch_bounds__(NW * 64, 1)
 mlp_bwd_dw_x6_kernel(const float *__restrict__ A, int lda, const float *__restrict__ dZ, int K, int nt_base, MlpArgs a, float *__restrict__ ws,
                      size_t np_stride, size_t w_off, size_t b_off) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_d6[];
-    constexpr int XW4 = kD6CT * 4;                         // float4 per X-slice row (96)
-    constexpr int SX = kD6S * XW4 / 512;                   // X load slots per thread (6)
+    constexpr int NT = NW * 64, NWT = CT / 8, HALVES = NW / 8, MTL = (kMT + HALVES - 1) / HALVES;
+    constexpr int kD6XRS = d6_xrs(CT), kD6XPL = kD6S * kD6XRS;
+    constexpr int kD6_X = 0, kD6_Z = 3 * kD6XPL, kD6_B = kD6_Z + 3 * kD6ZPL;
+    constexpr int XW4 = CT * 4;                            // float4 per X-slice row (96 / 64)
+    constexpr int SX = (kD6S * XW4 + NT - 1) / NT;         // X load slots per thread (6 / 2)
     constexpr int ZW4 = kAL / 4;                           // float4 per dZ row (28)
-    constexpr int SZ = (kD6S * ZW4 + 511) / 512;           // dZ load slots per thread (2, the second one 3/4 used)
+    constexpr int SZ = (kD6S * ZW4 + NT - 1) / NT;         // dZ load slots per thread (2 / 1, the last one partly used)
     const int R = a.R;
-    const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, W = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4, Wall = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W = Wall & 7, half = Wall >> 3;               // column tiles W, W + 8, ..; dZ tiles half, half + HALVES, ..
     const int chunk = ((R + gridDim.x - 1) / gridDim.x + kD6S - 1) / kD6S * kD6S;
     const int r_begin = blockIdx.x * chunk, r_end = min(R, r_begin + chunk);
     const uint32_t thr = drop_thr(a.p_drop);
@@ -80,11 +85,11 @@ mlp_bwd_dw_x6_kernel(const float *__restrict__ A, int lda, const float *__restri
     // slot geometry is RECOMPUTED at each use from an opaque copy of the thread index: hoisted out of the slab loop it costs ~24 registers this
     // kernel does not have (21 accumulator tiles + 9 + 3 fragments + 8 prefetch registers)
     auto xgeo = [&](int s, int t_, int &row, int &col, bool &ok) __attribute__((always_inline)) {
-        const int idx = s * 512 + t_;
-        row = idx / XW4; col = col0 + 4 * (idx % XW4); ok = col < K;      // K % 4 == 0 on this path: a float4 is inside the row or beyond it
+        const int idx = s * NT + t_;
+        row = idx / XW4; col = col0 + 4 * (idx % XW4); ok = col < K && idx < kD6S * XW4;      // K % 4 == 0 on this path: a float4 is inside the row or beyond it
     };
     auto zgeo = [&](int s, int t_, int &row, int &col, bool &ok) __attribute__((always_inline)) {
-        const int idx = s * 512 + t_;
+        const int idx = s * NT + t_;
         ok = idx < kD6S * ZW4; row = ok ? idx / ZW4 : 0; col = ok ? 4 * (idx % ZW4) : 0;
     };
     f32x4 rx[SX], rz[SZ], zsum[SZ];
@@ -157,34 +162,36 @@ mlp_bwd_dw_x6_kernel(const float *__restrict__ A, int lda, const float *__restri
     const uint32_t tr_x = lds0 + (uint32_t)(kD6_X + (4 * g + (j >> 2)) * kD6XRS + 8 * (j & 3));
     const uint32_t tr_z = lds0 + (uint32_t)(kD6_Z + (4 * g + (j >> 2)) * kD6ZRS + 8 * (j & 3));
 
-    f32x4 acc[3][kMT];
+    f32x4 acc[NWT][MTL];
 #pragma unroll
-    for (int n = 0; n < 3; ++n)
+    for (int n = 0; n < NWT; ++n)
 #pragma unroll
-        for (int mt = 0; mt < kMT; ++mt) acc[n][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ml = 0; ml < MTL; ++ml) acc[n][ml] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if (r_begin < r_end) gload(r_begin);
     for (int r0 = r_begin; r0 < r_end; r0 += kD6S) {
         stage(r0);
         __syncthreads();
         if (r0 + kD6S < r_end) gload(r0 + kD6S);           // next slab in flight under this slab's MFMAs
-        DFrag xb[3][3];
+        DFrag xb[NWT][3];
 #pragma unroll
-        for (int n = 0; n < 3; ++n) read_tr(xb[n], tr_x, kD6XPL, kD6XRS, W + 8 * n);
+        for (int n = 0; n < NWT; ++n) read_tr(xb[n], tr_x, kD6XPL, kD6XRS, W + 8 * n);
 #pragma unroll
-        for (int mt = 0; mt < kMT; ++mt) {
+        for (int ml = 0; ml < MTL; ++ml) {
+            const int mt = ml * HALVES + half;
+            if (mt >= kMT) break;                          // wave-uniform
             DFrag za[3];
             read_tr(za, tr_z, kD6ZPL, kD6ZRS, mt);
 #pragma unroll
-            for (int n = 0; n < 3; ++n) {
-                f32x4 c = acc[n][mt];
+            for (int n = 0; n < NWT; ++n) {
+                f32x4 c = acc[n][ml];
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[0].v, xb[n][2].v, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[1].v, xb[n][1].v, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[2].v, xb[n][0].v, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[0].v, xb[n][1].v, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[1].v, xb[n][0].v, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[0].v, xb[n][0].v, c, 0, 0, 0);
-                acc[n][mt] = c;
+                acc[n][ml] = c;
             }
         }
         __syncthreads();
@@ -192,14 +199,15 @@ mlp_bwd_dw_x6_kernel(const float *__restrict__ A, int lda, const float *__restri
     // partials: dW[o][k], o = 16 mt + 4 g + c (rows of the D tile), k = this wave's column (lane j of the D tile)
     float *out = ws + (size_t)blockIdx.x * np_stride + w_off;
 #pragma unroll
-    for (int n = 0; n < 3; ++n) {
+    for (int n = 0; n < NWT; ++n) {
         const int k = col0 + 16 * (W + 8 * n) + j;
 #pragma unroll
-        for (int mt = 0; mt < kMT; ++mt)
+        for (int ml = 0; ml < MTL; ++ml)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
+                const int mt = ml * HALVES + half;
                 const int o = 16 * mt + 4 * g + c;
-                if (k < K && o < kH) out[(size_t)o * K + k] = acc[n][mt][c];
+                if (k < K && o < kH && mt < kMT) out[(size_t)o * K + k] = acc[n][ml][c];
             }
     }
     if (nt_base == 0) {                                    // d bias = column sums of dZ: per-thread sums over the slabs, then over the 32 slab rows
@@ -220,12 +228,22 @@ mlp_bwd_dw_x6_kernel(const float *__restrict__ A, int lda, const float *__restri
     }
 }
 
-int launch_dw_x6(const float *A, int lda, const float *dZ, int K, int nt_base, const MlpArgs &a, float *ws, size_t np_stride, size_t w_off, size_t b_off,
+// all passes over the ntk column tiles of the layer.  The sixteen-wave form when it needs no more passes than the eight-wave / 24-tile form (every pass re-reads and
+// re-splits dZ): F = 700 = 44 tiles is 2 passes of 24 against 3 of 16 — config 4 measured 1.858 ms against 1.881 with the extra pass.  PTR_DW_X6_FORM=16 / 24 forces a form.
+int launch_dw_x6(const float *A, int lda, const float *dZ, int K, int ntk, const MlpArgs &a, float *ws, size_t np_stride, size_t w_off, size_t b_off,
                  int nblk, hipStream_t st, const char *who) {
-    auto kern = mlp_bwd_dw_x6_kernel<true>;
-    if (int e = allow_lds(kern, kD6Lds)) return e;
-    hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), kD6Lds, st, A, lda, dZ, K, nt_base, a, ws, np_stride, w_off, b_off);
-    return check_hip(hipGetLastError(), who);
+    const char *fe = getenv("PTR_DW_X6_FORM");
+    const int forced = fe ? atoi(fe) : 0;
+    const bool f24 = forced == 24 || (forced != 16 && (ntk + 15) / 16 > (ntk + 23) / 24);
+    auto go = [&](auto kern, int ct, int threads) -> int {
+        if (int e = allow_lds(kern, d6_lds(ct))) return e;
+        for (int base = 0; base < ntk; base += ct) {
+            hipLaunchKernelGGL(kern, dim3(nblk), dim3(threads), d6_lds(ct), st, A, lda, dZ, K, base, a, ws, np_stride, w_off, b_off);
+            if (int e = check_hip(hipGetLastError(), who)) return e;
+        }
+        return 0;
+    };
+    return f24 ? go(mlp_bwd_dw_x6_kernel<true, 24, 8>, 24, 512) : go(mlp_bwd_dw_x6_kernel<true, 16, 16>, 16, 1024);
 }
 
 // PTR_DW_X6: "0" never, "1" (default) the first layer's dW of wide inputs (more than 12 column tiles, i.e. F > 192) from 32768 rows on, "2" always

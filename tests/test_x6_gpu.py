@@ -329,3 +329,34 @@ def test_x6_wide_dw_matches_float64_modules_and_the_fp32_kernel(F, NL, R, p, mon
         if i >= 2:                                                                                # untouched kernels: the same bits
             assert torch.equal(grads["2"][off:off + n], grads["0"][off:off + n]), i
         off += n
+
+
+@pytest.mark.parametrize("F,R", [(700, 1111), (400, 40000), (256, 3333)])
+def test_x6_wide_dw_forms_are_bit_identical(F, R, monkeypatch):
+    """The sixteen-wave / 16-tile and the eight-wave / 24-tile form of the bf16x6 first-layer dW (PTR_DW_X6_FORM) distribute the SAME tile products over
+    different waves and passes: every partial accumulates its 32-row slabs in the same order, so the gradients are bit-identical."""
+    from ptranking_amd import _lib
+    from ptranking_amd.scorer import FusedPointScorer
+    torch.manual_seed(R + F)
+    NL, p = 3, 0.1
+    fused = FusedPointScorer(F, num_layers=NL, dropout=p).cuda()
+    fused.train()
+    X = torch.randn(R, F, device="cuda")
+    w = torch.randn(R, device="cuda")
+    preds = torch.empty(R, device="cuda")
+    acts = _scorer.alloc_acts(R, NL, "cuda")
+    st = _lib.current_stream(X.device)
+    _lib.call("ptr_mlp_forward", _lib.ptr(X), _lib.ptr(fused.flat.data), R, F, NL, 1, C.c_float(p), C.c_uint64(77), _lib.ptr(preds), _lib.ptr(acts), st)
+    ws = torch.empty(_lib.query("ptr_mlp_backward_ws_floats", F, NL), device="cuda")
+    dz = torch.empty(max(1, _lib.query("ptr_mlp_backward_dz_floats", R, F, NL)), device="cuda")
+    monkeypatch.setenv("PTR_DW_X6", "2")
+    out = {}
+    for form in ("16", "24"):
+        monkeypatch.setenv("PTR_DW_X6_FORM", form)
+        g = torch.full_like(fused.flat.data, float("nan"))
+        _lib.call("ptr_mlp_backward", _lib.ptr(X), _lib.ptr(fused.flat.data), _lib.ptr(acts), _lib.ptr(w), R, F, NL, C.c_float(p), C.c_uint64(77),
+                  _lib.ptr(dz), _lib.ptr(ws), _lib.ptr(g), st)
+        torch.cuda.synchronize()
+        assert not torch.isnan(g).any()
+        out[form] = g.clone()
+    assert torch.equal(out["16"], out["24"])
