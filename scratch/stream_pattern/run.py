@@ -17,6 +17,9 @@ cases = [(0, "16 rows x 64 B, rows of 144 floats (576 B)", X, Y, N + 8, 2 * 18 *
          (2, "8 rows x 128 B, rows of 192 floats (768 B)", Xw, Yw, 192, 2 * 20 * 1024 * (R // 32)),
          (3, "4 rows x 256 B, rows of 192 floats (768 B)", Xw, Yw, 192, 2 * 24 * 1024 * (R // 32)),
          (0, "16 rows x 64 B, rows of 192 floats (768 B)", Xw, Yw, 192, 2 * 18 * 1024 * (R // 32))]
+cases += [(4, "16 rows x 64 B, rows of 128 floats (like for like)", Xa, Ya, 128, 2 * 16 * 1024 * (R // 32)),
+          (5, "8 rows x 128 B, rows of 128 floats (like for like)", Xa, Ya, 128, 2 * 16 * 1024 * (R // 32)),
+          (6, "4 rows x 256 B, rows of 128 floats (like for like)", Xa, Ya, 128, 2 * 16 * 1024 * (R // 32))]
 for mode, name, xx, yy, ldx, nbytes in cases:
     for waves, wg_per_cu in ((8, 1), (16, 2)):
         grid = 256 * wg_per_cu

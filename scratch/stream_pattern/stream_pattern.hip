@@ -41,6 +41,10 @@ extern "C" int run_stream(int mode, int waves, int grid, const float *X, float *
     if (mode == 0) stream_kernel<0, 18, 18><<<grid, waves * 64, 0, s>>>(X, Y, ldx, ldy, ntiles, rows_per_tile);
     else if (mode == 1) stream_kernel<1, 17, 17><<<grid, waves * 64, 0, s>>>(X, Y, ldx, ldy, ntiles, rows_per_tile);
     else if (mode == 2) stream_kernel<2, 20, 20><<<grid, waves * 64, 0, s>>>(X, Y, ldx, ldy, ntiles, rows_per_tile);      // 4 row groups x 5 column groups of 32 (160 >= 136: padded buffers)
-    else stream_kernel<3, 24, 24><<<grid, waves * 64, 0, s>>>(X, Y, ldx, ldy, ntiles, rows_per_tile);                       // 8 row groups x 3 column groups of 64 (192 columns: padded)
+    else if (mode == 3) stream_kernel<3, 24, 24><<<grid, waves * 64, 0, s>>>(X, Y, ldx, ldy, ntiles, rows_per_tile);        // 8 row groups x 3 column groups of 64 (192 columns: padded)
+    // like for like on 128-column rows (512 B, every piece aligned, every byte touched): 16 instructions per 32 x 128 tile either way
+    else if (mode == 4) stream_kernel<0, 16, 16><<<grid, waves * 64, 0, s>>>(X, Y, ldx, ldy, ntiles, rows_per_tile);        // 16 rows x 64 B
+    else if (mode == 5) stream_kernel<2, 16, 16><<<grid, waves * 64, 0, s>>>(X, Y, ldx, ldy, ntiles, rows_per_tile);        // 8 rows x 128 B
+    else stream_kernel<3, 16, 16><<<grid, waves * 64, 0, s>>>(X, Y, ldx, ldy, ntiles, rows_per_tile);                       // 4 rows x 256 B
     return (int)hipGetLastError();
 }
